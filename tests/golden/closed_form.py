@@ -1,0 +1,67 @@
+"""Closed-form (RNG-free) test inputs shared by the fixture generator and the parity tests.
+
+Formulas are those of SURVEY.md Appendix B; every tensor is built from float64 index grids and
+cast to float32, so the build container and the GPU box construct bit-identical inputs.
+"""
+import math
+
+import torch
+
+
+def _grid(B, C, h, w):
+    b = torch.arange(B, dtype=torch.float64).view(B, 1, 1, 1)
+    c = torch.arange(C, dtype=torch.float64).view(1, C, 1, 1)
+    i = torch.arange(h, dtype=torch.float64).view(1, 1, h, 1)
+    j = torch.arange(w, dtype=torch.float64).view(1, 1, 1, w)
+    return b, c, i, j
+
+
+def feat(B, C, h, w, ph):
+    b, c, i, j = _grid(B, C, h, w)
+    return torch.sin(0.1 * (b + 1) * (c + 1) + 0.37 * i + 0.11 * j + ph).float()
+
+
+def flow(B, H, W, s):
+    b, _, i, j = _grid(B, 1, H, W)
+    fx = s * (1.5 * torch.sin(0.02 * i) + 0.5 * b + 1) + 0 * j
+    fy = s * (-torch.cos(0.03 * j) - 0.25 * b) + 0 * i
+    return torch.cat([fx, fy], 1).float()
+
+
+def occ(B, H, W, k):
+    b, _, i, j = _grid(B, 1, H, W)
+    v = (torch.floor(i / 8) + torch.floor(j / 8) + b) % k == 0
+    return v[:, 0].float()
+
+
+def base_case(N=4, H=64, W=64):
+    """The N=4, 64x64 case of Appendix B."""
+    d = {}
+    d["fwd"] = flow(N, H, W, +1.0)
+    d["bwd"] = flow(N, H, W, -1.0)
+    d["x"] = feat(N, 3, H, W, 0.0)
+    d["imgs"] = feat(N, 3, H, W, 0.5)
+    d["fo"] = occ(N, H, W, 5)
+    d["bo"] = occ(N, H, W, 7)
+    d["sal"] = torch.sigmoid(feat(N, 1, H // 2, W // 2, 1.0))
+    d["lat"] = feat(2 * N, 8, 8, 8, 0.2)
+    return d
+
+
+def attn_weights(C):
+    """W_k[i,j] = sin(0.05 i (k+1) + 0.07 j + k)/sqrt(C), k = 0..3 for (q,k,v,out); out bias 0."""
+    i = torch.arange(C, dtype=torch.float64).view(C, 1)
+    j = torch.arange(C, dtype=torch.float64).view(1, C)
+    return [(torch.sin(0.05 * i * (k + 1) + 0.07 * j + k) / math.sqrt(C)).float() for k in range(4)]
+
+
+def attn_hidden(B, HW, C, phase=0.0):
+    b = torch.arange(B, dtype=torch.float64).view(B, 1, 1)
+    p = torch.arange(HW, dtype=torch.float64).view(1, HW, 1)
+    c = torch.arange(C, dtype=torch.float64).view(1, 1, C)
+    return torch.sin(0.3 * (b + 1) + 0.05 * p + 0.21 * c + phase).float()
+
+
+def checksum(t):
+    t = t.double()
+    return float(t.sum()), float(t.abs().sum())
