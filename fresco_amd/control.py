@@ -1,0 +1,116 @@
+"""AttentionControl: mode flags + reference-feature store of FRESCO-guided attention.
+
+Same public attributes, methods and state transitions as the reference class
+(src/diffusion_hacked.py:23-137): the denoising loop (src/pipe_FRESCO.py:171-174) and the batch driver
+(run_fresco.py:231) toggle it by name, and the shared processor relies on the cyclic read index that
+advances once per self-attention layer.
+"""
+import gc
+
+import torch
+
+
+class AttentionControl:
+    def __init__(self):
+        self.stored_attn = self.get_empty_store()
+        self.store = False
+        self.index = 0
+        self.attn_mask = None
+        self.interattn_paras = None
+        self.use_interattn = False
+        self.use_cfattn = False
+        self.use_intraattn = False
+        self.intraattn_bias = 0
+        self.intraattn_scale_factor = 0.2
+        self.interattn_scale_factor = 0.2
+
+    @staticmethod
+    def get_empty_store():
+        return {"decoder_attn": []}
+
+    def clear_store(self):
+        del self.stored_attn
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        gc.collect()
+        self.stored_attn = self.get_empty_store()
+        self.disable_intraattn()
+
+    # ---- collection of the input video's hidden states (diffusion_hacked.py:58-63) -------------
+    def enable_store(self):
+        self.store = True
+
+    def disable_store(self):
+        self.store = False
+
+    # ---- spatial-guided attention (diffusion_hacked.py:65-76) ----------------------------------
+    def enable_intraattn(self):
+        self.index = 0
+        self.use_intraattn = True
+        self.disable_store()
+        if len(self.stored_attn["decoder_attn"]) == 0:
+            self.use_intraattn = False  # nothing recorded: silently stays off
+
+    def disable_intraattn(self):
+        self.index = 0
+        self.use_intraattn = False
+        self.disable_store()
+
+    # ---- efficient cross-frame attention (diffusion_hacked.py:78-94) ---------------------------
+    def disable_cfattn(self):
+        self.use_cfattn = False
+
+    def enable_cfattn(self, attn_mask=None):
+        if attn_mask:
+            if self.attn_mask:
+                del self.attn_mask
+            self.attn_mask = attn_mask
+            self.use_cfattn = True
+        elif self.attn_mask:
+            self.use_cfattn = True
+        else:
+            print("Warning: no valid cross-frame attention parameters available!")
+            self.disable_cfattn()
+
+    # ---- temporal-guided attention (diffusion_hacked.py:96-112) --------------------------------
+    def disable_interattn(self):
+        self.use_interattn = False
+
+    def enable_interattn(self, interattn_paras=None):
+        if interattn_paras:
+            if self.interattn_paras:
+                del self.interattn_paras
+            self.interattn_paras = interattn_paras
+            self.use_interattn = True
+        elif self.interattn_paras:
+            self.use_interattn = True
+        else:
+            print("Warning: no valid temporal-guided attention parameters available!")
+            self.disable_interattn()
+
+    def disable_controller(self):
+        self.disable_intraattn()
+        self.disable_interattn()
+        self.disable_cfattn()
+
+    def enable_controller(self, interattn_paras=None, attn_mask=None):
+        self.enable_intraattn()
+        self.enable_interattn(interattn_paras)
+        self.enable_cfattn(attn_mask)
+
+    # ---- store / cyclic read (diffusion_hacked.py:123-137) -------------------------------------
+    def forward(self, context):
+        store = self.stored_attn["decoder_attn"]
+        if self.store:
+            store.append(context.detach())
+        if self.use_intraattn and len(store) > 0:
+            tmp = store[self.index]
+            self.index += 1
+            if self.index >= len(store):
+                self.index = 0
+                self.disable_store()
+            return tmp
+        return context
+
+    def __call__(self, context):
+        return self.forward(context)

@@ -1,0 +1,365 @@
+// Dense fp16 attention with shared key groups for FRESCO's spatial-guided and efficient
+// cross-frame passes (reference: src/diffusion_hacked.py:225-247, 250-254, 281-285, 303-305, 371).
+//
+// Two kernels:
+//   kv_pack_kernel  : gathers the selected K / V rows of one key group and writes them in the
+//                     tile order the MFMA loop consumes:  Kp[g][h][Mpad][DPK]  (rows = keys, head
+//                     dim zero-padded to a multiple of 16) and  Vt[g][h][DPV][Mpad]  (V transposed:
+//                     rows = head dim padded to a multiple of 32, keys contiguous).  HBM-bound.
+//   attn_flash_kernel: flash-style attention on v_mfma_f32_32x32x16_f16.  One wave owns 32 query
+//                     rows; S^T = K Q^T is computed "swapped" so that every lane holds the scores
+//                     of ONE query (its column of the 32x32 MFMA C tile): row max / row sum are
+//                     in-lane plus one cross-lane exchange with lane^32, and the exponentiated
+//                     scores are already laid out as the B operand of  O^T = V^T P^T.
+//                     K / V^T tiles of 64 keys are staged through double-buffered LDS whose row
+//                     strides are odd multiples of 16 B (conflict-free ds_read_b128).
+//
+// MFMA 32x32x16 f16 operand layout used below (gfx950): lane l supplies 8 consecutive k for
+// row/col (l & 31), k-chunk (l >> 5); C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
+#include "common.h"
+
+namespace fresco {
+
+template <int D>
+struct AttnCfg {
+    static constexpr int DPK = (D + 15) / 16 * 16;  // head dim padded for the QK^T contraction
+    static constexpr int DPV = (D + 31) / 32 * 32;  // head dim padded for the O^T row blocks
+    static constexpr int NKS = DPK / 16;            // MFMA k-steps per QK^T block
+    static constexpr int NDB = DPV / 32;            // 32-row blocks of O^T
+    static constexpr int NKC = DPK / 8;             // 16-byte chunks per K row
+    static constexpr int KROW = DPK * 2 + (((DPK * 2 / 16) % 2 == 0) ? 16 : 0);  // LDS bytes per K row
+    static constexpr int VROW = 64 * 2 + 16;                                     // LDS bytes per V^T row
+    static constexpr int KTILE = 64 * KROW;
+    static constexpr int VTILE = DPV * VROW;
+    static constexpr int LDS_BYTES = 2 * (KTILE + VTILE);
+    static constexpr int KCH = 64 * NKC;  // 16-byte chunks in a K tile
+    static constexpr int VCH = DPV * 8;   // 16-byte chunks in a V^T tile
+    static constexpr int KPT = (KCH + 255) / 256;
+    static constexpr int VPT = (VCH + 255) / 256;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+static inline int mpad_of(int M) { return (M + 63) / 64 * 64; }
+
+// ---------------------------------------------------------------------------------------------
+// pack: grid (Mpad/64, H, G), 256 threads
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__ k,
+                                                       const half_t* __restrict__ v,
+                                                       const int32_t* __restrict__ kv_rows,
+                                                       half_t* __restrict__ kp, half_t* __restrict__ vt,
+                                                       int H, int M, int Mpad, int64_t group_rows) {
+    using Cfg = AttnCfg<D>;
+    const int tile = blockIdx.x, h = blockIdx.y, g = blockIdx.z;
+    const int C = H * D;
+    __shared__ int32_t rows[64];
+    __shared__ __attribute__((aligned(16))) half_t vs[64][D + 8];  // +8 halfs: 16-B aligned rows
+
+    if (threadIdx.x < 64) {
+        const int m = tile * 64 + threadIdx.x;
+        int32_t r = -1;
+        if (m < M) r = kv_rows ? kv_rows[m] : m;
+        rows[threadIdx.x] = r;
+    }
+    __syncthreads();
+
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    // K: 64 keys x NKC chunks, written contiguously
+    half_t* kdst = kp + ((int64_t)(g * H + h) * Mpad + tile * 64) * Cfg::DPK;
+    for (int c = threadIdx.x; c < 64 * Cfg::NKC; c += 256) {
+        const int row = c / Cfg::NKC, dc = c % Cfg::NKC;
+        uint4 val = zero;
+        const int32_t r = rows[row];
+        if (r >= 0 && dc * 8 < D)
+            val = *reinterpret_cast<const uint4*>(k + ((int64_t)g * group_rows + r) * C + h * D + dc * 8);
+        *reinterpret_cast<uint4*>(kdst + (int64_t)c * 8) = val;
+    }
+    // V: stage the 64 x D slab, then write it transposed
+    for (int c = threadIdx.x; c < 64 * (D / 8); c += 256) {
+        const int row = c / (D / 8), dc = c % (D / 8);
+        uint4 val = zero;
+        const int32_t r = rows[row];
+        if (r >= 0)
+            val = *reinterpret_cast<const uint4*>(v + ((int64_t)g * group_rows + r) * C + h * D + dc * 8);
+        *reinterpret_cast<uint4*>(&vs[row][dc * 8]) = val;
+    }
+    __syncthreads();
+    half_t* vdst = vt + (int64_t)(g * H + h) * Cfg::DPV * Mpad + tile * 64;
+    for (int c = threadIdx.x; c < Cfg::DPV * 8; c += 256) {
+        const int d = c >> 3, kc = c & 7;
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (d < D) ? vs[kc * 8 + j][d] : (half_t)0;
+        *reinterpret_cast<half8_t*>(vdst + (int64_t)d * Mpad + kc * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// flash attention: grid (H * nQblk * B), 256 threads = 4 waves x 32 query rows
+// blockIdx.x = (b * nQblk + qblk) * H + h   -> head h lands on XCD (h % 8): each XCD's L2 holds
+// only its own heads' packed K / V^T.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restrict__ q,
+                                                          const half_t* __restrict__ kp,
+                                                          const half_t* __restrict__ vt,
+                                                          half_t* __restrict__ out, int B, int H, int Lq,
+                                                          int M, int Mpad, int batch_per_group,
+                                                          float scale_log2, float diag_bias_log2) {
+    using Cfg = AttnCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nQblk = (Lq + 127) / 128;
+    const int h = blockIdx.x % H;
+    const int qblk = (blockIdx.x / H) % nQblk;
+    const int b = blockIdx.x / (H * nQblk);
+    const int g = b / batch_per_group;
+    const int C = H * D;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qrow = qblk * 128 + wave * 32 + l31;
+    const int qrow_c = qrow < Lq ? qrow : Lq - 1;
+    // S^T row (lane & 31) is fed with key  swap_bits_2_3(lane & 31): the C-tile registers of a
+    // lane then hold keys 16*(r>>3) + 8*hi + (r&7), i.e. 8 consecutive keys per MFMA k-chunk.
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+
+    // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
+    half8_t qf[Cfg::NKS];
+    {
+        const half_t* qp = q + ((int64_t)b * Lq + qrow_c) * C + h * D;
+#pragma unroll
+        for (int ks = 0; ks < Cfg::NKS; ++ks) {
+            const int d0 = ks * 16 + hi * 8;
+            half8_t t = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (d0 < D) t = *reinterpret_cast<const half8_t*>(qp + d0);
+            qf[ks] = t;
+        }
+    }
+
+    const char* kg = reinterpret_cast<const char*>(kp + (int64_t)(g * H + h) * Mpad * Cfg::DPK);
+    const char* vg = reinterpret_cast<const char*>(vt + (int64_t)(g * H + h) * Cfg::DPV * Mpad);
+    const int nT = Mpad / 64;
+
+    u32x4 kst[Cfg::KPT], vst[Cfg::VPT];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < Cfg::KPT; ++i) {
+            int c = tid + i * 256;
+            if (Cfg::KCH % 256 != 0) c = c < Cfg::KCH ? c : 0;  // clamp: the load is unconditional
+            kst[i] = *reinterpret_cast<const u32x4*>(kg + ((int64_t)t * Cfg::KCH + c) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::VPT; ++i) {
+            int c = tid + i * 256;
+            if (Cfg::VCH % 256 != 0) c = c < Cfg::VCH ? c : 0;
+            const int d = c >> 3, kc = c & 7;
+            vst[i] = *reinterpret_cast<const u32x4*>(vg + ((int64_t)d * Mpad + t * 64 + kc * 8) * 2);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* kb = smem + buf * (Cfg::KTILE + Cfg::VTILE);
+        char* vb = kb + Cfg::KTILE;
+#pragma unroll
+        for (int i = 0; i < Cfg::KPT; ++i) {
+            const int c = tid + i * 256;
+            if (c < Cfg::KCH) {
+                const int row = c / Cfg::NKC, dc = c % Cfg::NKC;
+                *reinterpret_cast<u32x4*>(kb + row * Cfg::KROW + dc * 16) = kst[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::VPT; ++i) {
+            const int c = tid + i * 256;
+            if (c < Cfg::VCH) {
+                const int d = c >> 3, kc = c & 7;
+                *reinterpret_cast<u32x4*>(vb + d * Cfg::VROW + kc * 16) = vst[i];
+            }
+        }
+    };
+
+    floatx16 o[Cfg::NDB];
+#pragma unroll
+    for (int db = 0; db < Cfg::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -1e30f;  // running max, in the scaled log2 domain
+    float l_run = 0.f;     // this lane's half of the row sum (its 32 of every 64 keys)
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const bool need_diag = diag_bias_log2 != 0.f;
+    for (int t = 0; t < nT; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nT) load_tile(t + 1);
+
+        const char* kb = smem + buf * (Cfg::KTILE + Cfg::VTILE);
+        const char* vb = kb + Cfg::KTILE;
+
+        // ---- S^T = K Q^T : two 32-key blocks --------------------------------------------------
+        floatx16 s[2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kbk][r] = 0.f;
+            const char* kr = kb + (kbk * 32 + krow) * Cfg::KROW + hi * 16;
+#pragma unroll
+            for (int ks = 0; ks < Cfg::NKS; ++ks) {
+                const half8_t a = *reinterpret_cast<const half8_t*>(kr + ks * 32);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[kbk], 0, 0, 0);
+            }
+        }
+
+        // ---- rare paths: padded keys of the last tile, diagonal bias --------------------------
+        const bool tail = (t == nT - 1) && (Mpad != M);
+        if (tail || need_diag) {
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + kbk * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    float x = s[kbk][r];
+                    if (need_diag && key == qrow) x += diag_bias_log2 / scale_log2;
+                    if (key >= M) x = -1e30f / scale_log2;
+                    s[kbk][r] = x;
+                }
+        }
+
+        // ---- online softmax, one query per lane -----------------------------------------------
+        float mt = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt * scale_log2);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        half8_t pf[4];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(fmaf(s[kbk][r], scale_log2, -m_new));
+                psum += p;
+                pf[kbk * 2 + (r >> 3)][r & 7] = (half_t)p;
+            }
+        l_run = fmaf(l_run, alpha, psum);
+#pragma unroll
+        for (int db = 0; db < Cfg::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+        // ---- O^T += V^T P^T ---------------------------------------------------------------------
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const char* vr = vb + l31 * Cfg::VROW + (kc * 16 + hi * 8) * 2;
+#pragma unroll
+            for (int db = 0; db < Cfg::NDB; ++db) {
+                const half8_t a = *reinterpret_cast<const half8_t*>(vr + db * 32 * Cfg::VROW);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[kc], o[db], 0, 0, 0);
+            }
+        }
+
+        if (t + 1 < nT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow < Lq) {
+        half_t* op = out + ((int64_t)b * Lq + qrow) * C + h * D;
+#pragma unroll
+        for (int db = 0; db < Cfg::NDB; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = db * 32 + g4 * 8 + hi * 4;
+                if (d0 < D) {
+                    half4_t w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (half_t)(o[db][g4 * 4 + j] * inv);
+                    *reinterpret_cast<half4_t*>(op + d0) = w;
+                }
+            }
+    }
+}
+
+template <int D>
+static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const int32_t* kv_rows,
+                       half_t* out, char* ws, int B, int H, int Lq, int n_groups, int M,
+                       int64_t group_rows, float scale, float diag_bias, hipStream_t st) {
+    using Cfg = AttnCfg<D>;
+    const int Mpad = mpad_of(M);
+    half_t* kp = reinterpret_cast<half_t*>(ws);
+    half_t* vt = kp + (size_t)n_groups * H * Mpad * Cfg::DPK;
+    dim3 pg(Mpad / 64, H, n_groups);
+    hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, H, M, Mpad,
+                       group_rows);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        attr_set = true;
+    }
+    const int nQblk = (Lq + 127) / 128;
+    const float log2e = 1.4426950408889634f;
+    hipLaunchKernelGGL((attn_flash_kernel<D>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
+                       kp, vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e);
+    return check_launch();
+}
+
+static size_t attn_ws_bytes(int n_groups, int H, int M, int D) {
+    const size_t Mpad = mpad_of(M);
+    const size_t dpk = (D + 15) / 16 * 16, dpv = (D + 31) / 32 * 32;
+    return align_up((size_t)n_groups * H * Mpad * (dpk + dpv) * sizeof(half_t), 256);
+}
+
+}  // namespace fresco
+
+using namespace fresco;
+
+extern "C" size_t fresco_attn_workspace_bytes(int n_groups, int H, int M, int D) {
+    if (n_groups <= 0 || H <= 0 || M <= 0 || D <= 0) return 0;
+    return attn_ws_bytes(n_groups, H, M, D);
+}
+
+extern "C" int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* kv_rows,
+                               void* out, void* workspace, size_t workspace_bytes, int B, int H,
+                               int Lq, int D, int n_groups, int M, int64_t group_rows, float scale,
+                               float diag_bias, void* stream) {
+    if (!q || !k || !v || !out || !workspace) return FRESCO_EINVAL;
+    if (B <= 0 || H <= 0 || Lq <= 0 || D <= 0 || n_groups <= 0 || M <= 0 || group_rows <= 0)
+        return FRESCO_EINVAL;
+    if (B % n_groups != 0 || !(scale > 0.f)) return FRESCO_EINVAL;
+    if (workspace_bytes < attn_ws_bytes(n_groups, H, M, D)) return FRESCO_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const half_t* qh = static_cast<const half_t*>(q);
+    const half_t* kh = static_cast<const half_t*>(k);
+    const half_t* vh = static_cast<const half_t*>(v);
+    half_t* oh = static_cast<half_t*>(out);
+    char* ws = static_cast<char*>(workspace);
+#define FRESCO_ATTN_CASE(DD)                                                                       \
+    case DD:                                                                                       \
+        return launch_attn<DD>(qh, kh, vh, kv_rows, oh, ws, B, H, Lq, n_groups, M, group_rows, scale, \
+                               diag_bias, st);
+    switch (D) {
+        FRESCO_ATTN_CASE(8)
+        FRESCO_ATTN_CASE(16)
+        FRESCO_ATTN_CASE(32)
+        FRESCO_ATTN_CASE(40)
+        FRESCO_ATTN_CASE(64)
+        FRESCO_ATTN_CASE(80)
+        FRESCO_ATTN_CASE(96)
+        FRESCO_ATTN_CASE(128)
+        default:
+            return FRESCO_EUNSUPPORTED;
+    }
+#undef FRESCO_ATTN_CASE
+}

@@ -1,0 +1,729 @@
+// FRESCO feature optimisation (reference: src/diffusion_hacked.py:416-488), autograd-free, fp32.
+//
+//   L(cs) = 2*mean(|(c2 - W_b c1) mb| + |(c1 - W_f c2) mf|) + w*mean|V V^T - T|
+//   c1 = cs[f], c2 = cs[f+1 mod N], mb = 1-occ_b, mf = 1-occ_f, V = rows of cs (hw x C) L2-normalised.
+//
+// Gradients, per CFG half, frame f, with k = 2/(B*C*hw):
+//   s1[f] = sign((c2 - W_b[f] c1) mb[f]) mb[f] k,   s2[f] = sign((c1 - W_f[f] c2) mf[f]) mf[f] k
+//   dL/dcs[f] = s2[f] + s1[f-1] - W_b[f]^T s1[f] - W_f[f-1]^T s2[f-1]
+//   S = sign(V V^T - T) w/(B hw^2);  dV = (S + S^T) V = 2 S V (T symmetric);  dX = (dV - V <V,dV>)/|X|
+//
+// Kernels:
+//   csr_build      one block per (direction, frame): transposes the 4-tap bilinear matrix into CSR so
+//                  that W^T s is a deterministic gather (rows sorted by source pixel); entry weight
+//                  already carries mask[src]*k.  Built once per optimize_feature call.
+//   temporal_sign  signs of both residuals as int8 (HBM-bound, 4-tap gathers, taps shared by channels)
+//   temporal_grad  assembles dL/dcs of the temporal term from the int8 signs + CSR gathers
+//   colnorm        |X[p]| and V^T (C x hw: the NCHW plane layout IS V^T, so both MFMA operands of
+//                  V V^T are read with lanes along consecutive pixels)
+//   gram           128x128 tiles of V V^T on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain);
+//                  epilogue writes sign(G - T) as int8 (or G itself for the Gram target)
+//   sv             dV^T = 2 coef V^T S on the same MFMA (S in {-1,0,1}, exact)
+//   adam_update    norm backward + Adam step, fused, fp32 state
+#include "common.h"
+
+namespace fresco {
+
+// ------------------------------------------------------------------------------------------------
+// shared bilinear tap helper (same arithmetic as warp.hip: geometry.py:50-55,65-72)
+// ------------------------------------------------------------------------------------------------
+struct OTaps {
+    int idx[4];
+    float w[4];
+};
+
+__device__ __forceinline__ OTaps otaps(float fx, float fy, int x, int y, int h, int w) {
+    const float gx = 2.f * ((float)x + fx) / (float)(w - 1) - 1.f;
+    const float gy = 2.f * ((float)y + fy) / (float)(h - 1) - 1.f;
+    const float ix = ((gx + 1.f) / 2.f) * (float)(w - 1);
+    const float iy = ((gy + 1.f) / 2.f) * (float)(h - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float tx = ix - x0f, ty = iy - y0f;
+    const float x0c = fminf(fmaxf(x0f, -2.f), (float)w + 1.f);
+    const float y0c = fminf(fmaxf(y0f, -2.f), (float)h + 1.f);
+    const int x0 = (int)x0c, y0 = (int)y0c, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < w && x0f == x0c, vx1 = x1 >= 0 && x1 < w && x0f == x0c;
+    const bool vy0 = y0 >= 0 && y0 < h && y0f == y0c, vy1 = y1 >= 0 && y1 < h && y0f == y0c;
+    const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
+    const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+    OTaps t;
+    t.idx[0] = cy0 * w + cx0;
+    t.idx[1] = cy0 * w + cx1;
+    t.idx[2] = cy1 * w + cx0;
+    t.idx[3] = cy1 * w + cx1;
+    t.w[0] = (vx0 && vy0) ? (1.f - tx) * (1.f - ty) : 0.f;
+    t.w[1] = (vx1 && vy0) ? tx * (1.f - ty) : 0.f;
+    t.w[2] = (vx0 && vy1) ? (1.f - tx) * ty : 0.f;
+    t.w[3] = (vx1 && vy1) ? tx * ty : 0.f;
+    return t;
+}
+
+__device__ __forceinline__ float osample(const float* __restrict__ plane, const OTaps& t) {
+    return plane[t.idx[0]] * t.w[0] + plane[t.idx[1]] * t.w[1] + plane[t.idx[2]] * t.w[2] +
+           plane[t.idx[3]] * t.w[3];
+}
+
+__device__ __forceinline__ int sgn(float x) { return (x > 0.f) - (x < 0.f); }
+
+// ------------------------------------------------------------------------------------------------
+// CSR of W^T.  grid (N, 2): blockIdx.y = 0 -> bwd flow (samples c1), 1 -> fwd flow (samples c2).
+// rowptr: [2][N][hw+1], cursor: [2][N][hw] scratch, src: [2][N][4hw], wgt: [2][N][4hw]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void csr_build_kernel(const float* __restrict__ bwd_flow,
+                                                          const float* __restrict__ fwd_flow,
+                                                          const float* __restrict__ bwd_occ,
+                                                          const float* __restrict__ fwd_occ,
+                                                          int* __restrict__ rowptr, int* __restrict__ cursor,
+                                                          int* __restrict__ src, float* __restrict__ wgt,
+                                                          int N, int h, int w, float kscale) {
+    const int hw = h * w;
+    const int f = blockIdx.x, dir = blockIdx.y;
+    const float* flow = (dir == 0 ? bwd_flow : fwd_flow) + (int64_t)f * 2 * hw;
+    const float* occ = (dir == 0 ? bwd_occ : fwd_occ) + (int64_t)f * hw;
+    int* rp = rowptr + (int64_t)(dir * N + f) * (hw + 1);
+    int* cur = cursor + (int64_t)(dir * N + f) * hw;
+    int* sp = src + (int64_t)(dir * N + f) * 4 * hw;
+    float* wp = wgt + (int64_t)(dir * N + f) * 4 * hw;
+    const int tid = threadIdx.x;
+    __shared__ int scan_buf[1024];
+    __shared__ int carry;
+
+    for (int i = tid; i < hw; i += 1024) cur[i] = 0;
+    __syncthreads();
+    // count entries per target
+    for (int p = tid; p < hw; p += 1024) {
+        const OTaps t = otaps(flow[p], flow[hw + p], p % w, p / w, h, w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (t.w[j] != 0.f) atomicAdd(&cur[t.idx[j]], 1);
+    }
+    __syncthreads();
+    // exclusive scan -> rowptr
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < hw; base += 1024) {
+        const int i = base + tid;
+        const int val = i < hw ? atomicAdd(&cur[i], 0) : 0;  // counts were built by L2 atomics
+        scan_buf[tid] = val;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int add = tid >= off ? scan_buf[tid - off] : 0;
+            __syncthreads();
+            scan_buf[tid] += add;
+            __syncthreads();
+        }
+        const int incl = scan_buf[tid];
+        const int c0 = carry;
+        if (i < hw) rp[i] = c0 + incl - val;
+        __syncthreads();
+        if (tid == 1023) carry = c0 + incl;
+        __syncthreads();
+    }
+    if (tid == 0) rp[hw] = carry;
+    __syncthreads();
+    for (int i = tid; i < hw; i += 1024) cur[i] = rp[i];
+    __syncthreads();
+    // fill (arbitrary order within a row)
+    for (int p = tid; p < hw; p += 1024) {
+        const OTaps t = otaps(flow[p], flow[hw + p], p % w, p / w, h, w);
+        const float mk = (1.f - occ[p]) * kscale;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (t.w[j] != 0.f) {
+                const int pos = atomicAdd(&cur[t.idx[j]], 1);
+                sp[pos] = p;
+                wp[pos] = t.w[j] * mk;
+            }
+    }
+    __syncthreads();
+    // sort every row by source pixel -> deterministic summation order
+    for (int r = tid; r < hw; r += 1024) {
+        const int b = rp[r], e = rp[r + 1];
+        for (int i = b + 1; i < e; ++i) {
+            const int ks = sp[i];
+            const float kw = wp[i];
+            int j = i - 1;
+            while (j >= b && sp[j] > ks) {
+                sp[j + 1] = sp[j];
+                wp[j + 1] = wp[j];
+                --j;
+            }
+            sp[j + 1] = ks;
+            wp[j + 1] = kw;
+        }
+    }
+}
+
+constexpr int OCPT = 8;  // channels per thread in the temporal kernels
+
+// grid (ceil(hw/256), ceil(C/OCPT), chunk*N).  sgn1/sgn2: (chunk*N, C, hw) int8.
+// loss (optional): loss[0] += sum |r1| + |r2|  (unscaled)
+__global__ __launch_bounds__(256) void temporal_sign_kernel(
+    const float* __restrict__ cs, const float* __restrict__ bwd_flow, const float* __restrict__ fwd_flow,
+    const float* __restrict__ bwd_occ, const float* __restrict__ fwd_occ, int8_t* __restrict__ sgn1,
+    int8_t* __restrict__ sgn2, float* __restrict__ loss, int N, int C, int h, int w) {
+    const int hw = h * w;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z, ck = b / N, f = b % N;
+    const int fn = (f + 1) % N;
+    const int c0 = blockIdx.y * OCPT, cend = min(c0 + OCPT, C);
+    float lsum = 0.f;
+    if (p < hw) {
+        const float* fb = bwd_flow + (int64_t)f * 2 * hw;
+        const float* ff = fwd_flow + (int64_t)f * 2 * hw;
+        const OTaps tb = otaps(fb[p], fb[hw + p], p % w, p / w, h, w);
+        const OTaps tf = otaps(ff[p], ff[hw + p], p % w, p / w, h, w);
+        const float mb = 1.f - bwd_occ[(int64_t)f * hw + p];
+        const float mf = 1.f - fwd_occ[(int64_t)f * hw + p];
+        for (int c = c0; c < cend; ++c) {
+            const float* c1 = cs + ((int64_t)(ck * N + f) * C + c) * hw;
+            const float* c2 = cs + ((int64_t)(ck * N + fn) * C + c) * hw;
+            const float r1 = (c2[p] - osample(c1, tb)) * mb;
+            const float r2 = (c1[p] - osample(c2, tf)) * mf;
+            const int64_t o = ((int64_t)b * C + c) * hw + p;
+            sgn1[o] = (int8_t)sgn(r1);
+            sgn2[o] = (int8_t)sgn(r2);
+            lsum += fabsf(r1) + fabsf(r2);
+        }
+    }
+    if (loss) {
+        __shared__ float red[4];
+        const float tot = block_sum_256(lsum, red);
+        if (threadIdx.x == 0) atomicAdd(loss, tot);
+    }
+}
+
+// grad[b][c][p] = k mf[f][p] sgn2[f] + k mb[f-1][p] sgn1[f-1] - sum_rowB[f][p] w*sgn1[f][src]
+//                                                         - sum_rowF[f-1][p] w*sgn2[f-1][src]
+__global__ __launch_bounds__(256) void temporal_grad_kernel(
+    const int8_t* __restrict__ sgn1, const int8_t* __restrict__ sgn2, const float* __restrict__ bwd_occ,
+    const float* __restrict__ fwd_occ, const int* __restrict__ rowptr, const int* __restrict__ src,
+    const float* __restrict__ wgt, float* __restrict__ grad, int N, int C, int hw, float kscale) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const int b = blockIdx.z, ck = b / N, f = b % N;
+    const int fp = (f + N - 1) % N;
+    const int bp = ck * N + fp;
+    const int c0 = blockIdx.y * OCPT, cend = min(c0 + OCPT, C);
+    const float a2 = kscale * (1.f - fwd_occ[(int64_t)f * hw + p]);
+    const float a1 = kscale * (1.f - bwd_occ[(int64_t)fp * hw + p]);
+    const int* rpB = rowptr + (int64_t)(0 * N + f) * (hw + 1);
+    const int* rpF = rowptr + (int64_t)(1 * N + fp) * (hw + 1);
+    const int bB = rpB[p], eB = rpB[p + 1];
+    const int bF = rpF[p], eF = rpF[p + 1];
+    const int* sB = src + (int64_t)(0 * N + f) * 4 * hw;
+    const float* wB = wgt + (int64_t)(0 * N + f) * 4 * hw;
+    const int* sF = src + (int64_t)(1 * N + fp) * 4 * hw;
+    const float* wF = wgt + (int64_t)(1 * N + fp) * 4 * hw;
+    for (int c = c0; c < cend; ++c) {
+        const int8_t* s1f = sgn1 + ((int64_t)b * C + c) * hw;
+        const int8_t* s2f = sgn2 + ((int64_t)b * C + c) * hw;
+        const int8_t* s1p = sgn1 + ((int64_t)bp * C + c) * hw;
+        const int8_t* s2p = sgn2 + ((int64_t)bp * C + c) * hw;
+        float g = a2 * (float)s2f[p] + a1 * (float)s1p[p];
+        float adj = 0.f;
+        for (int e = bB; e < eB; ++e) adj = fmaf(wB[e], (float)s1f[sB[e]], adj);
+        float adj2 = 0.f;
+        for (int e = bF; e < eF; ++e) adj2 = fmaf(wF[e], (float)s2p[sF[e]], adj2);
+        grad[((int64_t)b * C + c) * hw + p] = g - adj - adj2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column norms + normalised copy.  block = 64 pixels x 4 channel slices; grid (ceil(hw/64), B)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colnorm_kernel(const float* __restrict__ cs, float* __restrict__ vt,
+                                                       float* __restrict__ nrm, int C, int hw) {
+    __shared__ float part[4][64];
+    const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + px;
+    const int b = blockIdx.y;
+    const float* x = cs + (int64_t)b * C * hw;
+    float acc = 0.f;
+    if (p < hw)
+        for (int c = sl; c < C; c += 4) {
+            const float t = x[(int64_t)c * hw + p];
+            acc = fmaf(t, t, acc);
+        }
+    part[sl][px] = acc;
+    __syncthreads();
+    const float n = sqrtf(part[0][px] + part[1][px] + part[2][px] + part[3][px]);
+    if (p < hw) {
+        if (sl == 0) nrm[(int64_t)b * hw + p] = n;
+        float* v = vt + (int64_t)b * C * hw;
+        for (int c = sl; c < C; c += 4) v[(int64_t)c * hw + p] = x[(int64_t)c * hw + p] / n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 MFMA GEMM core: block = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 2 x 2
+// MFMA 32x32x2 tiles, K chunk 16 staged in LDS as As[k][128], Bs[k][128] (lane-consecutive reads).
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+// C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+// ------------------------------------------------------------------------------------------------
+constexpr int GT = 128;  // block tile
+constexpr int GK = 16;   // K chunk
+
+struct GemmAcc {
+    floatx16 a[2][2];
+};
+
+__device__ __forceinline__ void gemm_zero(GemmAcc& acc) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.a[i][j][r] = 0.f;
+}
+
+__device__ __forceinline__ void gemm_chunk(GemmAcc& acc, const float (*As)[GT], const float (*Bs)[GT],
+                                           int wm, int wn, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < GK / 2; ++kk) {
+        const int k = kk * 2 + hi;
+        const float a0 = As[k][wm * 64 + l31], a1 = As[k][wm * 64 + 32 + l31];
+        const float b0 = Bs[k][wn * 64 + l31], b1 = Bs[k][wn * 64 + 32 + l31];
+        acc.a[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.a[0][0], 0, 0, 0);
+        acc.a[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.a[0][1], 0, 0, 0);
+        acc.a[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.a[1][0], 0, 0, 0);
+        acc.a[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.a[1][1], 0, 0, 0);
+    }
+}
+
+// loads GK rows x 128 contiguous floats:  dst[i] (i = 0..1) = 4 floats at row (tid/32 + 8*i), col (tid%32)*4
+// of the matrix with leading dimension ld whose tile origin is (row0, col0); zero outside [rows, cols).
+__device__ __forceinline__ void load_rowmajor_tile(const float* __restrict__ base, int64_t ld, int row0,
+                                                   int col0, int rows, int cols, bool vec_ok, int tid,
+                                                   floatx4 (&dst)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = row0 + (tid >> 5) + 8 * i;
+        const int c = col0 + (tid & 31) * 4;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            const float* p = base + (int64_t)r * ld + c;
+            if (vec_ok && c + 3 < cols) {
+                v = *reinterpret_cast<const floatx4*>(p);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < cols) v[j] = p[j];
+            }
+        }
+        dst[i] = v;
+    }
+}
+
+__device__ __forceinline__ void store_rowmajor_tile(float (*S)[GT], int tid, const floatx4 (&src)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<floatx4*>(&S[(tid >> 5) + 8 * i][(tid & 31) * 4]) = src[i];
+}
+
+// G = V V^T tile.  MODE 0: write int8 sign(G - T) (+ optional loss += sum|G - T|); MODE 1: write G.
+// grid (ceil(hw/128), ceil(hw/128), B)
+template <int MODE>
+__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ vt,
+                                                    const float* __restrict__ target,
+                                                    int8_t* __restrict__ sgn_out, float* __restrict__ g_out,
+                                                    float* __restrict__ loss, int C, int hw) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK][GT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.y * GT, q0 = blockIdx.x * GT;
+    const float* v = vt + (int64_t)b * C * hw;
+    const bool vec_ok = (hw % 4 == 0);
+
+    GemmAcc acc;
+    gemm_zero(acc);
+    floatx4 ra[2], rb[2];
+    const int nk = (C + GK - 1) / GK;
+    load_rowmajor_tile(v, hw, 0, p0, C, hw, vec_ok, tid, ra);
+    load_rowmajor_tile(v, hw, 0, q0, C, hw, vec_ok, tid, rb);
+    store_rowmajor_tile(As[0], tid, ra);
+    store_rowmajor_tile(Bs[0], tid, rb);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) {
+            load_rowmajor_tile(v, hw, (kc + 1) * GK, p0, C, hw, vec_ok, tid, ra);
+            load_rowmajor_tile(v, hw, (kc + 1) * GK, q0, C, hw, vec_ok, tid, rb);
+        }
+        gemm_chunk(acc, As[buf], Bs[buf], wm, wn, lane);
+        if (kc + 1 < nk) {
+            store_rowmajor_tile(As[buf ^ 1], tid, ra);
+            store_rowmajor_tile(Bs[buf ^ 1], tid, rb);
+        }
+        __syncthreads();
+    }
+
+    const int l31 = lane & 31, hi = lane >> 5;
+    float lsum = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = q0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = p0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < hw && col < hw) {
+                    const int64_t o = ((int64_t)b * hw + row) * hw + col;
+                    const float gval = acc.a[mi][ni][r];
+                    if (MODE == 0) {
+                        const float d = gval - target[o];
+                        sgn_out[o] = (int8_t)sgn(d);
+                        lsum += fabsf(d);
+                    } else {
+                        g_out[o] = gval;
+                    }
+                }
+            }
+        }
+    if (MODE == 0 && loss) {
+        __shared__ float red[4];
+        const float tot = block_sum_256(lsum, red);
+        if (tid == 0) atomicAdd(loss, tot);
+    }
+}
+
+// dV^T[c][p] = alpha * sum_q V^T[c][q] * S[q][p]   (S symmetric sign matrix, int8)
+// grid (ceil(hw/128), ceil(C/128), B)
+__global__ __launch_bounds__(256) void sv_kernel(const float* __restrict__ vt,
+                                                  const int8_t* __restrict__ sgn_in,
+                                                  float* __restrict__ dvt, int C, int hw, float alpha) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK][GT];  // As[k][c]
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GT];  // Bs[k][p]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * GT, p0 = blockIdx.x * GT;
+    const float* v = vt + (int64_t)b * C * hw;
+    const int8_t* s = sgn_in + (int64_t)b * hw * hw;
+    const bool vec_ok = (hw % 4 == 0);
+    const bool svec_ok = (hw % 16 == 0);
+
+    // A loader: thread -> (c = tid/2, 8 k's at (tid%2)*8): two float4 per thread
+    // B loader: thread -> (k = tid/16, 8 p's at (tid%16)*8): 8 int8 per thread
+    floatx4 ra[2];
+    float rb[8];
+    auto load_a = [&](int k0) {
+        const int c = c0 + (tid >> 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + (tid & 1) * 8 + i * 4;
+            floatx4 t = {0.f, 0.f, 0.f, 0.f};
+            if (c < C) {
+                const float* p = v + (int64_t)c * hw + k;
+                if (vec_ok && k + 3 < hw) {
+                    t = *reinterpret_cast<const floatx4*>(p);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k + j < hw) t[j] = p[j];
+                }
+            }
+            ra[i] = t;
+        }
+    };
+    auto load_b = [&](int k0) {
+        const int k = k0 + (tid >> 4);
+        const int p = p0 + (tid & 15) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[j] = 0.f;
+        if (k < hw) {
+            const int8_t* sp = s + (int64_t)k * hw + p;
+            if (svec_ok && p + 7 < hw) {
+                const int2 raw = *reinterpret_cast<const int2*>(sp);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    rb[j] = (float)(int8_t)((raw.x >> (8 * j)) & 0xff);
+                    rb[4 + j] = (float)(int8_t)((raw.y >> (8 * j)) & 0xff);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (p + j < hw) rb[j] = (float)sp[j];
+            }
+        }
+    };
+    auto store_ab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[buf][(tid & 1) * 8 + i * 4 + j][tid >> 1] = ra[i][j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[buf][tid >> 4][(tid & 15) * 8 + j] = rb[j];
+    };
+
+    GemmAcc acc;
+    gemm_zero(acc);
+    const int nk = (hw + GK - 1) / GK;
+    load_a(0);
+    load_b(0);
+    store_ab(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) {
+            load_a((kc + 1) * GK);
+            load_b((kc + 1) * GK);
+        }
+        gemm_chunk(acc, As[buf], Bs[buf], wm, wn, lane);
+        if (kc + 1 < nk) store_ab(buf ^ 1);
+        __syncthreads();
+    }
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = p0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < C && col < hw) dvt[((int64_t)b * C + row) * hw + col] = acc.a[mi][ni][r] * alpha;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// norm backward + Adam.  block = 64 pixels x 4 channel slices; grid (ceil(hw/64), B)
+//   g = grad_t (if has_t) + (dV - V <V,dV>)/|X| (if has_s)
+// mode 0: Adam update of cs, m, v;  mode 1: write g to gout (loss_grad entry)
+// ------------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float beta1, beta2, step_size, bc2_sqrt, eps;
+};
+
+__global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs, float* __restrict__ m,
+                                                           float* __restrict__ v2,
+                                                           const float* __restrict__ grad_t,
+                                                           const float* __restrict__ vt,
+                                                           const float* __restrict__ dvt,
+                                                           const float* __restrict__ nrm, float* __restrict__ gout,
+                                                           int C, int hw, int has_t, int has_s, int mode,
+                                                           AdamArgs a) {
+    __shared__ float part[4][64];
+    const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + px;
+    const int b = blockIdx.y;
+    const int64_t base = (int64_t)b * C * hw;
+    float dot = 0.f, inv_n = 0.f;
+    if (has_s) {
+        float acc = 0.f;
+        if (p < hw)
+            for (int c = sl; c < C; c += 4) {
+                const int64_t o = base + (int64_t)c * hw + p;
+                acc = fmaf(vt[o], dvt[o], acc);
+            }
+        part[sl][px] = acc;
+        __syncthreads();
+        dot = part[0][px] + part[1][px] + part[2][px] + part[3][px];
+        if (p < hw) inv_n = 1.f / nrm[(int64_t)b * hw + p];
+    }
+    if (p >= hw) return;
+    for (int c = sl; c < C; c += 4) {
+        const int64_t o = base + (int64_t)c * hw + p;
+        float g = has_t ? grad_t[o] : 0.f;
+        if (has_s) g += (dvt[o] - vt[o] * dot) * inv_n;
+        if (mode == 1) {
+            gout[o] = g;
+        } else {
+            const float mm = a.beta1 * m[o] + (1.f - a.beta1) * g;
+            const float vv = a.beta2 * v2[o] + (1.f - a.beta2) * g * g;
+            m[o] = mm;
+            v2[o] = vv;
+            const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
+            cs[o] = cs[o] - a.step_size * (mm / denom);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct OptWs {
+    float *grad, *m, *v, *vt, *dvt, *nrm, *wgt;
+    int8_t *sgn1, *sgn2, *ssign;
+    int *rowptr, *cursor, *src;
+};
+
+static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int h, int wd, int has_t,
+                            int has_s) {
+    const size_t B = (size_t)chunk * N, hw = (size_t)h * wd, E = B * C * hw;
+    // size query: lay out from a fake non-null base (no memory is touched)
+    if (!basep) basep = reinterpret_cast<char*>(static_cast<uintptr_t>(4096));
+    char* p = basep;
+    OptWs tmp;
+    tmp.m = carve<float>(p, E);
+    tmp.v = carve<float>(p, E);
+    tmp.grad = has_t ? carve<float>(p, E) : nullptr;
+    tmp.sgn1 = has_t ? carve<int8_t>(p, E) : nullptr;
+    tmp.sgn2 = has_t ? carve<int8_t>(p, E) : nullptr;
+    tmp.rowptr = has_t ? carve<int>(p, (size_t)2 * N * (hw + 1)) : nullptr;
+    tmp.cursor = has_t ? carve<int>(p, (size_t)2 * N * hw) : nullptr;
+    tmp.src = has_t ? carve<int>(p, (size_t)2 * N * 4 * hw) : nullptr;
+    tmp.wgt = has_t ? carve<float>(p, (size_t)2 * N * 4 * hw) : nullptr;
+    tmp.vt = has_s ? carve<float>(p, E) : nullptr;
+    tmp.dvt = has_s ? carve<float>(p, E) : nullptr;
+    tmp.nrm = has_s ? carve<float>(p, B * hw) : nullptr;
+    tmp.ssign = has_s ? carve<int8_t>(p, B * hw * hw) : nullptr;
+    if (w) *w = tmp;
+    return (size_t)(p - basep);
+}
+
+static int opt_check_grid(int chunk, int N, int C) {
+    if ((int64_t)chunk * N > 65535 || (C + OCPT - 1) / OCPT > 65535) return FRESCO_EUNSUPPORTED;
+    return FRESCO_OK;
+}
+
+// one closure evaluation; mode 0 = Adam step, mode 1 = write gradient to gout
+static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const float* bwd_flow,
+                        const float* fwd_occ, const float* bwd_occ, const float* target, int chunk, int N,
+                        int C, int h, int wd, float intra_weight, int has_t, int has_s, int mode,
+                        float* gout, float* loss, AdamArgs a, hipStream_t st) {
+    const int B = chunk * N, hw = h * wd;
+    const float kscale = 2.f / ((float)B * (float)C * (float)hw);
+    if (has_t) {
+        dim3 grid((hw + 255) / 256, (C + OCPT - 1) / OCPT, B);
+        hipLaunchKernelGGL(temporal_sign_kernel, grid, dim3(256), 0, st, cs, bwd_flow, fwd_flow, bwd_occ,
+                           fwd_occ, w.sgn1, w.sgn2, loss, N, C, h, wd);
+        hipLaunchKernelGGL(temporal_grad_kernel, grid, dim3(256), 0, st, w.sgn1, w.sgn2, bwd_occ, fwd_occ,
+                           w.rowptr, w.src, w.wgt, w.grad, N, C, hw, kscale);
+    }
+    if (has_s) {
+        hipLaunchKernelGGL(colnorm_kernel, dim3((hw + 63) / 64, B), dim3(256), 0, st, cs, w.vt, w.nrm, C, hw);
+        const int nt = (hw + GT - 1) / GT;
+        hipLaunchKernelGGL((gram_kernel<0>), dim3(nt, nt, B), dim3(256), 0, st, w.vt, target, w.ssign,
+                           (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
+        const float coef = intra_weight / ((float)B * (float)hw * (float)hw);
+        hipLaunchKernelGGL(sv_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vt, w.ssign, w.dvt, C,
+                           hw, 2.f * coef);
+    }
+    hipLaunchKernelGGL(adam_update_kernel, dim3((hw + 63) / 64, B), dim3(256), 0, st, cs, w.m, w.v, w.grad,
+                       w.vt, w.dvt, w.nrm, gout, C, hw, has_t, has_s, mode, a);
+}
+
+// loss[0], loss[1] hold raw sums after opt_closure; scale them to the reference's means
+__global__ void loss_finalize_kernel(float* loss, float s0, float s1) {
+    loss[0] *= s0;
+    loss[1] *= s1;
+}
+
+}  // namespace fresco
+
+using namespace fresco;
+
+extern "C" size_t fresco_opt_workspace_bytes(int chunk, int N, int C, int h, int w, int has_temporal,
+                                             int has_target) {
+    if (chunk <= 0 || N <= 0 || C <= 0 || h <= 0 || w <= 0) return 0;
+    return opt_ws_layout(nullptr, nullptr, chunk, N, C, h, w, has_temporal, has_target);
+}
+
+static int opt_common_checks(const float* cs, const float* fwd_flow, const float* bwd_flow,
+                             const float* fwd_occ, const float* bwd_occ, const float* target,
+                             void* workspace, size_t workspace_bytes, int chunk, int N, int C, int h, int w,
+                             int* has_t, int* has_s, float intra_weight) {
+    if (!cs || !workspace || chunk <= 0 || N <= 0 || C <= 0 || h <= 1 || w <= 1) return FRESCO_EINVAL;
+    const bool any_t = fwd_flow || bwd_flow || fwd_occ || bwd_occ;
+    const bool all_t = fwd_flow && bwd_flow && fwd_occ && bwd_occ;
+    if (any_t && !all_t) return FRESCO_EINVAL;
+    *has_t = all_t ? 1 : 0;
+    *has_s = (target && intra_weight > 0.f) ? 1 : 0;
+    if (!*has_t && !*has_s) return FRESCO_EINVAL;
+    if (int rc = opt_check_grid(chunk, N, C)) return rc;
+    if (workspace_bytes < opt_ws_layout(nullptr, nullptr, chunk, N, C, h, w, *has_t, *has_s))
+        return FRESCO_EWORKSPACE;
+    return FRESCO_OK;
+}
+
+static void opt_prepare(const OptWs& ws, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                        const float* bwd_occ, int chunk, int N, int C, int h, int w, int has_t,
+                        hipStream_t st) {
+    if (!has_t) return;
+    const int B = chunk * N, hw = h * w;
+    const float kscale = 2.f / ((float)B * (float)C * (float)hw);
+    hipLaunchKernelGGL(csr_build_kernel, dim3(N, 2), dim3(1024), 0, st, bwd_flow, fwd_flow, bwd_occ, fwd_occ,
+                       ws.rowptr, ws.cursor, ws.src, ws.wgt, N, h, w, kscale);
+}
+
+extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                              const float* bwd_occ, const float* target, void* workspace,
+                              size_t workspace_bytes, int chunk, int N, int C, int h, int w,
+                              float intra_weight, int iters, float lr, float beta1, float beta2, float eps,
+                              void* stream) {
+    int has_t = 0, has_s = 0;
+    if (int rc = opt_common_checks(cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, workspace,
+                                   workspace_bytes, chunk, N, C, h, w, &has_t, &has_s, intra_weight))
+        return rc;
+    if (iters < 0) return FRESCO_EINVAL;
+    hipStream_t st = as_stream(stream);
+    OptWs ws;
+    opt_ws_layout(&ws, static_cast<char*>(workspace), chunk, N, C, h, w, has_t, has_s);
+    const size_t E = (size_t)chunk * N * C * h * w;
+    (void)hipMemsetAsync(ws.m, 0, E * sizeof(float), st);
+    (void)hipMemsetAsync(ws.v, 0, E * sizeof(float), st);
+    opt_prepare(ws, fwd_flow, bwd_flow, fwd_occ, bwd_occ, chunk, N, C, h, w, has_t, st);
+    double b1t = 1.0, b2t = 1.0;
+    for (int it = 1; it <= iters; ++it) {
+        b1t *= (double)beta1;
+        b2t *= (double)beta2;
+        AdamArgs a;
+        a.beta1 = beta1;
+        a.beta2 = beta2;
+        a.step_size = (float)((double)lr / (1.0 - b1t));
+        a.bc2_sqrt = (float)sqrt(1.0 - b2t);
+        a.eps = eps;
+        opt_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, N, C, h, w, intra_weight,
+                    has_t, has_s, 0, nullptr, nullptr, a, st);
+    }
+    return check_launch();
+}
+
+extern "C" int fresco_opt_loss_grad(const float* cs, const float* fwd_flow, const float* bwd_flow,
+                                    const float* fwd_occ, const float* bwd_occ, const float* target,
+                                    float* grad, float* loss, void* workspace, size_t workspace_bytes,
+                                    int chunk, int N, int C, int h, int w, float intra_weight,
+                                    void* stream) {
+    int has_t = 0, has_s = 0;
+    if (!grad) return FRESCO_EINVAL;
+    if (int rc = opt_common_checks(cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, workspace,
+                                   workspace_bytes, chunk, N, C, h, w, &has_t, &has_s, intra_weight))
+        return rc;
+    hipStream_t st = as_stream(stream);
+    OptWs ws;
+    opt_ws_layout(&ws, static_cast<char*>(workspace), chunk, N, C, h, w, has_t, has_s);
+    opt_prepare(ws, fwd_flow, bwd_flow, fwd_occ, bwd_occ, chunk, N, C, h, w, has_t, st);
+    if (loss) (void)hipMemsetAsync(loss, 0, 2 * sizeof(float), st);
+    AdamArgs a = {0.f, 0.f, 0.f, 1.f, 0.f};
+    opt_closure(ws, const_cast<float*>(cs), fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, N, C, h, w,
+                intra_weight, has_t, has_s, 1, grad, loss, a, st);
+    if (loss) {
+        const double B = (double)chunk * N, hw = (double)h * w;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, loss, (float)(2.0 / (B * C * hw)),
+                           (float)((double)intra_weight / (B * hw * hw)));
+    }
+    return check_launch();
+}
+
+extern "C" int fresco_gram_target(const float* x, float* target, void* workspace, size_t workspace_bytes,
+                                  int B, int C, int hw, void* stream) {
+    if (!x || !target || !workspace || B <= 0 || C <= 0 || hw <= 0) return FRESCO_EINVAL;
+    if (B > 65535) return FRESCO_EUNSUPPORTED;
+    const size_t E = (size_t)B * C * hw;
+    if (workspace_bytes < align_up(E * 4, 256) + align_up((size_t)B * hw * 4, 256)) return FRESCO_EWORKSPACE;
+    char* p = static_cast<char*>(workspace);
+    float* vt = carve<float>(p, E);
+    float* nrm = carve<float>(p, (size_t)B * hw);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(colnorm_kernel, dim3((hw + 63) / 64, B), dim3(256), 0, st, x, vt, nrm, C, hw);
+    const int nt = (hw + GT - 1) / GT;
+    hipLaunchKernelGGL((gram_kernel<1>), dim3(nt, nt, B), dim3(256), 0, st, vt, (const float*)nullptr,
+                       (int8_t*)nullptr, target, (float*)nullptr, C, hw);
+    return check_launch();
+}

@@ -1,0 +1,272 @@
+"""Tensor-level entry points over the C ABI (include/fresco_hip.h).
+
+PyTorch is used for device memory, the current HIP stream and dtype casts only; every arithmetic op
+below is one call into libfresco_hip.so.  All functions require HIP ("cuda") tensors and raise on
+CPU tensors -- there is no fallback path.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import FrescoHipError
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise FrescoHipError("fresco_amd operators run on the GPU only (got a %s tensor); "
+                                 "there is no CPU fallback" % t.device)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _f32c(t):
+    return t.to(torch.float32).contiguous()
+
+
+class Workspace:
+    """Grow-only device scratch buffer (the C ABI never allocates)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_default_ws = Workspace()
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, group_rows=None,
+              diag_bias=0.0, workspace=None):
+    """softmax(scale * q k^T + diag_bias*I) v with grouped keys (fresco_attn_fwd).
+
+    q: (B, Lq, C) fp16.  k, v: (..., C) fp16 whose leading dims flatten to rows.
+    Default grouping: one key group per batch element (plain attention): k, v are (B, Lk, C).
+    """
+    _need_gpu(q, k, v, kv_rows)
+    if q.dtype != torch.float16 or k.dtype != torch.float16 or v.dtype != torch.float16:
+        raise TypeError("fresco_amd.attention: fp16 tensors required (got %s/%s/%s); the SD-1.5 FRESCO "
+                        "pipeline runs its UNet in fp16" % (q.dtype, k.dtype, v.dtype))
+    B, Lq, C = q.shape
+    D = C // heads
+    if D * heads != C:
+        raise ValueError("channels %d not divisible by heads %d" % (C, heads))
+    q = q.contiguous()
+    k = k.contiguous().view(-1, C)
+    v = v.contiguous().view(-1, C)
+    if k.shape != v.shape:
+        raise ValueError("k and v must have the same shape")
+    if n_groups is None:
+        n_groups = B
+        group_rows = k.shape[0] // B
+        M = group_rows
+    if kv_rows is not None:
+        if kv_rows.dtype != torch.int32:
+            raise TypeError("kv_rows must be int32")
+        kv_rows = kv_rows.contiguous()
+        M = kv_rows.numel()
+    if n_groups * group_rows > k.shape[0]:
+        raise ValueError("k has %d rows, grouping needs %d" % (k.shape[0], n_groups * group_rows))
+    lib = _lib.load()
+    ws_bytes = lib.fresco_attn_workspace_bytes(n_groups, heads, M, D)
+    ws = (workspace or _default_ws).get(ws_bytes, q.device)
+    out = torch.empty_like(q)
+    rc = lib.fresco_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(kv_rows), out.data_ptr(),
+                             ws.data_ptr(), ws.numel(), B, heads, Lq, D, n_groups, M, group_rows,
+                             float(scale), float(diag_bias), _stream())
+    _lib.check(rc, "fresco_attn_fwd(B=%d,H=%d,Lq=%d,D=%d,groups=%d,M=%d)" % (B, heads, Lq, D, n_groups, M))
+    return out
+
+
+def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk):
+    """fresco_temporal_attn: q, k, v (chunk*N, HW, C) fp16; fwd_map (N,HW) int64; mask (HW,N,N) bool."""
+    _need_gpu(q, k, v, fwd_map, mask)
+    if q.dtype != torch.float16 or k.dtype != torch.float16 or v.dtype != torch.float16:
+        raise TypeError("fresco_amd.temporal_attention: fp16 tensors required")
+    Bt, HW, C = q.shape
+    N = Bt // chunk
+    D = C // heads
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    fwd_map = fwd_map.reshape(N, HW)
+    if fwd_map.dtype != torch.int64:
+        fwd_map = fwd_map.to(torch.int64)
+    fwd_map = fwd_map.contiguous()
+    mask = mask.reshape(HW, N, N)
+    if mask.dtype == torch.bool:
+        mask = mask.contiguous().view(torch.uint8)
+    elif mask.dtype != torch.uint8:
+        mask = (mask != 0).contiguous().view(torch.uint8)
+    mask = mask.contiguous()
+    out = torch.empty_like(q)
+    rc = _lib.load().fresco_temporal_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), fwd_map.data_ptr(),
+                                          mask.data_ptr(), out.data_ptr(), chunk, N, HW, heads, D,
+                                          float(scale), _stream())
+    _lib.check(rc, "fresco_temporal_attn(chunk=%d,N=%d,HW=%d,H=%d,D=%d)" % (chunk, N, HW, heads, D))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# warp family (fp32)
+# ---------------------------------------------------------------------------------------------
+def flow_warp(x, flow):
+    """(B,C,h,w) fp32 sampled at pixel + flow[b % Bf] (bilinear, zeros, align_corners=True)."""
+    _need_gpu(x, flow)
+    x, flow = _f32c(x), _f32c(flow)
+    B, C, h, w = x.shape
+    Bf = flow.shape[0]
+    if flow.shape[1:] != (2, h, w) or B % Bf != 0:
+        raise ValueError("flow %s does not match feature %s" % (tuple(flow.shape), tuple(x.shape)))
+    out = torch.empty_like(x)
+    rc = _lib.load().fresco_flow_warp(x.data_ptr(), flow.data_ptr(), out.data_ptr(), B, C, h, w, Bf, _stream())
+    _lib.check(rc, "fresco_flow_warp")
+    return out
+
+
+def resize_bilinear(x, scale_factor, mul=1.0):
+    """F.interpolate(x * mul, scale_factor=s, mode='bilinear') for (B,C,H,W)."""
+    _need_gpu(x)
+    x = _f32c(x)
+    B, C, H, W = x.shape
+    ho, wo = int(math.floor(H * scale_factor)), int(math.floor(W * scale_factor))
+    if ho <= 0 or wo <= 0:
+        raise ValueError("resize to empty output")
+    out = torch.empty(B, C, ho, wo, dtype=torch.float32, device=x.device)
+    r = 1.0 / scale_factor
+    rc = _lib.load().fresco_resize_bilinear(x.data_ptr(), out.data_ptr(), B * C, H, W, ho, wo, r, r,
+                                            float(mul), _stream())
+    _lib.check(rc, "fresco_resize_bilinear")
+    return out
+
+
+def max_pool(x, k):
+    """F.max_pool2d(x, kernel_size=k) for (B,C,H,W)."""
+    _need_gpu(x)
+    x = _f32c(x)
+    B, C, H, W = x.shape
+    out = torch.empty(B, C, H // k, W // k, dtype=torch.float32, device=x.device)
+    rc = _lib.load().fresco_max_pool(x.data_ptr(), out.data_ptr(), B * C, H, W, k, _stream())
+    _lib.check(rc, "fresco_max_pool")
+    return out
+
+
+def dilate(x, k):
+    _need_gpu(x)
+    x = _f32c(x)
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    rc = _lib.load().fresco_dilate(x.data_ptr(), out.data_ptr(), B * C, H, W, k, _stream())
+    _lib.check(rc, "fresco_dilate")
+    return out
+
+
+def warp_fuse_chain(lat, bwd_flow, fwd_flow, bwd_occ, fwd_occ, sal, warp_sal, warp_sal_last, chunk):
+    """In-place frame chain of warp_tensor on lat (chunk*N, C, h, w) fp32 contiguous."""
+    _need_gpu(lat)
+    assert lat.dtype == torch.float32 and lat.is_contiguous()
+    Bt, C, h, w = lat.shape
+    N = Bt // chunk
+    args = [_f32c(t) for t in (bwd_flow, fwd_flow, bwd_occ, fwd_occ, sal, warp_sal, warp_sal_last)]
+    rc = _lib.load().fresco_warp_fuse_chain(lat.data_ptr(), *[t.data_ptr() for t in args], chunk, N, C, h, w,
+                                            _stream())
+    _lib.check(rc, "fresco_warp_fuse_chain(N=%d)" % N)
+    return lat
+
+
+def adain(content, style, eps_content=1e-5, eps_style=1.0):
+    _need_gpu(content, style)
+    if content.shape != style.shape:
+        raise ValueError("AdaIN: content %s vs style %s" % (tuple(content.shape), tuple(style.shape)))
+    dt = torch.result_type(content, style)
+    if dt not in (torch.float16, torch.float32):
+        dt = torch.float32
+    c, s = content.to(dt).contiguous(), style.to(dt).contiguous()
+    rows = c.shape[0] * c.shape[1]
+    L = c.numel() // rows
+    out = torch.empty_like(c)
+    rc = _lib.load().fresco_adain(c.data_ptr(), s.data_ptr(), out.data_ptr(), rows, L, float(eps_content),
+                                  float(eps_style), _lib.F16 if dt == torch.float16 else _lib.F32, _stream())
+    _lib.check(rc, "fresco_adain")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# feature optimisation (fp32)
+# ---------------------------------------------------------------------------------------------
+def _opt_args(cs, prep, target, chunk):
+    Bt, C, h, w = cs.shape
+    N = Bt // chunk
+    if prep is not None:
+        fwd_flow, bwd_flow, fwd_occ, bwd_occ = [_f32c(t) for t in prep]
+        assert fwd_flow.shape == (N, 2, h, w) and bwd_flow.shape == (N, 2, h, w), (fwd_flow.shape, (N, 2, h, w))
+        assert fwd_occ.numel() == N * h * w and bwd_occ.numel() == N * h * w
+        keep = (fwd_flow, bwd_flow, fwd_occ, bwd_occ)
+    else:
+        keep = (None, None, None, None)
+    if target is not None:
+        target = _f32c(target)
+        assert target.shape == (Bt, h * w, h * w), (target.shape, (Bt, h * w, h * w))
+    return N, C, h, w, keep, target
+
+
+def opt_run(cs, prep, target, intra_weight, iters, chunk, lr=0.2, betas=(0.9, 0.999), eps=1e-8,
+            workspace=None):
+    """`iters` Adam steps on cs (chunk*N, C, h, w) fp32 contiguous, in place (fresco_opt_run).
+    prep = (fwd_flow, bwd_flow, fwd_occ, bwd_occ) at feature resolution, or None."""
+    _need_gpu(cs)
+    assert cs.dtype == torch.float32 and cs.is_contiguous()
+    N, C, h, w, keep, target = _opt_args(cs, prep, target, chunk)
+    lib = _lib.load()
+    has_t, has_s = int(prep is not None), int(target is not None and intra_weight > 0)
+    nbytes = lib.fresco_opt_workspace_bytes(chunk, N, C, h, w, has_t, has_s)
+    ws = (workspace or _default_ws).get(nbytes, cs.device)
+    rc = lib.fresco_opt_run(cs.data_ptr(), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
+                            _ptr(target), ws.data_ptr(), ws.numel(), chunk, N, C, h, w, float(intra_weight),
+                            int(iters), float(lr), float(betas[0]), float(betas[1]), float(eps), _stream())
+    _lib.check(rc, "fresco_opt_run(chunk=%d,N=%d,C=%d,h=%d,w=%d)" % (chunk, N, C, h, w))
+    return cs
+
+
+def opt_loss_grad(cs, prep, target, intra_weight, chunk, workspace=None):
+    """One closure evaluation: returns (loss_temporal, loss_spatial) device tensor (2,) and grad."""
+    _need_gpu(cs)
+    cs = _f32c(cs)
+    N, C, h, w, keep, target = _opt_args(cs, prep, target, chunk)
+    lib = _lib.load()
+    has_t, has_s = int(prep is not None), int(target is not None and intra_weight > 0)
+    nbytes = lib.fresco_opt_workspace_bytes(chunk, N, C, h, w, has_t, has_s)
+    ws = (workspace or _default_ws).get(nbytes, cs.device)
+    grad = torch.empty_like(cs)
+    loss = torch.zeros(2, dtype=torch.float32, device=cs.device)
+    rc = lib.fresco_opt_loss_grad(cs.data_ptr(), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
+                                  _ptr(target), grad.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  chunk, N, C, h, w, float(intra_weight), _stream())
+    _lib.check(rc, "fresco_opt_loss_grad")
+    return loss, grad
+
+
+def gram_target(x, workspace=None):
+    """Cosine Gram matrix of (B,C,h,w) features -> (B,hw,hw) fp32 (fresco_gram_target)."""
+    _need_gpu(x)
+    x = _f32c(x)
+    B, C, h, w = x.shape
+    hw = h * w
+    out = torch.empty(B, hw, hw, dtype=torch.float32, device=x.device)
+    nbytes = (B * C * hw * 4 + 255) // 256 * 256 + (B * hw * 4 + 255) // 256 * 256
+    ws = (workspace or _default_ws).get(nbytes, x.device)
+    rc = _lib.load().fresco_gram_target(x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, C, hw,
+                                        _stream())
+    _lib.check(rc, "fresco_gram_target")
+    return out

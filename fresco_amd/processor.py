@@ -1,0 +1,136 @@
+"""FRESCOAttnProcessor2_0: the diffusers AttnProcessor the reference installs on every attention of
+`up_blocks.2*` / `up_blocks.3*` (src/diffusion_hacked.py:142-403), with the three attention passes
+running in libfresco_hip.so.
+
+Call protocol, constructor signature, the attributes read from the diffusers `Attention` module and
+the controller interaction are the reference's; the data path is not:
+  * head split / merge are index arithmetic inside the kernels (no (B,H,L,D) copies);
+  * efficient cross-frame K/V selection + repeat (225-247) is one packed K / V^T image per CFG half,
+    shared by all frames;
+  * spatial-guided pass (257-288): no HW x HW eye mask is materialised; `key * 0.2` is a logit scale;
+  * temporal pass (309-367): one fused gather / N x N masked softmax / scatter kernel;
+  * the linear projections stay `attn.to_q/to_k/to_v/to_out` (torch GEMMs owned by diffusers).
+"""
+import math
+
+import torch
+
+from . import _lib, ops
+from .control import AttentionControl
+
+
+class FRESCOAttnProcessor2_0:
+    def __init__(self, unet_chunk_size=2, controller=None):
+        _lib.load()  # fail here, loudly, when the HIP library is absent
+        self.unet_chunk_size = unet_chunk_size
+        self.controller = controller
+        self._ws = ops.Workspace()
+        self._rows_cache = {}
+
+    # flat int32 indices of the True entries of a (N, HW) mask, cached per mask tensor
+    def _kv_rows(self, mask):
+        key = (mask.data_ptr(), tuple(mask.shape), mask._version)
+        hit = self._rows_cache.get(key)
+        if hit is None:
+            if len(self._rows_cache) > 16:
+                self._rows_cache.clear()
+            hit = torch.nonzero(mask.reshape(-1), as_tuple=False).squeeze(1).to(torch.int32).contiguous()
+            self._rows_cache[key] = hit
+        return hit
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
+        residual = hidden_states
+        if attn.spatial_norm is not None:
+            hidden_states = attn.spatial_norm(hidden_states, temb)
+        input_ndim = hidden_states.ndim
+        if input_ndim == 4:
+            batch_size, channel, height, width = hidden_states.shape
+            hidden_states = hidden_states.view(batch_size, channel, height * width).transpose(1, 2)
+        batch_size = hidden_states.shape[0]
+        if attention_mask is not None:
+            raise NotImplementedError("fresco_amd: attention_mask is not supported (the FRESCO pipeline "
+                                      "never passes one, src/pipe_FRESCO.py:201-209)")
+        if attn.group_norm is not None:
+            hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
+
+        ctrl = self.controller
+        query = attn.to_q(hidden_states)
+        crossattn = encoder_hidden_states is not None
+        if not crossattn:
+            encoder_hidden_states = hidden_states
+            if ctrl and ctrl.store:
+                ctrl(hidden_states.detach().clone())
+        elif attn.norm_cross:
+            encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
+        key = attn.to_k(encoder_hidden_states)
+        value = attn.to_v(encoder_hidden_states)
+
+        heads = attn.heads
+        head_dim = key.shape[-1] // heads
+        sm_scale = 1.0 / math.sqrt(head_dim)
+        fresco = bool(ctrl) and not crossattn
+        chunk = self.unet_chunk_size
+
+        # spatial-guided pass: the current query becomes the VALUE of an attention over the stored
+        # features of the input video (diffusion_hacked.py:257-288)
+        q_att = query
+        if fresco and ctrl.use_intraattn:
+            ref = ctrl(None)
+            assert ref.shape == encoder_hidden_states.shape
+            q_ref = attn.to_q(ref)
+            k_ref = attn.to_k(ref)
+            q_att = ops.attention(q_ref, k_ref, query, heads, ctrl.intraattn_scale_factor * sm_scale,
+                                  diag_bias=float(ctrl.intraattn_bias), workspace=self._ws)
+
+        # main pass: efficient cross-frame attention (225-247, 303-305) or plain attention
+        if fresco and ctrl.use_cfattn:
+            video_length = key.shape[0] // chunk
+            hw = key.shape[1]
+            mask = None
+            if ctrl.attn_mask is not None:
+                for m in ctrl.attn_mask:
+                    if m.shape[1] == hw:
+                        mask = m
+            rows = self._kv_rows(mask) if mask is not None else None
+            hs = ops.attention(q_att, key, value, heads, sm_scale, kv_rows=rows, n_groups=chunk,
+                               M=hw if rows is None else rows.numel(), group_rows=video_length * hw,
+                               workspace=self._ws)
+        else:
+            hs = ops.attention(q_att, key, value, heads, sm_scale, workspace=self._ws)
+
+        # temporal-guided pass along the flow trajectories (309-367)
+        if fresco and ctrl.use_interattn:
+            fwd_mapping = interattn_mask = None
+            paras = ctrl.interattn_paras
+            for i, f in enumerate(paras["fwd_mappings"]):
+                if f.shape[2] == hs.shape[1]:
+                    fwd_mapping = f
+                    interattn_mask = paras["interattn_masks"][i]
+            if fwd_mapping is None:
+                raise ValueError("fresco_amd: no temporal-attention parameters for %d tokens" % hs.shape[1])
+            hs = ops.temporal_attention(query, key, hs, fwd_mapping, interattn_mask, heads,
+                                        ctrl.interattn_scale_factor * sm_scale, chunk)
+
+        hs = hs.to(query.dtype)
+        hs = attn.to_out[0](hs)
+        hs = attn.to_out[1](hs)
+        if input_ndim == 4:
+            hs = hs.transpose(-1, -2).reshape(batch_size, channel, height, width)
+        if attn.residual_connection:
+            hs = hs + residual
+        hs = hs / attn.rescale_output_factor
+        return hs
+
+
+def apply_FRESCO_attn(pipe):
+    """Install one shared FRESCO processor on the decoder attentions (diffusion_hacked.py:390-403).
+    The other attentions keep diffusers' stock AttnProcessor2_0."""
+    from diffusers.models.attention_processor import AttnProcessor2_0
+
+    frescoProc = FRESCOAttnProcessor2_0(2, AttentionControl())
+    attnProc = AttnProcessor2_0()
+    procs = {}
+    for k in pipe.unet.attn_processors.keys():
+        procs[k] = frescoProc if (k.startswith("up_blocks.2") or k.startswith("up_blocks.3")) else attnProc
+    pipe.unet.set_attn_processor(procs)
+    return frescoProc

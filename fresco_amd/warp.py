@@ -1,0 +1,76 @@
+"""flow_warp / warp_tensor / AdaIN / Dilate with the reference's signatures, on the HIP kernels.
+
+Reference: src/ebsynth/deps/gmflow/gmflow/geometry.py:41-72 (flow_warp), src/flow_utils.py:18-53
+(warp_tensor), src/utils.py:58-93 (calc_mean_std, adaptive_instance_normalization, Dilate).
+"""
+import torch
+
+from . import ops
+
+
+def flow_warp(feature, flow, mask=False, padding_mode="zeros"):
+    """geometry.py:65-72.  Only the configuration FRESCO uses: zeros padding, no validity mask."""
+    if mask or padding_mode != "zeros":
+        raise NotImplementedError("fresco_amd.flow_warp: mask=False, padding_mode='zeros' only")
+    assert flow.size(1) == 2
+    return ops.flow_warp(feature, flow).to(feature.dtype)
+
+
+def _prep_flow_occ(h, flows, occs, with_dilate):
+    """flow_utils.py:24-31 / diffusion_hacked.py:437-442: flows, occs at feature height h."""
+    H = flows[0].shape[2]
+    scale = h * 1.0 / H
+    kernel = int(1 / scale)
+    out = []
+    for i in (0, 1):
+        fl = ops.resize_bilinear(flows[i], scale, mul=scale)
+        oc = ops.max_pool(occs[i].unsqueeze(1), kernel)
+        if with_dilate and scale == 1:
+            oc = ops.dilate(oc, 13)
+        out.append((fl, oc))
+    (fwd_flow, fwd_occ), (bwd_flow, bwd_occ) = out
+    if fwd_flow.shape[2] != h:
+        raise ValueError("flow of height %d does not resize to feature height %d" % (H, h))
+    return fwd_flow, bwd_flow, fwd_occ, bwd_occ
+
+
+@torch.no_grad()
+def warp_tensor(sample, flows, occs, saliency, unet_chunk_size):
+    """flow_utils.py:18-53: warp frame i into frame i+1 along the chain and blend by
+    (1-occ) * saliency * warped saliency; the last step warps frame 0 into frame N-1."""
+    h = sample.shape[2]
+    fwd_flow, bwd_flow, fwd_occ, bwd_occ = _prep_flow_occ(h, flows, occs, with_dilate=True)
+    scale2 = h * 1.0 / saliency.shape[2]
+    sal = ops.resize_bilinear(saliency, scale2)
+    n = sample.shape[0] // unet_chunk_size
+    warp_sal = ops.flow_warp(sal, bwd_flow)
+    warp_sal_last = ops.flow_warp(sal[0:1], fwd_flow[n - 1:n])
+    lat = sample.to(torch.float32).contiguous().clone()
+    ops.warp_fuse_chain(lat, bwd_flow, fwd_flow, bwd_occ, fwd_occ, sal, warp_sal, warp_sal_last,
+                        unet_chunk_size)
+    return lat.to(sample.dtype)
+
+
+def calc_mean_std(feat, eps=1e-5, chunk=1):
+    raise NotImplementedError("fresco_amd fuses calc_mean_std into adaptive_instance_normalization")
+
+
+def adaptive_instance_normalization(content_feat, style_feat, chunk=1):
+    """utils.py:70-78.  The reference passes `chunk` positionally into calc_mean_std's `eps` for the
+    style statistics (utils.py:73 vs :58), i.e. style std = sqrt(var + chunk); reproduced here."""
+    assert content_feat.size()[:2] == style_feat.size()[:2]
+    return ops.adain(content_feat, style_feat, eps_content=1e-5, eps_style=float(chunk))
+
+
+class Dilate:
+    """utils.py:81-93: replicate-pad + k x k box sum + clamp to [0, 1]."""
+
+    def __init__(self, kernel_size=7, channels=1, device="cpu"):
+        if channels != 1:
+            raise NotImplementedError("fresco_amd.Dilate: channels=1 only (all the reference uses)")
+        self.kernel_size = kernel_size
+        self.channels = channels
+        self.mean = (kernel_size - 1) // 2
+
+    def __call__(self, x):
+        return ops.dilate(x, self.kernel_size).to(x.dtype)

@@ -1,0 +1,169 @@
+/*
+ * fresco_hip.h -- C ABI of libfresco_hip.so: the MI355X (gfx950 / CDNA4) kernels behind FRESCO's
+ * flow-guided attention, feature warp and feature-optimisation hot path.
+ *
+ * Conventions (every entry point):
+ *   - plain device pointers + explicit sizes; no torch / C++ types cross this boundary;
+ *   - returns FRESCO_OK (0) or a negative FRESCO_E* code; nothing is thrown, nothing printed;
+ *   - never allocates: scratch memory is passed in by the caller, sized by the matching
+ *     *_workspace_bytes() query (host-only, no GPU needed);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *   - no global state: concurrent calls on different streams with disjoint buffers are safe.
+ *
+ * Reference interface each entry point replaces (paths relative to the FRESCO tree):
+ *   src/diffusion_hacked.py  = DH,  src/flow_utils.py = FU,  src/utils.py = UT,
+ *   src/ebsynth/deps/gmflow/gmflow/geometry.py = GEO.
+ *
+ * "half" below is IEEE binary16 (the dtype the SD-1.5 pipeline runs in, run_fresco.py:63-80).
+ */
+#ifndef FRESCO_HIP_H
+#define FRESCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRESCO_OK 0
+#define FRESCO_EINVAL (-1)      /* null pointer / non-positive size / inconsistent arguments   */
+#define FRESCO_EUNSUPPORTED (-2) /* shape outside what the kernels are instantiated for        */
+#define FRESCO_EWORKSPACE (-3)  /* workspace too small                                          */
+#define FRESCO_ELAUNCH (-4)     /* hipGetLastError() != hipSuccess after a launch              */
+
+/* dtype codes for entry points that accept more than one element type */
+#define FRESCO_F16 0
+#define FRESCO_F32 1
+
+/* library / build identification: "fresco_hip <version> gfx950" */
+const char* fresco_version(void);
+/* last HIP error string seen by a FRESCO_ELAUNCH on this thread ("" if none) */
+const char* fresco_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * (a2 + a3)  Dense attention with shared / per-batch keys  -- replaces the two
+ * F.scaled_dot_product_attention calls at DH:281-285 (spatial-guided) and DH:303-305
+ * (efficient cross-frame), the K/V row selection + repeat at DH:225-247, and the head
+ * split / merge views at DH:250-254, 371.
+ *
+ *   out[b, l, h*D + d] = sum_m softmax_m( scale * <q[b,l,h,:], K[g,m,h,:]> + diag_bias*[l==m] ) * V[g,m,h,d]
+ *
+ *   q   : (B, Lq, H*D) half, row-major (what attn.to_q returns)
+ *   k,v : row-major matrices of H*D-wide half rows.  Key group g (0 <= g < n_groups) uses the M
+ *         rows   g*group_rows + (kv_rows ? kv_rows[m] : m),  m = 0..M-1.
+ *         Query batch b attends to group  g = b / (B / n_groups).
+ *           cross-frame : n_groups = unet_chunk_size, group_rows = N*HW, kv_rows = flat indices of
+ *                         the True entries of controller.attn_mask (N,HW), or NULL with M = HW for
+ *                         "every frame uses frame 0" (former_frame_index, DH:227).
+ *           spatial     : n_groups = B, group_rows = HW, kv_rows = NULL, M = HW,
+ *                         q = to_q(ref), k = to_k(ref), v = current query, scale = 0.2/sqrt(D).
+ *   out : (B, Lq, H*D) half.
+ *   D must be a multiple of 8, 8 <= D <= 128.  Softmax in fp32, P and V in half, accumulation fp32.
+ * ------------------------------------------------------------------------------------------ */
+size_t fresco_attn_workspace_bytes(int n_groups, int H, int M, int D);
+
+int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* kv_rows,
+                    void* out, void* workspace, size_t workspace_bytes,
+                    int B, int H, int Lq, int D,
+                    int n_groups, int M, int64_t group_rows,
+                    float scale, float diag_bias, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a4)  Temporal-guided (FLATTEN) attention -- replaces DH:309-367: 3 rearrange+gather round
+ * trips, the per-pixel N x N masked SDPA and the inverse gather.
+ *
+ *   for every aligned pixel p, CFG half c, head h, frames f,g in [0,N):
+ *     row(f) = fwd_map[f*HW + p]
+ *     out[c*N+f, row(f), h, :] = sum_g softmax_g( scale*<q[c*N+f,row(f),h,:], k[c*N+g,row(g),h,:]>
+ *                                                 | mask[p,f,g] ) * v[c*N+g,row(g),h,:]
+ *   q,k,v,out : (chunk*N, HW, H*D) half;  fwd_map : (N, HW) int64 (a permutation per frame);
+ *   mask : (HW, N, N) uint8/bool, non-zero = may attend (diagonal always set, FU:120-131).
+ *   N <= 32, D multiple of 8.
+ * ------------------------------------------------------------------------------------------ */
+int fresco_temporal_attn(const void* q, const void* k, const void* v, const int64_t* fwd_map,
+                         const uint8_t* mask, void* out,
+                         int chunk, int N, int HW, int H, int D, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a8)  flow_warp / bilinear_sample  (GEO:41-72): bilinear, zeros padding, align_corners=True.
+ *   x, out : (B, C, h, w) fp32;  flow : (Bf, 2, h, w) fp32, channel 0 = x, 1 = y.
+ *   Batch b samples with flow[b % Bf]  (Bf = B, or the un-repeated N when x holds `chunk` copies).
+ * ------------------------------------------------------------------------------------------ */
+int fresco_flow_warp(const float* x, const float* flow, float* out,
+                     int B, int C, int h, int w, int Bf, void* stream);
+
+/* F.interpolate(x * mul, scale_factor=s, mode='bilinear') (align_corners=False, no antialias);
+ * (B,C,H,W) -> (B,C,ho,wo) fp32 with the source-coordinate scale rscale = 1/s as torch computes
+ * it when scale_factor is given (FU:26,30,35; DH:439,441,937). */
+int fresco_resize_bilinear(const float* x, float* out, int BC, int H, int W, int ho, int wo,
+                           float rscale_h, float rscale_w, float mul, void* stream);
+
+/* F.max_pool2d(x, kernel_size=k) (stride k, floor) on (BC,H,W) fp32 -> (BC,H/k,W/k)  (FU:27,31; DH:440,442) */
+int fresco_max_pool(const float* x, float* out, int BC, int H, int W, int k, void* stream);
+
+/* Dilate (UT:81-93): replicate pad (k-1)/2, k x k box sum, clamp [0,1]; (BC,H,W) fp32, k odd */
+int fresco_dilate(const float* x, float* out, int BC, int H, int W, int k, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a7)  warp_tensor frame chain (FU:41-51).  `lat` (chunk*N, C, h, w) fp32 is updated IN PLACE:
+ *   for c in chunk: for i in 0..N-2:  lat[c*N+i+1] = lat[c*N+i+1]*(1-m) + warp(lat[c*N+i], bwd_flow[i])*m,
+ *                                      m = (1-bwd_occ[i]) * sal[i+1] * warp_sal[i]
+ *                   last:             lat[c*N+N-1] blended with warp(lat[c*N], fwd_flow[N-1]),
+ *                                      m = (1-fwd_occ[N-1]) * sal[N-1] * warp_sal_last
+ *   bwd_flow, fwd_flow : (N,2,h,w); bwd_occ, fwd_occ, sal, warp_sal : (N,h,w); warp_sal_last : (h,w).
+ *   The chain is sequential in the frame index (N launches), parallel over chunk, C, h, w.
+ * ------------------------------------------------------------------------------------------ */
+int fresco_warp_fuse_chain(float* lat, const float* bwd_flow, const float* fwd_flow,
+                           const float* bwd_occ, const float* fwd_occ, const float* sal,
+                           const float* warp_sal, const float* warp_sal_last,
+                           int chunk, int N, int C, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a9)  adaptive_instance_normalization (UT:58-78) over rows of L = h*w elements:
+ *   out = (content - mean_c) / sqrt(var_c + eps_content) * sqrt(var_s + eps_style) + mean_s,
+ *   unbiased variance.  The reference's style eps is 1.0 (UT:73 passes chunk into eps).
+ *   content, style, out : (rows, L), dtype FRESCO_F16 or FRESCO_F32 (all three the same).
+ * ------------------------------------------------------------------------------------------ */
+int fresco_adain(const void* content, const void* style, void* out, int rows, int L,
+                 float eps_content, float eps_style, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a6)  optimize_feature (DH:416-488): Adam on an fp32 copy of the features against
+ *   L = 2*mean(|(c2 - W_b c1)(1-occ_b)| + |(c1 - W_f c2)(1-occ_f)|) + intra_weight*mean|V V^T - T|.
+ *
+ *   cs        : (chunk*N, C, h, w) fp32, updated in place (the optimised parameter)
+ *   fwd_flow, bwd_flow : (N, 2, h, w) fp32 at feature resolution (already scaled), or NULL
+ *   fwd_occ, bwd_occ   : (N, h, w) fp32, or NULL           (temporal term off when NULL)
+ *   target    : (chunk*N, hw, hw) fp32 Gram target, or NULL (spatial term off when NULL)
+ *   iters Adam steps (lr, beta1, beta2, eps as torch.optim.Adam); no autograd: analytic
+ *   gradients.  The adjoint of the bilinear warp is evaluated as a deterministic gather over a
+ *   per-call CSR of the tap matrix (no atomics), so results are run-to-run reproducible.
+ *
+ *   fresco_opt_loss_grad evaluates the closure once: grad (same shape as cs) and, if loss != NULL,
+ *   loss[0] = temporal term, loss[1] = spatial term (device floats).  Test / debugging entry.
+ * ------------------------------------------------------------------------------------------ */
+size_t fresco_opt_workspace_bytes(int chunk, int N, int C, int h, int w, int has_temporal,
+                                  int has_target);
+
+int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd_flow,
+                   const float* fwd_occ, const float* bwd_occ, const float* target,
+                   void* workspace, size_t workspace_bytes,
+                   int chunk, int N, int C, int h, int w,
+                   float intra_weight, int iters, float lr, float beta1, float beta2, float eps,
+                   void* stream);
+
+int fresco_opt_loss_grad(const float* cs, const float* fwd_flow, const float* bwd_flow,
+                         const float* fwd_occ, const float* bwd_occ, const float* target,
+                         float* grad, float* loss, void* workspace, size_t workspace_bytes,
+                         int chunk, int N, int C, int h, int w, float intra_weight, void* stream);
+
+/* Gram target of get_intraframe_paras (DH:889-895): T[b] = V V^T, V = rows of x (B,C,h,w)
+ * viewed as (B, hw, C) and L2-normalised; fp32 (B,hw,hw).  workspace: B*C*hw + B*hw floats. */
+int fresco_gram_target(const float* x, float* target, void* workspace, size_t workspace_bytes,
+                       int B, int C, int hw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRESCO_HIP_H */
