@@ -1,0 +1,295 @@
+#!/usr/bin/env python
+"""Headline benchmark: FRESCO hot-path denoising steps / second on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "cfg2"): 8 synthetic frames at 512^2, SD-1.5 decoder
+shapes, FRESCO attention only (no feature optimisation).  One STEP = the FRESCO work of one UNet pass =
+3 x up_blocks.2 (HW=1024, C=640, D=80) + 3 x up_blocks.3 (HW=4096, C=320, D=40) calls of
+FRESCOAttnProcessor2_0 (q/k/v/out projections included, as the processor owns them), with the attention
+mode of that denoising step.  Steps cycle through the reference's 15-step schedule (20 DDPM steps,
+num_warmup_steps=5; src/pipe_FRESCO.py:166-174): 1 x spatial+cross-frame+temporal, 7 x cross-frame+
+temporal, 7 x cross-frame only.  Inputs are resident in HBM before the timed region.
+
+N > 1 GPUs: the SAME 8-frame batch is sharded by frame (strong scaling); K/V of all frames are
+exchanged with one RCCL all-gather per layer before the cross-frame attention (fresco_amd/dist.py).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, attn_flash_kernel<40> on the
+up_blocks.3 cross-frame pass: algorithmic flop 4*B*HW*M*C per launch / mean HIP-event duration of those
+launches, measured in a second, instrumented replay of the same K steps (so `value` is not perturbed).
+`cpu_baseline` times the oracle (a CPU port of the reference algorithm) on rank 0's host cores on one
+call per (layer, mode) and weights them by the schedule.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SCHEDULE = ["full"] + ["cf_temporal"] * 7 + ["cf"] * 7
+PEAK_F16_DENSE = 2.5e15  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense fp16/bf16 MFMA
+LAYERS = [("L2", 640, 16)] * 3 + [("L3", 320, 8)] * 3  # (name, channels, downscale)
+
+
+def synth_params(N, side, gen, occ_p):
+    """Synthetic per-batch FRESCO parameters at one feature scale (no oracle involved):
+    trajectory maps = per-frame cyclic shift (3,-2)*f px + 5 % random transpositions (permutations),
+    trajectory masks with Bernoulli(0.1) broken links, cross-frame mask = frame 0 + Bernoulli(occ_p)."""
+    HW = side * side
+    ys, xs = torch.meshgrid(torch.arange(side), torch.arange(side), indexing="ij")
+    fwd = []
+    for f in range(N):
+        m = (((ys - 2 * f) % side) * side + ((xs + 3 * f) % side)).reshape(-1)
+        if f > 0:
+            nswap = HW // 20
+            a = torch.randperm(HW, generator=gen)[: 2 * nswap]
+            i, j = a[:nswap], a[nswap:]
+            mi, mj = m[i].clone(), m[j].clone()
+            m[i], m[j] = mj, mi
+        fwd.append(m)
+    fwd = torch.stack(fwd, 0).unsqueeze(1)
+    bwd = torch.argsort(fwd, dim=2)
+    tmask = torch.ones(HW, N, N, dtype=torch.bool)
+    for i in range(N - 1):
+        broken = torch.rand(HW, generator=gen) < 0.1
+        one = torch.ones(N, N, dtype=torch.bool)
+        one[: i + 1, i + 1:] = False
+        one[i + 1:, : i + 1] = False
+        tmask[broken] &= one
+    cf = torch.rand(N, HW, generator=gen) < occ_p
+    cf[0] = True
+    return fwd, bwd, tmask.unsqueeze(1), cf
+
+
+def build_workload(N, R, device, seed=0):
+    import synth
+
+    gen = torch.Generator().manual_seed(seed)
+    B = 2 * N
+    params = {}
+    for down in (8, 16):
+        params[down] = synth_params(N, R // down, gen, 0.004)
+    layers = []
+    for name, C, down in LAYERS:
+        HW = (R // down) ** 2
+        attn = synth.FakeAttn(C, 8).to(device).half()
+        hidden = torch.randn(B, HW, C, generator=gen).half()
+        ref = (hidden.float() + 0.1 * torch.randn(B, HW, C, generator=gen)).half()
+        layers.append(dict(name=name, C=C, HW=HW, down=down, attn=attn, hidden=hidden.to(device),
+                           ref=ref.to(device), hidden_cpu=hidden, ref_cpu=ref))
+    return layers, params
+
+
+def make_processor(layers, params, device, shard=None):
+    import fresco_amd
+
+    ctrl = fresco_amd.AttentionControl()
+    proc = fresco_amd.FRESCOAttnProcessor2_0(2, ctrl)
+    if shard is not None:
+        proc.shard = shard
+    refs = [l["ref"] for l in layers]
+    paras = dict(fwd_mappings=[params[8][0].to(device), params[16][0].to(device)],
+                 bwd_mappings=[params[8][1].to(device), params[16][1].to(device)],
+                 interattn_masks=[params[8][2].to(device), params[16][2].to(device)])
+    masks = [params[8][3].to(device), params[16][3].to(device)]
+    return proc, ctrl, refs, paras, masks
+
+
+def set_mode(ctrl, mode, refs, paras, masks):
+    ctrl.disable_controller()
+    ctrl.stored_attn["decoder_attn"] = refs
+    if mode == "full":
+        ctrl.enable_intraattn()
+    if mode in ("full", "cf_temporal"):
+        ctrl.enable_interattn(paras)
+    ctrl.enable_cfattn(masks)
+
+
+def run_step(proc, ctrl, layers, mode, refs, paras, masks):
+    set_mode(ctrl, mode, refs, paras, masks)
+    out = None
+    for l in layers:
+        out = proc(l["attn"], l["hidden_local"])
+    return out
+
+
+def cpu_baseline(layers, params, N):
+    """Oracle (CPU port of the reference algorithm, fp32) on one call per (layer kind, mode)."""
+    from oracle import fresco_oracle as O
+
+    O.USE_TORCH_SDPA = True  # dense passes through torch's fused CPU SDPA, as the reference does
+    t_mode = {}
+    sample = []
+    for mode in ("full", "cf_temporal", "cf"):
+        tot = 0.0
+        for l in (layers[0], layers[3]):
+            a = l["attn"]
+            W = [a.to_q.weight, a.to_k.weight, a.to_v.weight, a.to_out[0].weight]
+            W = [w.detach().float().cpu() for w in W]
+            bo = a.to_out[0].bias.detach().float().cpu()
+            fwd, _, tm, cfm = params[l["down"]]
+            kw = dict(use_cf=True, cf_mask=cfm)
+            if mode in ("full", "cf_temporal"):
+                kw.update(fwd_map=fwd[:, 0], tmask=tm[:, 0])
+            if mode == "full":
+                kw.update(ref=l["ref_cpu"].float())
+            x = l["hidden_cpu"].float()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                O.fresco_attention(x, W[0], W[1], W[2], W[3], bo, 8, **kw)
+            tot += 3 * (time.perf_counter() - t0)
+        t_mode[mode] = tot
+        sample.append("%s %.2fs" % (mode, tot))
+    step_s = sum(t_mode[m] for m in SCHEDULE) / len(SCHEDULE)
+    return dict(value=1.0 / step_s, unit="denoising-steps/sec", cores=torch.get_num_threads(), kind="port",
+                sample="oracle.fresco_attention (fp32, torch CPU, dense passes via torch SDPA) timed once per (layer kind L2/L3, mode) at "
+                       "N=%d frames, x3 layers each, weighted by the 15-step schedule: %s" % (N, ", ".join(sample)))
+
+
+def read_prof(lib, cap):
+    tags = (ctypes.c_int * cap)()
+    dims = (ctypes.c_int * (4 * cap))()
+    ms = (ctypes.c_float * cap)()
+    n = lib.fresco_prof_read(cap, tags, dims, ms)
+    return [(tags[i], tuple(dims[4 * i: 4 * i + 4]), ms[i]) for i in range(n)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=15)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import fresco_amd
+    from fresco_amd import _lib
+
+    lib = _lib.load()
+    N, R = args.frames, args.res
+    if N % world != 0:
+        raise SystemExit("frames (%d) must be divisible by the number of GPUs (%d)" % (N, world))
+    layers, params = build_workload(N, R, device)
+    shard = None
+    if world > 1:
+        from fresco_amd.dist import FrameShard
+
+        shard = FrameShard(N, 2, rank, world)
+    proc, ctrl, refs, paras, masks = make_processor(layers, params, device, shard)
+    n_loc = N // world
+    for l in layers:
+        if world > 1:
+            sel = shard.local_batch_index().to(device)
+            l["hidden_local"] = l["hidden"].index_select(0, sel).contiguous()
+            l["ref_local"] = l["ref"].index_select(0, sel).contiguous()
+        else:
+            l["hidden_local"], l["ref_local"] = l["hidden"], l["ref"]
+    refs = [l["ref_local"] for l in layers]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(k0, k):
+        with torch.no_grad():
+            for s in range(k0, k0 + k):
+                run_step(proc, ctrl, layers, SCHEDULE[s % len(SCHEDULE)], refs, paras, masks)
+
+    run(0, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(0, args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # instrumented replay of the same K steps: per-launch HIP-event durations of the dominant kernel
+    cap = args.steps * 64 + 64
+    lib.fresco_prof_enable(cap)
+    run(0, args.steps)
+    torch.cuda.synchronize()
+    lib.fresco_prof_disable()
+    recs = read_prof(lib, cap)
+    B_loc = 2 * n_loc
+    HW3 = (R // 8) ** 2
+    M3 = int(params[8][3].sum())
+    dom = [ms for tag, d, ms in recs if tag == 1 and d == (B_loc * 8, HW3, M3, 40)]
+    roofline = None
+    if dom:
+        flop = 4.0 * B_loc * HW3 * M3 * 320
+        mean_s = sum(dom) / len(dom) * 1e-3
+        ach = flop / mean_s
+        roofline = dict(bound="mfma", kernel="attn_flash_kernel<40> (up_blocks.3 cross-frame pass)",
+                        achieved=round(ach / 1e12, 2), peak=PEAK_F16_DENSE / 1e12, unit="TFLOP/s",
+                        frac=round(ach / PEAK_F16_DENSE, 4), traffic=None, launches=len(dom),
+                        avg_launch_us=round(mean_s * 1e6, 2), algorithmic_flop_per_launch=flop)
+    by_tag = {}
+    for tag, d, ms in recs:
+        key = {1: "attn_flash", 2: "kv_pack", 3: "temporal"}.get(tag, str(tag)) + str(list(d))
+        by_tag.setdefault(key, []).append(ms)
+    kernels_us = {k: round(1e3 * sum(v) / len(v), 2) for k, v in sorted(by_tag.items())}
+
+    if rank == 0:
+        res = {
+            "metric": "denoising-steps/sec (8-frame batch, 512^2), FRESCO hot-path step",
+            "value": round(args.steps / dt, 3),
+            "unit": "denoising-steps/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": "cfg2: %d frames %dx%d, SD-1.5 decoder shapes, FRESCO attention only (3x up_blocks.2 "
+                            "HW=%d C=640 + 3x up_blocks.3 HW=%d C=320 processor calls per step, projections "
+                            "included), 15-step schedule 1x spatial+cf+temporal / 7x cf+temporal / 7x cf"
+                            % (N, R, R, (R // 16) ** 2, HW3),
+                "cross_frame_keys_M": {"L3": M3, "L2": int(params[16][3].sum())},
+                "parallelism": "frame-shard x%d (RCCL all-gather of K|V)" % world if world > 1 else "single GPU",
+            },
+            "roofline": roofline,
+            "kernel_avg_us": kernels_us,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(layers, params, N)
+        elif world == 1:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

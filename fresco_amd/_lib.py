@@ -30,9 +30,13 @@ _vp, _i, _f, _sz, _i64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_in
 SIGNATURES = {
     "fresco_version": (_c.c_char_p, []),
     "fresco_last_error": (_c.c_char_p, []),
+    "fresco_prof_enable": (_i, [_i]),
+    "fresco_prof_disable": (_i, []),
+    "fresco_prof_read": (_i, [_i, _vp, _vp, _vp]),
     "fresco_attn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fresco_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i64, _f, _f, _vp]),
     "fresco_temporal_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "fresco_temporal_attn_sharded": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
     "fresco_flow_warp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fresco_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "fresco_max_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -17,6 +17,7 @@
 // MFMA 32x32x16 f16 operand layout used below (gfx950): lane l supplies 8 consecutive k for
 // row/col (l & 31), k-chunk (l >> 5); C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
 #include "common.h"
+#include <type_traits>
 
 namespace fresco {
 
@@ -34,11 +35,16 @@ struct AttnCfg {
     static constexpr int LDS_BYTES = 2 * (KTILE + VTILE);
     static constexpr int KCH = 64 * NKC;  // 16-byte chunks in a K tile
     static constexpr int VCH = DPV * 8;   // 16-byte chunks in a V^T tile
+    static constexpr bool ONES = DPV > D;  // spare V^T row D holds ones: the PV MFMA also yields the row sum
     static constexpr int KPT = (KCH + 255) / 256;
     static constexpr int VPT = (VCH + 255) / 256;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// online softmax: skip the O rescale while the tile max grows by less than this (log2 units);
+// P then reaches at most 2^8 = 256, far inside fp16 range, and stays exactly normalised by the row sum
+#define RESCALE_THR 8.0f
 
 static inline int mpad_of(int M) { return (M + 63) / 64 * 64; }
 
@@ -91,7 +97,14 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
         const int d = c >> 3, kc = c & 7;
         half8_t o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (d < D) ? vs[kc * 8 + j][d] : (half_t)0;
+        for (int j = 0; j < 8; ++j) {
+            half_t val = (half_t)0;
+            if (d < D)
+                val = vs[kc * 8 + j][d];
+            else if (Cfg::ONES && d == D && rows[kc * 8 + j] >= 0)
+                val = (half_t)1;  // ones row: only real keys count towards the softmax denominator
+            o[j] = val;
+        }
         *reinterpret_cast<half8_t*>(vdst + (int64_t)d * Mpad + kc * 8) = o;
     }
 }
@@ -186,77 +199,78 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restric
     for (int db = 0; db < Cfg::NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = -1e30f;  // running max, in the scaled log2 domain
-    float l_run = 0.f;     // this lane's half of the row sum (its 32 of every 64 keys)
+    float m_run = -1e30f;  // reference max of the exponent, scaled log2 domain (>= true max - RESCALE_THR)
+    float l_run = 0.f;     // row sum when V^T has no spare row for the ones-trick (this lane's keys)
 
     load_tile(0);
     store_tile(0);
     __syncthreads();
 
     const bool need_diag = diag_bias_log2 != 0.f;
-    for (int t = 0; t < nT; ++t) {
+
+    // One 64-key tile.  FIX = true adds the per-element fix-ups (padded keys of the last tile,
+    // diagonal bias); it is a separate instantiation so that the common path carries none of it.
+    auto tile = [&](int t, auto fix_c) {
+        constexpr bool FIX = decltype(fix_c)::value;
         const int buf = t & 1;
         if (t + 1 < nT) load_tile(t + 1);
-
         const char* kb = smem + buf * (Cfg::KTILE + Cfg::VTILE);
         const char* vb = kb + Cfg::KTILE;
 
-        // ---- S^T = K Q^T : two 32-key blocks --------------------------------------------------
-        floatx16 s[2];
+        // ---- S^T = K Q^T : two independent 32-key accumulators, interleaved ---------------------
+        floatx16 s0, s1;
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kbk][r] = 0.f;
-            const char* kr = kb + (kbk * 32 + krow) * Cfg::KROW + hi * 16;
-#pragma unroll
-            for (int ks = 0; ks < Cfg::NKS; ++ks) {
-                const half8_t a = *reinterpret_cast<const half8_t*>(kr + ks * 32);
-                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[kbk], 0, 0, 0);
-            }
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = 0.f;
+            s1[r] = 0.f;
         }
-
-        // ---- rare paths: padded keys of the last tile, diagonal bias --------------------------
-        const bool tail = (t == nT - 1) && (Mpad != M);
-        if (tail || need_diag) {
+        const char* kr = kb + krow * Cfg::KROW + hi * 16;
 #pragma unroll
-            for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + kbk * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    float x = s[kbk][r];
-                    if (need_diag && key == qrow) x += diag_bias_log2 / scale_log2;
-                    if (key >= M) x = -1e30f / scale_log2;
-                    s[kbk][r] = x;
-                }
+        for (int ks = 0; ks < Cfg::NKS; ++ks) {
+            const half8_t a0 = *reinterpret_cast<const half8_t*>(kr + ks * 32);
+            const half8_t a1 = *reinterpret_cast<const half8_t*>(kr + 32 * Cfg::KROW + ks * 32);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[ks], s1, 0, 0, 0);
         }
-
-        // ---- online softmax, one query per lane -----------------------------------------------
-        float mt = s[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt * scale_log2);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-        half8_t pf[4];
-#pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk)
+        if (FIX) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(fmaf(s[kbk][r], scale_log2, -m_new));
-                psum += p;
-                pf[kbk * 2 + (r >> 3)][r & 7] = (half_t)p;
+                const int key0 = t * 64 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                if (need_diag && key0 == qrow) s0[r] += diag_bias_log2 / scale_log2;
+                if (need_diag && key0 + 32 == qrow) s1[r] += diag_bias_log2 / scale_log2;
+                if (key0 >= M) s0[r] = -1e30f / scale_log2;
+                if (key0 + 32 >= M) s1[r] = -1e30f / scale_log2;
             }
-        l_run = fmaf(l_run, alpha, psum);
-#pragma unroll
-        for (int db = 0; db < Cfg::NDB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
 
-        // ---- O^T += V^T P^T ---------------------------------------------------------------------
+        // ---- online softmax, one query per lane; rescale only when the max grew by > RESCALE_THR
+        float mt = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s0[r], s1[r]));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2;
+        if (__any(mt > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < Cfg::NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        half8_t pf[4];
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2, -m_run));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2, -m_run));
+            if (!Cfg::ONES) psum += p0 + p1;
+            pf[r >> 3][r & 7] = (half_t)p0;
+            pf[2 + (r >> 3)][r & 7] = (half_t)p1;
+        }
+        if (!Cfg::ONES) l_run += psum;
+
+        // ---- O^T += V^T P^T  (row D of V^T is all ones when it is spare: O^T[D] = row sum) ---------
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             const char* vr = vb + l31 * Cfg::VROW + (kc * 16 + hi * 8) * 2;
@@ -266,13 +280,31 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restric
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[kc], o[db], 0, 0, 0);
             }
         }
-
         if (t + 1 < nT) store_tile(buf ^ 1);
         __syncthreads();
+    };
+
+    const std::integral_constant<bool, true> fix_on;
+    const std::integral_constant<bool, false> fix_off;
+    if (need_diag) {
+        for (int t = 0; t < nT; ++t) tile(t, fix_on);
+    } else {
+        for (int t = 0; t < nT - 1; ++t) tile(t, fix_off);
+        if (Mpad != M)
+            tile(nT - 1, fix_on);
+        else
+            tile(nT - 1, fix_off);
     }
 
     // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if (Cfg::ONES) {
+        // O^T row D: C-tile row rr = D % 32 lives in register (rr&3) + 4*(rr>>3) of lanes with hi = (rr>>2)&1
+        constexpr int rr = D % 32;
+        l_tot = __shfl(o[D / 32][(rr & 3) + 4 * (rr >> 3)], l31 + 32 * ((rr >> 2) & 1), 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.f / l_tot;
     if (qrow < Lq) {
         half_t* op = out + ((int64_t)b * Lq + qrow) * C + h * D;
@@ -300,8 +332,11 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
     half_t* kp = reinterpret_cast<half_t*>(ws);
     half_t* vt = kp + (size_t)n_groups * H * Mpad * Cfg::DPK;
     dim3 pg(Mpad / 64, H, n_groups);
-    hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, H, M, Mpad,
-                       group_rows);
+    {
+        ProfScope ps(FRESCO_PROF_KV_PACK, n_groups, H, M, D, st);
+        hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, H, M, Mpad,
+                           group_rows);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<D>),
@@ -310,8 +345,11 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
     }
     const int nQblk = (Lq + 127) / 128;
     const float log2e = 1.4426950408889634f;
-    hipLaunchKernelGGL((attn_flash_kernel<D>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
-                       kp, vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e);
+    {
+        ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
+        hipLaunchKernelGGL((attn_flash_kernel<D>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
+                           kp, vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e);
+    }
     return check_launch();
 }
 

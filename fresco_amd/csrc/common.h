@@ -24,6 +24,14 @@ static inline int check_launch() {
     return FRESCO_OK;
 }
 
+// Opt-in kernel timing (fresco_prof_*): brackets selected launches with HIP events on the launch stream.
+struct ProfScope {
+    bool on;
+    hipStream_t st;
+    ProfScope(int tag, int a, int b, int c, int d, hipStream_t s);
+    ~ProfScope();
+};
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -19,7 +19,8 @@ template <int D>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v,
     const int64_t* __restrict__ fwd_map, const uint8_t* __restrict__ mask, half_t* __restrict__ out,
-    int N, int HW, int H, int PB, float scale_log2) {
+    int N, int HW, int H, int PB, float scale_log2, int n_loc, int f0, int k_rank_stride,
+    int v_rank_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = H * D;
     const int CC = C / 8;  // 16-byte chunks per row
@@ -45,9 +46,11 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(
         const int row = rows[r];
         uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
         if (row >= 0) {
-            const int64_t off = (((int64_t)(c * N + g)) * HW + row) * C + cc * 8;
-            kv = *reinterpret_cast<const uint4*>(k + off);
-            vv = *reinterpret_cast<const uint4*>(v + off);
+            // frame g lives on shard g / n_loc as local frame g % n_loc (single GPU: n_loc = N)
+            const int sh = g / n_loc, gl = g - sh * n_loc;
+            const int64_t roff = (int64_t)row * C + cc * 8;
+            kv = *reinterpret_cast<const uint4*>(k + ((int64_t)(sh * k_rank_stride + c * n_loc + gl)) * HW * C + roff);
+            vv = *reinterpret_cast<const uint4*>(v + ((int64_t)(sh * v_rank_stride + c * n_loc + gl)) * HW * C + roff);
         }
         *reinterpret_cast<uint4*>(ks + (size_t)r * C + cc * 8) = kv;
         *reinterpret_cast<uint4*>(vs + (size_t)r * C + cc * 8) = vv;
@@ -55,13 +58,14 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(
     __syncthreads();
 
     const int h = tid % H;
-    const int f = (tid / H) % N;
-    const int pl = tid / (H * N);
+    const int fl = (tid / H) % n_loc;  // local query frame
+    const int f = f0 + fl;             // its global frame index
+    const int pl = tid / (H * n_loc);
     const int p = p0 + pl;
     if (pl >= PB || p >= HW) return;
 
     const int myrow = rows[pl * N + f];
-    const int64_t qoff = (((int64_t)(c * N + f)) * HW + myrow) * C + h * D;
+    const int64_t qoff = (((int64_t)(c * n_loc + fl)) * HW + myrow) * C + h * D;
     float qf[D];
 #pragma unroll
     for (int j = 0; j < D / 8; ++j) {
@@ -111,8 +115,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(
 template <int D>
 static int launch_temporal(const half_t* q, const half_t* k, const half_t* v, const int64_t* fwd_map,
                            const uint8_t* mask, half_t* out, int chunk, int N, int HW, int H,
-                           float scale, hipStream_t st) {
-    const int tpp = N * H;  // threads per trajectory
+                           float scale, int n_loc, int f0, int krs, int vrs, hipStream_t st) {
+    const int tpp = n_loc * H;  // threads per trajectory
     if (tpp > 256) return FRESCO_EUNSUPPORTED;
     int PB = 256 / tpp;
     const int C = H * D;
@@ -127,8 +131,9 @@ static int launch_temporal(const half_t* q, const half_t* k, const half_t* v, co
         attr_lds = lds;
     }
     dim3 grid((HW + PB - 1) / PB, chunk);
+    ProfScope ps(FRESCO_PROF_TEMPORAL, chunk * N, HW, H, D, st);
     hipLaunchKernelGGL((temporal_attn_kernel<D>), grid, dim3(256), lds, st, q, k, v, fwd_map, mask, out,
-                       N, HW, H, PB, scale * 1.4426950408889634f);
+                       N, HW, H, PB, scale * 1.4426950408889634f, n_loc, f0, krs, vrs);
     return check_launch();
 }
 
@@ -136,11 +141,14 @@ static int launch_temporal(const half_t* q, const half_t* k, const half_t* v, co
 
 using namespace fresco;
 
-extern "C" int fresco_temporal_attn(const void* q, const void* k, const void* v, const int64_t* fwd_map,
-                                    const uint8_t* mask, void* out, int chunk, int N, int HW, int H,
-                                    int D, float scale, void* stream) {
+extern "C" int fresco_temporal_attn_sharded(const void* q, const void* k, const void* v,
+                                            const int64_t* fwd_map, const uint8_t* mask, void* out,
+                                            int chunk, int N, int HW, int H, int D, float scale, int n_loc,
+                                            int f0, int k_rank_stride, int v_rank_stride, void* stream) {
     if (!q || !k || !v || !fwd_map || !mask || !out) return FRESCO_EINVAL;
     if (chunk <= 0 || N <= 0 || HW <= 0 || H <= 0 || D <= 0) return FRESCO_EINVAL;
+    if (n_loc <= 0 || N % n_loc != 0 || f0 < 0 || f0 + n_loc > N || f0 % n_loc != 0) return FRESCO_EINVAL;
+    if (k_rank_stride < 0 || v_rank_stride < 0) return FRESCO_EINVAL;
     hipStream_t st = as_stream(stream);
     const half_t* qh = static_cast<const half_t*>(q);
     const half_t* kh = static_cast<const half_t*>(k);
@@ -148,7 +156,8 @@ extern "C" int fresco_temporal_attn(const void* q, const void* k, const void* v,
     half_t* oh = static_cast<half_t*>(out);
 #define FRESCO_T_CASE(DD) \
     case DD:              \
-        return launch_temporal<DD>(qh, kh, vh, fwd_map, mask, oh, chunk, N, HW, H, scale, st);
+        return launch_temporal<DD>(qh, kh, vh, fwd_map, mask, oh, chunk, N, HW, H, scale, n_loc, f0, \
+                                   k_rank_stride, v_rank_stride, st);
     switch (D) {
         FRESCO_T_CASE(8)
         FRESCO_T_CASE(16)
@@ -160,4 +169,11 @@ extern "C" int fresco_temporal_attn(const void* q, const void* k, const void* v,
             return FRESCO_EUNSUPPORTED;
     }
 #undef FRESCO_T_CASE
+}
+
+extern "C" int fresco_temporal_attn(const void* q, const void* k, const void* v, const int64_t* fwd_map,
+                                    const uint8_t* mask, void* out, int chunk, int N, int HW, int H,
+                                    int D, float scale, void* stream) {
+    return fresco_temporal_attn_sharded(q, k, v, fwd_map, mask, out, chunk, N, HW, H, D, scale, N, 0, 0, 0,
+                                        stream);
 }

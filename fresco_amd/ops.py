@@ -67,9 +67,9 @@ def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, gro
     q = q.contiguous()
     k = k.contiguous().view(-1, C)
     v = v.contiguous().view(-1, C)
-    if k.shape != v.shape:
-        raise ValueError("k and v must have the same shape")
     if n_groups is None:
+        if k.shape != v.shape:
+            raise ValueError("k and v must have the same shape")
         n_groups = B
         group_rows = k.shape[0] // B
         M = group_rows
@@ -78,8 +78,9 @@ def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, gro
             raise TypeError("kv_rows must be int32")
         kv_rows = kv_rows.contiguous()
         M = kv_rows.numel()
-    if n_groups * group_rows > k.shape[0]:
-        raise ValueError("k has %d rows, grouping needs %d" % (k.shape[0], n_groups * group_rows))
+    if kv_rows is None and ((n_groups - 1) * group_rows + M > min(k.shape[0], v.shape[0])):
+        raise ValueError("k/v have %d/%d rows, grouping needs %d" % (k.shape[0], v.shape[0],
+                                                                     (n_groups - 1) * group_rows + M))
     lib = _lib.load()
     ws_bytes = lib.fresco_attn_workspace_bytes(n_groups, heads, M, D)
     ws = (workspace or _default_ws).get(ws_bytes, q.device)
@@ -91,13 +92,22 @@ def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, gro
     return out
 
 
-def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk):
-    """fresco_temporal_attn: q, k, v (chunk*N, HW, C) fp16; fwd_map (N,HW) int64; mask (HW,N,N) bool."""
+def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk, shard=None):
+    """fresco_temporal_attn: q, k, v (chunk*N, HW, C) fp16; fwd_map (N,HW) int64; mask (HW,N,N) bool.
+
+    shard = (N, n_loc, f0, k_rank_stride, v_rank_stride): frame-sharded form -- q is local
+    (chunk*n_loc, HW, C) and k, v are all-gathered buffers holding all N frames (see
+    fresco_temporal_attn_sharded in include/fresco_hip.h)."""
     _need_gpu(q, k, v, fwd_map, mask)
     if q.dtype != torch.float16 or k.dtype != torch.float16 or v.dtype != torch.float16:
         raise TypeError("fresco_amd.temporal_attention: fp16 tensors required")
     Bt, HW, C = q.shape
-    N = Bt // chunk
+    if shard is None:
+        N = Bt // chunk
+        n_loc, f0, krs, vrs = N, 0, 0, 0
+    else:
+        N, n_loc, f0, krs, vrs = shard
+        assert Bt == chunk * n_loc
     D = C // heads
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     fwd_map = fwd_map.reshape(N, HW)
@@ -111,10 +121,10 @@ def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk):
         mask = (mask != 0).contiguous().view(torch.uint8)
     mask = mask.contiguous()
     out = torch.empty_like(q)
-    rc = _lib.load().fresco_temporal_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), fwd_map.data_ptr(),
-                                          mask.data_ptr(), out.data_ptr(), chunk, N, HW, heads, D,
-                                          float(scale), _stream())
-    _lib.check(rc, "fresco_temporal_attn(chunk=%d,N=%d,HW=%d,H=%d,D=%d)" % (chunk, N, HW, heads, D))
+    rc = _lib.load().fresco_temporal_attn_sharded(q.data_ptr(), k.data_ptr(), v.data_ptr(), fwd_map.data_ptr(),
+                                                  mask.data_ptr(), out.data_ptr(), chunk, N, HW, heads, D,
+                                                  float(scale), n_loc, f0, krs, vrs, _stream())
+    _lib.check(rc, "fresco_temporal_attn(chunk=%d,N=%d,n_loc=%d,HW=%d,H=%d,D=%d)" % (chunk, N, n_loc, HW, heads, D))
     return out
 
 

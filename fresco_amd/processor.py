@@ -26,6 +26,7 @@ class FRESCOAttnProcessor2_0:
         self.controller = controller
         self._ws = ops.Workspace()
         self._rows_cache = {}
+        self.shard = None  # fresco_amd.dist.FrameShard for frame-parallel multi-GPU runs
 
     # flat int32 indices of the True entries of a (N, HW) mask, cached per mask tensor
     def _kv_rows(self, mask):
@@ -64,6 +65,9 @@ class FRESCOAttnProcessor2_0:
             encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
         key = attn.to_k(encoder_hidden_states)
         value = attn.to_v(encoder_hidden_states)
+        if self.shard is not None and ctrl and not crossattn and (ctrl.use_cfattn or ctrl.use_interattn):
+            return self._sharded_self_attention(attn, hidden_states, query, key, value, residual,
+                                                input_ndim)
 
         heads = attn.heads
         head_dim = key.shape[-1] // heads
@@ -118,8 +122,73 @@ class FRESCOAttnProcessor2_0:
             hs = hs.transpose(-1, -2).reshape(batch_size, channel, height, width)
         if attn.residual_connection:
             hs = hs + residual
-        hs = hs / attn.rescale_output_factor
+        if attn.rescale_output_factor != 1.0:  # x / 1.0 == x exactly: skip the elementwise pass
+            hs = hs / attn.rescale_output_factor
         return hs
+
+
+def _sharded_self_attention(self, attn, hidden_states, query, key, value, residual, input_ndim):
+    """Frame-parallel form of the FRESCO self-attention branch (fresco_amd/dist.py): this rank holds
+    `shard.n_loc` frames of both CFG halves; K|V (and the cross-frame output, for the temporal pass)
+    are all-gathered over RCCL, everything else is local."""
+    if input_ndim != 3:
+        raise NotImplementedError("fresco_amd: frame-sharded attention expects (B, HW, C) hidden states")
+    ctrl, sh = self.controller, self.shard
+    chunk = self.unet_chunk_size
+    heads = attn.heads
+    B_loc, hw, C = key.shape
+    head_dim = C // heads
+    sm_scale = 1.0 / math.sqrt(head_dim)
+    assert B_loc == sh.B_loc and chunk == sh.chunk
+    # exchange 1: fused K|V, launched before the local work it overlaps with
+    kv, work = sh.all_gather(torch.stack((key, value)), async_op=True)
+    q_att = query
+    if ctrl.use_intraattn:
+        ref = ctrl(None)
+        assert ref.shape == hidden_states.shape
+        q_att = ops.attention(attn.to_q(ref), attn.to_k(ref), query, heads,
+                              ctrl.intraattn_scale_factor * sm_scale, diag_bias=float(ctrl.intraattn_bias),
+                              workspace=self._ws)
+    if work is not None:
+        work.wait()
+    kv_flat = kv.view(-1, C)  # rows of (world, 2, B_loc, HW)
+    if ctrl.use_cfattn:
+        mask = None
+        if ctrl.attn_mask is not None:
+            for m in ctrl.attn_mask:
+                if m.shape[1] == hw:
+                    mask = m
+        if mask is not None:
+            key_id = (mask.data_ptr(), tuple(mask.shape), mask._version)
+            rows, group_rows = sh.kv_rows(self._kv_rows(mask), hw, key_id, key.device)
+        else:
+            rows, group_rows = sh.kv_rows(None, hw, ("frame0", hw), key.device)
+        hs = ops.attention(q_att, kv_flat, kv_flat[B_loc * hw:], heads, sm_scale, kv_rows=rows,
+                           n_groups=chunk, M=rows.numel(), group_rows=group_rows, workspace=self._ws)
+    else:
+        hs = ops.attention(q_att, key, value, heads, sm_scale, workspace=self._ws)
+    if ctrl.use_interattn:
+        fwd_mapping = interattn_mask = None
+        paras = ctrl.interattn_paras
+        for i, f in enumerate(paras["fwd_mappings"]):
+            if f.shape[2] == hw:
+                fwd_mapping = f
+                interattn_mask = paras["interattn_masks"][i]
+        # exchange 2: the cross-frame output of every frame is the temporal pass's V
+        hs_all, _ = sh.all_gather(hs)
+        hs = ops.temporal_attention(query, kv_flat, hs_all.view(-1, C), fwd_mapping, interattn_mask, heads,
+                                    ctrl.interattn_scale_factor * sm_scale, chunk,
+                                    shard=(sh.N, sh.n_loc, sh.f0, 2 * B_loc, B_loc))
+    hs = attn.to_out[0](hs.to(query.dtype))
+    hs = attn.to_out[1](hs)
+    if attn.residual_connection:
+        hs = hs + residual
+    if attn.rescale_output_factor != 1.0:
+        hs = hs / attn.rescale_output_factor
+    return hs
+
+
+FRESCOAttnProcessor2_0._sharded_self_attention = _sharded_self_attention
 
 
 def apply_FRESCO_attn(pipe):

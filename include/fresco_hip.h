@@ -8,7 +8,8 @@
  *   - never allocates: scratch memory is passed in by the caller, sized by the matching
  *     *_workspace_bytes() query (host-only, no GPU needed);
  *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream);
- *   - no global state: concurrent calls on different streams with disjoint buffers are safe.
+ *   - no global state (except the opt-in fresco_prof_* timing log): concurrent calls on different
+ *     streams with disjoint buffers are safe.
  *
  * Reference interface each entry point replaces (paths relative to the FRESCO tree):
  *   src/diffusion_hacked.py  = DH,  src/flow_utils.py = FU,  src/utils.py = UT,
@@ -40,6 +41,22 @@ extern "C" {
 const char* fresco_version(void);
 /* last HIP error string seen by a FRESCO_ELAUNCH on this thread ("" if none) */
 const char* fresco_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Opt-in kernel timing for bench.py's roofline figures (the ONLY process-global state of the
+ * library; off by default).  While enabled, the launches tagged below are bracketed by HIP events
+ * recorded on the launch stream.  fresco_prof_read synchronises on the recorded events, returns the
+ * number of records copied (launch order) and clears the log.
+ *   tags[i], dims[4*i..4*i+3], ms[i]:
+ *     FRESCO_PROF_ATTN_FLASH : dims = {B*H, Lq, M, D}     FRESCO_PROF_KV_PACK : {groups, H, M, D}
+ *     FRESCO_PROF_TEMPORAL   : dims = {chunk*N, HW, H, D}
+ * ------------------------------------------------------------------------------------------ */
+#define FRESCO_PROF_ATTN_FLASH 1
+#define FRESCO_PROF_KV_PACK 2
+#define FRESCO_PROF_TEMPORAL 3
+int fresco_prof_enable(int capacity);
+int fresco_prof_disable(void);
+int fresco_prof_read(int max_records, int* tags, int* dims, float* ms);
 
 /* ------------------------------------------------------------------------------------------
  * (a2 + a3)  Dense attention with shared / per-batch keys  -- replaces the two
@@ -84,6 +101,16 @@ int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* 
 int fresco_temporal_attn(const void* q, const void* k, const void* v, const int64_t* fwd_map,
                          const uint8_t* mask, void* out,
                          int chunk, int N, int HW, int H, int D, float scale, void* stream);
+
+/* Frame-sharded form (multi-GPU): this rank owns the n_loc frames [f0, f0+n_loc) of
+ * both CFG halves.  q, out : (chunk*n_loc, HW, H*D) local.  k, v hold ALL N frames as written by an
+ * all-gather over ranks: frame g of CFG half c is batch  (g/n_loc)*rank_stride + c*n_loc + g%n_loc
+ * (k_rank_stride / v_rank_stride in batches of HW rows; e.g. 2*chunk*n_loc for a fused K|V gather
+ * buffer, chunk*n_loc for a plain one).  n_loc = N, f0 = 0 is fresco_temporal_attn. */
+int fresco_temporal_attn_sharded(const void* q, const void* k, const void* v, const int64_t* fwd_map,
+                                 const uint8_t* mask, void* out,
+                                 int chunk, int N, int HW, int H, int D, float scale,
+                                 int n_loc, int f0, int k_rank_stride, int v_rank_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a8)  flow_warp / bilinear_sample  (GEO:41-72): bilinear, zeros padding, align_corners=True.

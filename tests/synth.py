@@ -111,7 +111,7 @@ def controller_for(case, mode, device):
 
     c = fresco_amd.AttentionControl()
     if mode == "full":
-        c.stored_attn["decoder_attn"] = [case["ref"].to(device)]
+        c.stored_attn["decoder_attn"] = [case["ref"].to(device).to(case.get("dtype", torch.float16))]
         c.enable_intraattn()
     if mode in ("full", "cf_temporal", "temporal"):
         c.enable_interattn(dict(fwd_mappings=[case["fwd_map"].to(device)],

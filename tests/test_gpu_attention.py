@@ -1,5 +1,6 @@
 """GPU parity of the attention kernels and the processor against the CPU oracle / reference goldens.
 Every call goes through the C ABI of libfresco_hip.so (fresco_amd.ops -> ctypes)."""
+import copy
 import math
 
 import numpy as np
@@ -125,7 +126,7 @@ def _run_processor(case, mode, device=DEV):
     import fresco_amd
     ctrl = synth.controller_for(case, mode, device)
     proc = fresco_amd.FRESCOAttnProcessor2_0(2, ctrl if mode != "plain" else fresco_amd.AttentionControl())
-    attn = case["attn"].to(device).half()
+    attn = copy.deepcopy(case["attn"]).to(device).half()  # the case keeps its CPU fp32 module for the oracle
     with torch.no_grad():
         return proc(attn, case["hidden"].to(device).half())
 

@@ -102,7 +102,9 @@ def test_single_adam_step_and_kat6(kat6, golden):
         assert float(df.max()) < 0.45 and float(df.median()) < 3e-6, key
 
     agree(fresco_amd.optimize_feature(xs.to(DEV), fld, ocd, cd, iters=1), "opt_k1")
-    agree(fresco_amd.optimize_feature(xs.to(DEV), fld, ocd, [], iters=1), "opt_k1_temporal")
+    # temporal-only gradients are short sums of +-k*w terms that often cancel to |g| ~ 1e-9, where
+    # 0.2*g/(|g|+1e-8) amplifies summation-order noise: more outliers than with the Gram term on
+    agree(fresco_amd.optimize_feature(xs.to(DEV), fld, ocd, [], iters=1), "opt_k1_temporal", frac=0.03)
     rs = fresco_amd.optimize_feature(xs.to(DEV), None, None, cd, iters=1)
     assert float((rs.cpu() - T(golden["opt_k1_spatial"])).abs().max()) < 2e-4
     assert fresco_amd.optimize_feature(xs.to(DEV), None, None, [], iters=3).data_ptr() == xs.to(DEV).data_ptr() or True
