@@ -1,0 +1,131 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, host-only queries,
+loud failure without a GPU, the controller state machine against the reference's recorded trace, and
+the forward-hook logic on a stand-in UNet (no kernels are launched here)."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_exports_every_declared_symbol():
+    from fresco_amd import _lib
+    header = open(os.path.join(ROOT, "include", "fresco_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(fresco_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.fresco_version().decode().startswith("fresco_hip")
+
+
+def test_workspace_queries_are_host_only():
+    from fresco_amd import _lib
+    lib = _lib.load()
+    # cfg2 up_blocks.3 cross-frame: 2 groups x 8 heads x Mpad(4237)=4288 keys x (48 + 64) halfs
+    assert lib.fresco_attn_workspace_bytes(2, 8, 4237, 40) == 2 * 8 * 4288 * (48 + 64) * 2
+    assert lib.fresco_attn_workspace_bytes(0, 8, 10, 40) == 0
+    full = lib.fresco_opt_workspace_bytes(2, 8, 640, 64, 64, 1, 1)
+    assert full > lib.fresco_opt_workspace_bytes(2, 8, 640, 64, 64, 1, 0) > lib.fresco_opt_workspace_bytes(2, 8, 640, 64, 64, 0, 0)
+    assert full >= 16 * 4096 * 4096 + 5 * 16 * 640 * 4096 * 4
+
+
+def test_operators_refuse_cpu_tensors():
+    import fresco_amd
+    x = torch.zeros(2, 3, 4, 4)
+    with pytest.raises(fresco_amd.FrescoHipError):
+        fresco_amd.flow_warp(x, torch.zeros(2, 2, 4, 4))
+    with pytest.raises(fresco_amd.FrescoHipError):
+        fresco_amd.adaptive_instance_normalization(x, x)
+    with pytest.raises(fresco_amd.FrescoHipError):
+        fresco_amd.optimize_feature(x, [torch.zeros(1, 2, 8, 8)] * 2, [torch.zeros(1, 8, 8)] * 2, [], iters=1)
+    # the early-out contract needs no GPU (diffusion_hacked.py:423-424)
+    assert fresco_amd.optimize_feature(x, None, None, [], iters=1) is x
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from fresco_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libfresco_hip.so")
+    with pytest.raises(_lib.FrescoHipError):
+        _lib.load()
+
+
+def test_attention_control_matches_reference_trace():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import fresco_amd
+    import make_control_trace as mct
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "control_trace.json")))
+    got = mct.run(fresco_amd.AttentionControl)
+    assert got == want
+
+
+class _Blk(torch.nn.Module):
+    def __init__(self, k):
+        super().__init__()
+        self.k = k
+
+    def forward(self, hidden_states, temb=None):
+        return hidden_states + self.k
+
+
+class _UNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.up_blocks = torch.nn.ModuleList([_Blk(1.0), _Blk(10.0), _Blk(100.0)])
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, return_dict=True):
+        for b in self.up_blocks:
+            sample = b(hidden_states=sample, temb=None)
+        return (sample,) if not return_dict else {"sample": sample}
+
+
+class _Pipe:
+    def __init__(self):
+        self.unet = _UNet()
+
+
+def test_forward_hook_semantics(monkeypatch):
+    import fresco_amd
+    from fresco_amd import hook
+    calls = []
+
+    def fake_opt(sample, flows, occs, corr, intra_weight, iters, optimize_temporal=True):
+        calls.append(("opt", float(sample[0]), intra_weight, iters))
+        return sample * 2
+
+    def fake_warp(sample, flows, occs, saliency, chunk):
+        calls.append(("warp", float(sample[0]), chunk))
+        return sample + 0.5
+
+    monkeypatch.setattr(hook._opt, "optimize_feature", fake_opt)
+    monkeypatch.setattr(hook._warp, "warp_tensor", fake_warp)
+    pipe = _Pipe()
+    x = torch.zeros(1)
+    steps = torch.tensor([900, 800])
+    fresco_amd.apply_FRESCO_opt(pipe, steps=steps, layers=[0, 2], flows="f", occs="o", correlation_matrix=["c"],
+                                intra_weight=7.0, iters=3, saliency="s")
+    out = pipe.unet(x, torch.tensor(800), return_dict=False)
+    # layer 0: (0*2+0.5)+1 = 1.5 ; layer 1 untouched: 11.5 ; layer 2: (11.5*2+0.5)+100 = 123.5
+    assert float(out[0]) == 123.5
+    assert [float(t) for t in out[1:]] == [0.0, 11.5]  # up_samples = inputs of layers 0 and 2 BEFORE optimisation
+    assert calls == [("opt", 0.0, 7.0, 3), ("warp", 0.0, 2), ("opt", 11.5, 7.0, 3), ("warp", 23.0, 2)]
+    calls.clear()
+    out = pipe.unet(x, torch.tensor(700), return_dict=False)  # timestep not in steps
+    assert float(out[0]) == 111.0 and len(out) == 3 and not calls
+    assert isinstance(pipe.unet(x, 800), dict)  # return_dict=True: output untouched
+    # no saliency -> no warp; re-applying replaces (does not stack) the hooks
+    fresco_amd.apply_FRESCO_opt(pipe, steps=[800], layers=[1], flows="f", occs="o", correlation_matrix=["c"])
+    calls.clear()
+    out = pipe.unet(x, 800, return_dict=False)
+    assert float(out[0]) == 112.0 and [c[0] for c in calls] == ["opt"] and len(out) == 2
+    fresco_amd.disable_FRESCO_opt(pipe)
+    calls.clear()
+    out = pipe.unet(x, 800, return_dict=False)
+    assert float(out[0]) == 111.0 and not calls and len(out) == 1 + 3  # default layers [0,1,2,3] -> 3 blocks here
