@@ -17,6 +17,7 @@
 // MFMA 32x32x16 f16 operand layout used below (gfx950): lane l supplies 8 consecutive k for
 // row/col (l & 31), k-chunk (l >> 5); C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace fresco {
@@ -41,6 +42,14 @@ struct AttnCfg {
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// Ablation switch for tools/ablate_attn.hip (timing experiments only; the product build uses 0):
+// 1 = no exp (P = exponent argument), 2 = no softmax VALU at all, 3 = no PV MFMAs, 4 = no QK MFMAs,
+// 5 = no K/V staging (tile 0 reused, no barrier), 6 = no LDS fragment reads (constant fragments)
+#ifndef FRESCO_ABL
+#define FRESCO_ABL 0
+#endif
 
 // online softmax: skip the O rescale while the tile max grows by less than this (log2 units);
 // P then reaches at most 2^8 = 256, far inside fp16 range, and stays exactly normalised by the row sum
@@ -110,12 +119,14 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// flash attention: grid (H * nQblk * B), 256 threads = 4 waves x 32 query rows
+// flash attention: grid (H * nQblk * B), 256 threads = 4 waves x QB blocks of 32 query rows
 // blockIdx.x = (b * nQblk + qblk) * H + h   -> head h lands on XCD (h % 8): each XCD's L2 holds
 // only its own heads' packed K / V^T.
+// QB = 2: every K / V^T fragment read from LDS feeds two MFMAs and the two query blocks give the
+// scheduler independent MFMA (block j) and VALU softmax (block 1-j) streams to overlap in one wave.
 // ---------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restrict__ q,
+template <int D, int QB, int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __restrict__ q,
                                                           const half_t* __restrict__ kp,
                                                           const half_t* __restrict__ vt,
                                                           half_t* __restrict__ out, int B, int H, int Lq,
@@ -123,8 +134,9 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restric
                                                           float scale_log2, float diag_bias_log2) {
     using Cfg = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = 128 * QB;  // query rows per workgroup
 
-    const int nQblk = (Lq + 127) / 128;
+    const int nQblk = (Lq + ROWS - 1) / ROWS;
     const int h = blockIdx.x % H;
     const int qblk = (blockIdx.x / H) % nQblk;
     const int b = blockIdx.x / (H * nQblk);
@@ -134,22 +146,23 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restric
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int qrow = qblk * 128 + wave * 32 + l31;
-    const int qrow_c = qrow < Lq ? qrow : Lq - 1;
+    const int qrow0 = qblk * ROWS + wave * 32 * QB + l31;  // row of query block 0; block j: + 32*j
     // S^T row (lane & 31) is fed with key  swap_bits_2_3(lane & 31): the C-tile registers of a
     // lane then hold keys 16*(r>>3) + 8*hi + (r&7), i.e. 8 consecutive keys per MFMA k-chunk.
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
 
     // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
-    half8_t qf[Cfg::NKS];
-    {
-        const half_t* qp = q + ((int64_t)b * Lq + qrow_c) * C + h * D;
+    half8_t qf[QB][Cfg::NKS];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const int qr = qrow0 + 32 * j;
+        const half_t* qp = q + ((int64_t)b * Lq + (qr < Lq ? qr : Lq - 1)) * C + h * D;
 #pragma unroll
         for (int ks = 0; ks < Cfg::NKS; ++ks) {
             const int d0 = ks * 16 + hi * 8;
             half8_t t = {0, 0, 0, 0, 0, 0, 0, 0};
             if (d0 < D) t = *reinterpret_cast<const half8_t*>(qp + d0);
-            qf[ks] = t;
+            qf[j][ks] = t;
         }
     }
 
@@ -194,13 +207,17 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restric
         }
     };
 
-    floatx16 o[Cfg::NDB];
+    floatx16 o[QB][Cfg::NDB];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int db = 0; db < Cfg::NDB; ++db)
+    for (int j = 0; j < QB; ++j) {
+        m_run[j] = -1e30f;  // reference max of the exponent, scaled log2 domain (>= true max - RESCALE_THR)
+        l_run[j] = 0.f;     // row sum when V^T has no spare row for the ones-trick (this lane's keys)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = -1e30f;  // reference max of the exponent, scaled log2 domain (>= true max - RESCALE_THR)
-    float l_run = 0.f;     // row sum when V^T has no spare row for the ones-trick (this lane's keys)
+        for (int db = 0; db < Cfg::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[j][db][r] = 0.f;
+    }
 
     load_tile(0);
     store_tile(0);
@@ -212,63 +229,100 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restric
     // diagonal bias); it is a separate instantiation so that the common path carries none of it.
     auto tile = [&](int t, auto fix_c) {
         constexpr bool FIX = decltype(fix_c)::value;
-        const int buf = t & 1;
-        if (t + 1 < nT) load_tile(t + 1);
+        const int buf = (FRESCO_ABL == 5) ? 0 : (t & 1);
+        if (FRESCO_ABL != 5 && t + 1 < nT) load_tile(t + 1);
         const char* kb = smem + buf * (Cfg::KTILE + Cfg::VTILE);
         const char* vb = kb + Cfg::KTILE;
 
-        // ---- S^T = K Q^T : two independent 32-key accumulators, interleaved ---------------------
-        floatx16 s0, s1;
+        // ---- S^T = K Q^T : per query block two independent 32-key accumulators ------------------
+        floatx16 s[QB][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = 0.f;
-            s1[r] = 0.f;
-        }
+        for (int j = 0; j < QB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[j][0][r] = 0.f;
+                s[j][1][r] = 0.f;
+            }
         const char* kr = kb + krow * Cfg::KROW + hi * 16;
 #pragma unroll
         for (int ks = 0; ks < Cfg::NKS; ++ks) {
-            const half8_t a0 = *reinterpret_cast<const half8_t*>(kr + ks * 32);
-            const half8_t a1 = *reinterpret_cast<const half8_t*>(kr + 32 * Cfg::KROW + ks * 32);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[ks], s1, 0, 0, 0);
-        }
-        if (FIX) {
+            half8_t a0, a1;
+            if (FRESCO_ABL == 6) {
+                a0 = qf[0][ks];
+                a1 = qf[0][ks];
+            } else {
+                a0 = *reinterpret_cast<const half8_t*>(kr + ks * 32);
+                a1 = *reinterpret_cast<const half8_t*>(kr + 32 * Cfg::KROW + ks * 32);
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key0 = t * 64 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                if (need_diag && key0 == qrow) s0[r] += diag_bias_log2 / scale_log2;
-                if (need_diag && key0 + 32 == qrow) s1[r] += diag_bias_log2 / scale_log2;
-                if (key0 >= M) s0[r] = -1e30f / scale_log2;
-                if (key0 + 32 >= M) s1[r] = -1e30f / scale_log2;
+            for (int j = 0; j < QB; ++j) {
+                if (FRESCO_ABL == 4) {
+                    s[j][0][ks] += (float)a0[0];
+                    s[j][1][ks] += (float)a1[0];
+                } else {
+                    s[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[j][ks], s[j][0], 0, 0, 0);
+                    s[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[j][ks], s[j][1], 0, 0, 0);
+                }
             }
         }
 
-        // ---- online softmax, one query per lane; rescale only when the max grew by > RESCALE_THR
-        float mt = fmaxf(s0[0], s1[0]);
+        half8_t pf[QB][4];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s0[r], s1[r]));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2;
-        if (__any(mt > m_run + RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, mt);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
+        for (int j = 0; j < QB; ++j) {
+            if (FRESCO_ABL == 2) {  // keep S live, skip all softmax arithmetic
 #pragma unroll
-            for (int db = 0; db < Cfg::NDB; ++db)
+                for (int r = 0; r < 16; ++r) {
+                    asm volatile("" ::"v"(s[j][0][r]), "v"(s[j][1][r]));
+                    pf[j][r >> 3][r & 7] = (half_t)0.01f;
+                    pf[j][2 + (r >> 3)][r & 7] = (half_t)0.01f;
+                }
+                continue;
+            }
+            if (FIX) {
+                const int qr = qrow0 + 32 * j;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) {
+                    const int key0 = t * 64 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (need_diag && key0 == qr) s[j][0][r] += diag_bias_log2 / scale_log2;
+                    if (need_diag && key0 + 32 == qr) s[j][1][r] += diag_bias_log2 / scale_log2;
+                    if (key0 >= M) s[j][0][r] = -1e30f / scale_log2;
+                    if (key0 + 32 >= M) s[j][1][r] = -1e30f / scale_log2;
+                }
+            }
+            // ---- online softmax, one query per lane; rescale only when the max grew by > RESCALE_THR
+            float mt = fmaxf(s[j][0][0], s[j][1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[j][0][r]), s[j][1][r]);  // v_max3_f32
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2;
+            if (__any(mt > m_run[j] + RESCALE_THR)) {
+                const float m_new = fmaxf(m_run[j], mt);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+                m_run[j] = m_new;
+                l_run[j] *= alpha;
+#pragma unroll
+                for (int db = 0; db < Cfg::NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[j][db][r] *= alpha;
+            }
+            float psum = 0.f;
+            // exponent arguments two at a time (v_pk_fma_f32 on adjacent accumulator registers:
+            // one issue slot per pair)
+            const floatx2 sc2 = {scale_log2, scale_log2};
+            const floatx2 nm2 = {-m_run[j], -m_run[j]};
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const floatx2 sv = {s[j][kbk][r], s[j][kbk][r + 1]};
+                    const floatx2 x = __builtin_elementwise_fma(sv, sc2, nm2);
+                    const float p0 = (FRESCO_ABL == 1) ? x[0] : __builtin_amdgcn_exp2f(x[0]);
+                    const float p1 = (FRESCO_ABL == 1) ? x[1] : __builtin_amdgcn_exp2f(x[1]);
+                    if (!Cfg::ONES) psum += p0 + p1;
+                    pf[j][kbk * 2 + (r >> 3)][r & 7] = (half_t)p0;
+                    pf[j][kbk * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
+                }
+            if (!Cfg::ONES) l_run[j] += psum;
         }
-        half8_t pf[4];
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2, -m_run));
-            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2, -m_run));
-            if (!Cfg::ONES) psum += p0 + p1;
-            pf[r >> 3][r & 7] = (half_t)p0;
-            pf[2 + (r >> 3)][r & 7] = (half_t)p1;
-        }
-        if (!Cfg::ONES) l_run += psum;
 
         // ---- O^T += V^T P^T  (row D of V^T is all ones when it is spare: O^T[D] = row sum) ---------
 #pragma unroll
@@ -276,12 +330,20 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restric
             const char* vr = vb + l31 * Cfg::VROW + (kc * 16 + hi * 8) * 2;
 #pragma unroll
             for (int db = 0; db < Cfg::NDB; ++db) {
-                const half8_t a = *reinterpret_cast<const half8_t*>(vr + db * 32 * Cfg::VROW);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[kc], o[db], 0, 0, 0);
+                const half8_t a = (FRESCO_ABL == 6) ? qf[0][0] : *reinterpret_cast<const half8_t*>(vr + db * 32 * Cfg::VROW);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) {
+                    if (FRESCO_ABL == 3)
+                        o[j][db][kc] += (float)a[0] * (float)pf[j][kc][0];
+                    else
+                        o[j][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[j][kc], o[j][db], 0, 0, 0);
+                }
             }
         }
-        if (t + 1 < nT) store_tile(buf ^ 1);
-        __syncthreads();
+        if (FRESCO_ABL != 5) {
+            if (t + 1 < nT) store_tile(buf ^ 1);
+            __syncthreads();
+        }
     };
 
     const std::integral_constant<bool, true> fix_on;
@@ -297,30 +359,66 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const half_t* __restric
     }
 
     // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
-    float l_tot;
-    if (Cfg::ONES) {
-        // O^T row D: C-tile row rr = D % 32 lives in register (rr&3) + 4*(rr>>3) of lanes with hi = (rr>>2)&1
-        constexpr int rr = D % 32;
-        l_tot = __shfl(o[D / 32][(rr & 3) + 4 * (rr >> 3)], l31 + 32 * ((rr >> 2) & 1), 64);
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    }
-    const float inv = 1.f / l_tot;
-    if (qrow < Lq) {
-        half_t* op = out + ((int64_t)b * Lq + qrow) * C + h * D;
 #pragma unroll
-        for (int db = 0; db < Cfg::NDB; ++db)
+    for (int j = 0; j < QB; ++j) {
+        float l_tot;
+        if (Cfg::ONES) {
+            // O^T row D: C-tile row rr = D % 32 lives in register (rr&3) + 4*(rr>>3) of lanes with hi = (rr>>2)&1
+            constexpr int rr = D % 32;
+            l_tot = __shfl(o[j][D / 32][(rr & 3) + 4 * (rr >> 3)], l31 + 32 * ((rr >> 2) & 1), 64);
+        } else {
+            l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
+        }
+        const float inv = 1.f / l_tot;
+        const int qr = qrow0 + 32 * j;
+        if (qr < Lq) {
+            half_t* op = out + ((int64_t)b * Lq + qr) * C + h * D;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = db * 32 + g4 * 8 + hi * 4;
-                if (d0 < D) {
-                    half4_t w;
+            for (int db = 0; db < Cfg::NDB; ++db)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w[j] = (half_t)(o[db][g4 * 4 + j] * inv);
-                    *reinterpret_cast<half4_t*>(op + d0) = w;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = db * 32 + g4 * 8 + hi * 4;
+                    if (d0 < D) {
+                        half4_t w;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) w[jj] = (half_t)(o[j][db][g4 * 4 + jj] * inv);
+                        *reinterpret_cast<half4_t*>(op + d0) = w;
+                    }
                 }
-            }
+        }
     }
+}
+
+// Query blocks per wave.  2 wherever the accumulators still fit (D <= 96); FRESCO_ATTN_QB=1|2 in the
+// environment overrides it (tuning / A-B measurements only).
+static int attn_qb_choice(int D, int Lq) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("FRESCO_ATTN_QB");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2) return forced;
+    // measured on MI355X (cfg2 shapes, round 1): QB = 1 at 3 (D <= 40) / 2 waves per SIMD beats QB = 2 at
+    // 1 wave per SIMD by ~15 %: hipcc does not interleave the two query blocks' MFMA and VALU streams
+    return 1;
+}
+
+template <int D, int QB, int MINW = (QB == 1 && D <= 40) ? 3 : (QB == 1 && D <= 80 ? 2 : 1)>
+static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, half_t* out, int B, int H,
+                         int Lq, int M, int Mpad, int n_groups, float scale, float diag_bias,
+                         hipStream_t st) {
+    using Cfg = AttnCfg<D>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<D, QB, MINW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        attr_set = true;
+    }
+    const int nQblk = (Lq + 128 * QB - 1) / (128 * QB);
+    const float log2e = 1.4426950408889634f;
+    ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
+    hipLaunchKernelGGL((attn_flash_kernel<D, QB, MINW>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q, kp,
+                       vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e);
 }
 
 template <int D>
@@ -337,19 +435,10 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
         hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, H, M, Mpad,
                            group_rows);
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        attr_set = true;
-    }
-    const int nQblk = (Lq + 127) / 128;
-    const float log2e = 1.4426950408889634f;
-    {
-        ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
-        hipLaunchKernelGGL((attn_flash_kernel<D>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
-                           kp, vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e);
-    }
+    if (D <= 96 && attn_qb_choice(D, Lq) == 2)
+        launch_flash<D, (D <= 96 ? 2 : 1)>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
+    else
+        launch_flash<D, 1>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
     return check_launch();
 }
 

@@ -591,20 +591,32 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
     const float kscale = 2.f / ((float)B * (float)C * (float)hw);
     if (has_t) {
         dim3 grid((hw + 255) / 256, (C + OCPT - 1) / OCPT, B);
-        hipLaunchKernelGGL(temporal_sign_kernel, grid, dim3(256), 0, st, cs, bwd_flow, fwd_flow, bwd_occ,
-                           fwd_occ, w.sgn1, w.sgn2, loss, N, C, h, wd);
+        {
+            ProfScope ps(FRESCO_PROF_OPT_TSIGN, B, C, hw, 0, st);
+            hipLaunchKernelGGL(temporal_sign_kernel, grid, dim3(256), 0, st, cs, bwd_flow, fwd_flow, bwd_occ,
+                               fwd_occ, w.sgn1, w.sgn2, loss, N, C, h, wd);
+        }
+        ProfScope ps(FRESCO_PROF_OPT_TGRAD, B, C, hw, 0, st);
         hipLaunchKernelGGL(temporal_grad_kernel, grid, dim3(256), 0, st, w.sgn1, w.sgn2, bwd_occ, fwd_occ,
                            w.rowptr, w.src, w.wgt, w.grad, N, C, hw, kscale);
     }
     if (has_s) {
-        hipLaunchKernelGGL(colnorm_kernel, dim3((hw + 63) / 64, B), dim3(256), 0, st, cs, w.vt, w.nrm, C, hw);
+        {
+            ProfScope ps(FRESCO_PROF_OPT_COLNORM, B, C, hw, 0, st);
+            hipLaunchKernelGGL(colnorm_kernel, dim3((hw + 63) / 64, B), dim3(256), 0, st, cs, w.vt, w.nrm, C, hw);
+        }
         const int nt = (hw + GT - 1) / GT;
-        hipLaunchKernelGGL((gram_kernel<0>), dim3(nt, nt, B), dim3(256), 0, st, w.vt, target, w.ssign,
-                           (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
+        {
+            ProfScope ps(FRESCO_PROF_OPT_GRAM, B, C, hw, 0, st);
+            hipLaunchKernelGGL((gram_kernel<0>), dim3(nt, nt, B), dim3(256), 0, st, w.vt, target, w.ssign,
+                               (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
+        }
         const float coef = intra_weight / ((float)B * (float)hw * (float)hw);
+        ProfScope ps(FRESCO_PROF_OPT_SV, B, C, hw, 0, st);
         hipLaunchKernelGGL(sv_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vt, w.ssign, w.dvt, C,
                            hw, 2.f * coef);
     }
+    ProfScope ps(FRESCO_PROF_OPT_ADAM, B, C, hw, 0, st);
     hipLaunchKernelGGL(adam_update_kernel, dim3((hw + 63) / 64, B), dim3(256), 0, st, cs, w.m, w.v, w.grad,
                        w.vt, w.dvt, w.nrm, gout, C, hw, has_t, has_s, mode, a);
 }

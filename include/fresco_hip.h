@@ -54,6 +54,13 @@ const char* fresco_last_error(void);
 #define FRESCO_PROF_ATTN_FLASH 1
 #define FRESCO_PROF_KV_PACK 2
 #define FRESCO_PROF_TEMPORAL 3
+/* feature optimisation, dims = {B, C, hw, 0}: */
+#define FRESCO_PROF_OPT_TSIGN 4
+#define FRESCO_PROF_OPT_TGRAD 5
+#define FRESCO_PROF_OPT_COLNORM 6
+#define FRESCO_PROF_OPT_GRAM 7
+#define FRESCO_PROF_OPT_SV 8
+#define FRESCO_PROF_OPT_ADAM 9
 int fresco_prof_enable(int capacity);
 int fresco_prof_disable(void);
 int fresco_prof_read(int max_records, int* tags, int* dims, float* ms);

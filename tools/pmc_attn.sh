@@ -1,0 +1,33 @@
+#!/bin/bash
+# PMC counter passes over the cross-frame attention kernels (separate passes, kernel-trace only).
+TAG=${1:-p}
+REPO=$PWD
+OUT=$PWD/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+python tools/run_attn_only.py 20 | tee $OUT/timing.txt
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > $OUT/counters_list.txt 2>&1
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+P2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE"
+P3="FETCH_SIZE"
+P4="WRITE_SIZE"
+i=0
+for P in "$P1" "$P2" "$P3" "$P4"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python $REPO/tools/run_attn_only.py 3 > $OUT/pass$i.log 2>&1
+done
+cd $REPO
+python - <<'PY'
+import csv, glob, collections, os
+out = os.environ.get("OUT", "")
+base = sorted(glob.glob("gpurun_out/pmc_*"))[-1]
+for f in sorted(glob.glob(base + "/pass*/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:60]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+    print(f)
+    for k, d in agg.items():
+        if "fresco" in k:
+            print("  ", k, {c: round(v) for c, v in d.items()})
+PY

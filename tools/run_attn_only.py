@@ -1,0 +1,29 @@
+"""Launch only the cross-frame attention of cfg2 (for rocprofv3 --pmc runs): up_blocks.3 and up_blocks.2 shapes."""
+import sys, os, math
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fresco_amd import ops
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+g = torch.Generator().manual_seed(0)
+for (HW, C, D) in ((4096, 320, 40), (1024, 640, 80)):
+    N, chunk, H = 8, 2, 8
+    B = chunk * N
+    q = torch.randn(B, HW, C, generator=g).half().cuda()
+    k = torch.randn(B, HW, C, generator=g).half().cuda()
+    v = torch.randn(B, HW, C, generator=g).half().cuda()
+    mask = torch.rand(N, HW, generator=g) < 0.004
+    mask[0] = True
+    rows = mask.reshape(-1).nonzero().squeeze(1).to(torch.int32).cuda()
+    for _ in range(reps):
+        ops.attention(q, k, v, H, 1 / math.sqrt(D), kv_rows=rows, n_groups=chunk, M=rows.numel(), group_rows=N * HW)
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        ops.attention(q, k, v, H, 1 / math.sqrt(D), kv_rows=rows, n_groups=chunk, M=rows.numel(), group_rows=N * HW)
+    t1.record(); torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / reps
+    flop = 4.0 * B * HW * rows.numel() * C
+    print("attn HW=%d D=%d M=%d: %.1f us/call (pack+flash), %.0f TFLOP/s algorithmic" % (HW, D, rows.numel(), ms * 1e3, flop / ms / 1e9))
