@@ -195,6 +195,10 @@ __global__ __launch_bounds__(256) void temporal_sign_kernel(
 
 // grad[b][c][p] = k mf[f][p] sgn2[f] + k mb[f-1][p] sgn1[f-1] - sum_rowB[f][p] w*sgn1[f][src]
 //                                                         - sum_rowF[f-1][p] w*sgn2[f-1][src]
+// The two CSR rows of a pixel are shared by all channels: their first TG_MAXE entries are held in
+// registers (a smooth flow gives ~4 entries per row), longer rows continue from memory.
+constexpr int TG_MAXE = 6;
+
 __global__ __launch_bounds__(256) void temporal_grad_kernel(
     const int8_t* __restrict__ sgn1, const int8_t* __restrict__ sgn2, const float* __restrict__ bwd_occ,
     const float* __restrict__ fwd_occ, const int* __restrict__ rowptr, const int* __restrict__ src,
@@ -215,44 +219,87 @@ __global__ __launch_bounds__(256) void temporal_grad_kernel(
     const float* wB = wgt + (int64_t)(0 * N + f) * 4 * hw;
     const int* sF = src + (int64_t)(1 * N + fp) * 4 * hw;
     const float* wF = wgt + (int64_t)(1 * N + fp) * 4 * hw;
+    int iB[TG_MAXE], iF[TG_MAXE];
+    float vB[TG_MAXE], vF[TG_MAXE];
+#pragma unroll
+    for (int e = 0; e < TG_MAXE; ++e) {
+        const bool okB = bB + e < eB, okF = bF + e < eF;
+        iB[e] = okB ? sB[bB + e] : 0;  // weight 0 -> the (valid) index 0 contributes nothing
+        vB[e] = okB ? wB[bB + e] : 0.f;
+        iF[e] = okF ? sF[bF + e] : 0;
+        vF[e] = okF ? wF[bF + e] : 0.f;
+    }
     for (int c = c0; c < cend; ++c) {
         const int8_t* s1f = sgn1 + ((int64_t)b * C + c) * hw;
         const int8_t* s2f = sgn2 + ((int64_t)b * C + c) * hw;
         const int8_t* s1p = sgn1 + ((int64_t)bp * C + c) * hw;
         const int8_t* s2p = sgn2 + ((int64_t)bp * C + c) * hw;
-        float g = a2 * (float)s2f[p] + a1 * (float)s1p[p];
-        float adj = 0.f;
-        for (int e = bB; e < eB; ++e) adj = fmaf(wB[e], (float)s1f[sB[e]], adj);
-        float adj2 = 0.f;
-        for (int e = bF; e < eF; ++e) adj2 = fmaf(wF[e], (float)s2p[sF[e]], adj2);
+        const float g = a2 * (float)s2f[p] + a1 * (float)s1p[p];
+        float adj = 0.f, adj2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < TG_MAXE; ++e) {
+            adj = fmaf(vB[e], (float)s1f[iB[e]], adj);
+            adj2 = fmaf(vF[e], (float)s2p[iF[e]], adj2);
+        }
+        for (int e = bB + TG_MAXE; e < eB; ++e) adj = fmaf(wB[e], (float)s1f[sB[e]], adj);
+        for (int e = bF + TG_MAXE; e < eF; ++e) adj2 = fmaf(wF[e], (float)s2p[sF[e]], adj2);
         grad[((int64_t)b * C + c) * hw + p] = g - adj - adj2;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// column norms + normalised copy.  block = 64 pixels x 4 channel slices; grid (ceil(hw/64), B)
+// Per-pixel reductions over channels, in two deterministic steps so that small planes (8x8 .. 32x32)
+// still fill the chip: (1) partial sums over one of S channel slices: block = 64 pixels x 4
+// sub-slices, grid (ceil(hw/64), S, B), written to part[b][s][p]; (2) an elementwise kernel adds the S
+// partials in a fixed order.  MODE 0: sum x^2 (column norms), MODE 1: sum x*y (<V, dV>).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colnorm_kernel(const float* __restrict__ cs, float* __restrict__ vt,
-                                                       float* __restrict__ nrm, int C, int hw) {
-    __shared__ float part[4][64];
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ y,
+                                                            float* __restrict__ part, int C, int hw, int S) {
+    __shared__ float red[4][64];
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + px;
-    const int b = blockIdx.y;
-    const float* x = cs + (int64_t)b * C * hw;
+    const int s = blockIdx.y, b = blockIdx.z;
+    const int cper = (C + S - 1) / S;
+    const int cbeg = s * cper, cend = min(cbeg + cper, C);
+    const int64_t base = (int64_t)b * C * hw;
     float acc = 0.f;
     if (p < hw)
-        for (int c = sl; c < C; c += 4) {
-            const float t = x[(int64_t)c * hw + p];
-            acc = fmaf(t, t, acc);
+        for (int c = cbeg + sl; c < cend; c += 4) {
+            const int64_t o = base + (int64_t)c * hw + p;
+            acc = (MODE == 0) ? fmaf(x[o], x[o], acc) : fmaf(x[o], y[o], acc);
         }
-    part[sl][px] = acc;
+    red[sl][px] = acc;
     __syncthreads();
-    const float n = sqrtf(part[0][px] + part[1][px] + part[2][px] + part[3][px]);
-    if (p < hw) {
-        if (sl == 0) nrm[(int64_t)b * hw + p] = n;
-        float* v = vt + (int64_t)b * C * hw;
-        for (int c = sl; c < C; c += 4) v[(int64_t)c * hw + p] = x[(int64_t)c * hw + p] / n;
+    if (sl == 0 && p < hw) part[((int64_t)b * S + s) * hw + p] = red[0][px] + red[1][px] + red[2][px] + red[3][px];
+}
+
+constexpr int ECPT = 8;  // channels per thread in the elementwise kernels
+
+// vt = x / |x[p]|, nrm[b][p] = |x[p]|.  grid (ceil(hw/256), ceil(C/ECPT), B)
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ cs,
+                                                         const float* __restrict__ part, float* __restrict__ vt,
+                                                         float* __restrict__ nrm, int C, int hw, int S) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const int b = blockIdx.z, c0 = blockIdx.y * ECPT, cend = min(c0 + ECPT, C);
+    float ss = 0.f;
+    for (int s = 0; s < S; ++s) ss += part[((int64_t)b * S + s) * hw + p];
+    const float n = sqrtf(ss);
+    if (blockIdx.y == 0) nrm[(int64_t)b * hw + p] = n;
+    for (int c = c0; c < cend; ++c) {
+        const int64_t o = ((int64_t)b * C + c) * hw + p;
+        vt[o] = cs[o] / n;
     }
+}
+
+static int chan_slices(int hw, int B, int C) {
+    const int blocks = ((hw + 63) / 64) * B;
+    int S = (2048 + blocks - 1) / blocks;
+    if (S > 32) S = 32;
+    if (S > C / 4) S = C / 4 > 0 ? C / 4 : 1;
+    return S < 1 ? 1 : S;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -492,8 +539,8 @@ __global__ __launch_bounds__(256) void sv_kernel(const float* __restrict__ vt,
 }
 
 // ------------------------------------------------------------------------------------------------
-// norm backward + Adam.  block = 64 pixels x 4 channel slices; grid (ceil(hw/64), B)
-//   g = grad_t (if has_t) + (dV - V <V,dV>)/|X| (if has_s)
+// norm backward + Adam, elementwise.  grid (ceil(hw/256), ceil(C/ECPT), B)
+//   g = grad_t (if has_t) + (dV - V <V,dV>)/|X| (if has_s);  <V,dV>[b][p] = sum of the S partials
 // mode 0: Adam update of cs, m, v;  mode 1: write g to gout (loss_grad entry)
 // ------------------------------------------------------------------------------------------------
 struct AdamArgs {
@@ -505,30 +552,20 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
                                                            const float* __restrict__ grad_t,
                                                            const float* __restrict__ vt,
                                                            const float* __restrict__ dvt,
-                                                           const float* __restrict__ nrm, float* __restrict__ gout,
-                                                           int C, int hw, int has_t, int has_s, int mode,
+                                                           const float* __restrict__ nrm,
+                                                           const float* __restrict__ part, float* __restrict__ gout,
+                                                           int C, int hw, int S, int has_t, int has_s, int mode,
                                                            AdamArgs a) {
-    __shared__ float part[4][64];
-    const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + px;
-    const int b = blockIdx.y;
-    const int64_t base = (int64_t)b * C * hw;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const int b = blockIdx.z, c0 = blockIdx.y * ECPT, cend = min(c0 + ECPT, C);
     float dot = 0.f, inv_n = 0.f;
     if (has_s) {
-        float acc = 0.f;
-        if (p < hw)
-            for (int c = sl; c < C; c += 4) {
-                const int64_t o = base + (int64_t)c * hw + p;
-                acc = fmaf(vt[o], dvt[o], acc);
-            }
-        part[sl][px] = acc;
-        __syncthreads();
-        dot = part[0][px] + part[1][px] + part[2][px] + part[3][px];
-        if (p < hw) inv_n = 1.f / nrm[(int64_t)b * hw + p];
+        for (int s = 0; s < S; ++s) dot += part[((int64_t)b * S + s) * hw + p];
+        inv_n = 1.f / nrm[(int64_t)b * hw + p];
     }
-    if (p >= hw) return;
-    for (int c = sl; c < C; c += 4) {
-        const int64_t o = base + (int64_t)c * hw + p;
+    for (int c = c0; c < cend; ++c) {
+        const int64_t o = ((int64_t)b * C + c) * hw + p;
         float g = has_t ? grad_t[o] : 0.f;
         if (has_s) g += (dvt[o] - vt[o] * dot) * inv_n;
         if (mode == 1) {
@@ -548,7 +585,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
 // host side
 // ------------------------------------------------------------------------------------------------
 struct OptWs {
-    float *grad, *m, *v, *vt, *dvt, *nrm, *wgt;
+    float *grad, *m, *v, *vt, *dvt, *nrm, *wgt, *part;
     int8_t *sgn1, *sgn2, *ssign;
     int *rowptr, *cursor, *src;
 };
@@ -572,6 +609,7 @@ static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int 
     tmp.vt = has_s ? carve<float>(p, E) : nullptr;
     tmp.dvt = has_s ? carve<float>(p, E) : nullptr;
     tmp.nrm = has_s ? carve<float>(p, B * hw) : nullptr;
+    tmp.part = has_s ? carve<float>(p, B * 32 * hw) : nullptr;
     tmp.ssign = has_s ? carve<int8_t>(p, B * hw * hw) : nullptr;
     if (w) *w = tmp;
     return (size_t)(p - basep);
@@ -589,6 +627,8 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
                         float* gout, float* loss, AdamArgs a, hipStream_t st) {
     const int B = chunk * N, hw = h * wd;
     const float kscale = 2.f / ((float)B * (float)C * (float)hw);
+    const int S = chan_slices(hw, B, C);
+    const dim3 egrid((hw + 255) / 256, (C + ECPT - 1) / ECPT, B);
     if (has_t) {
         dim3 grid((hw + 255) / 256, (C + OCPT - 1) / OCPT, B);
         {
@@ -603,7 +643,9 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
     if (has_s) {
         {
             ProfScope ps(FRESCO_PROF_OPT_COLNORM, B, C, hw, 0, st);
-            hipLaunchKernelGGL(colnorm_kernel, dim3((hw + 63) / 64, B), dim3(256), 0, st, cs, w.vt, w.nrm, C, hw);
+            hipLaunchKernelGGL((chan_partial_kernel<0>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, cs,
+                               (const float*)nullptr, w.part, C, hw, S);
+            hipLaunchKernelGGL(normalize_kernel, egrid, dim3(256), 0, st, cs, w.part, w.vt, w.nrm, C, hw, S);
         }
         const int nt = (hw + GT - 1) / GT;
         {
@@ -612,13 +654,18 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
                                (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
         }
         const float coef = intra_weight / ((float)B * (float)hw * (float)hw);
-        ProfScope ps(FRESCO_PROF_OPT_SV, B, C, hw, 0, st);
-        hipLaunchKernelGGL(sv_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vt, w.ssign, w.dvt, C,
-                           hw, 2.f * coef);
+        {
+            ProfScope ps(FRESCO_PROF_OPT_SV, B, C, hw, 0, st);
+            hipLaunchKernelGGL(sv_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vt, w.ssign, w.dvt,
+                               C, hw, 2.f * coef);
+        }
     }
     ProfScope ps(FRESCO_PROF_OPT_ADAM, B, C, hw, 0, st);
-    hipLaunchKernelGGL(adam_update_kernel, dim3((hw + 63) / 64, B), dim3(256), 0, st, cs, w.m, w.v, w.grad,
-                       w.vt, w.dvt, w.nrm, gout, C, hw, has_t, has_s, mode, a);
+    if (has_s)
+        hipLaunchKernelGGL((chan_partial_kernel<1>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, w.vt, w.dvt,
+                           w.part, C, hw, S);
+    hipLaunchKernelGGL(adam_update_kernel, egrid, dim3(256), 0, st, cs, w.m, w.v, w.grad, w.vt, w.dvt, w.nrm,
+                       w.part, gout, C, hw, S, has_t, has_s, mode, a);
 }
 
 // loss[0], loss[1] hold raw sums after opt_closure; scale them to the reference's means
@@ -728,12 +775,18 @@ extern "C" int fresco_gram_target(const float* x, float* target, void* workspace
     if (!x || !target || !workspace || B <= 0 || C <= 0 || hw <= 0) return FRESCO_EINVAL;
     if (B > 65535) return FRESCO_EUNSUPPORTED;
     const size_t E = (size_t)B * C * hw;
-    if (workspace_bytes < align_up(E * 4, 256) + align_up((size_t)B * hw * 4, 256)) return FRESCO_EWORKSPACE;
+    if (workspace_bytes < align_up(E * 4, 256) + align_up((size_t)B * hw * 4, 256) * 33) return FRESCO_EWORKSPACE;
     char* p = static_cast<char*>(workspace);
     float* vt = carve<float>(p, E);
     float* nrm = carve<float>(p, (size_t)B * hw);
+    float* part = carve<float>(p, (size_t)B * 32 * hw);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(colnorm_kernel, dim3((hw + 63) / 64, B), dim3(256), 0, st, x, vt, nrm, C, hw);
+    const int S = chan_slices(hw, B, C);
+    if ((C + ECPT - 1) / ECPT > 65535) return FRESCO_EUNSUPPORTED;
+    hipLaunchKernelGGL((chan_partial_kernel<0>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, x,
+                       (const float*)nullptr, part, C, hw, S);
+    hipLaunchKernelGGL(normalize_kernel, dim3((hw + 255) / 256, (C + ECPT - 1) / ECPT, B), dim3(256), 0, st, x, part,
+                       vt, nrm, C, hw, S);
     const int nt = (hw + GT - 1) / GT;
     hipLaunchKernelGGL((gram_kernel<1>), dim3(nt, nt, B), dim3(256), 0, st, vt, (const float*)nullptr,
                        (int8_t*)nullptr, target, (float*)nullptr, C, hw);

@@ -274,7 +274,7 @@ def gram_target(x, workspace=None):
     B, C, h, w = x.shape
     hw = h * w
     out = torch.empty(B, hw, hw, dtype=torch.float32, device=x.device)
-    nbytes = (B * C * hw * 4 + 255) // 256 * 256 + (B * hw * 4 + 255) // 256 * 256
+    nbytes = (B * C * hw * 4 + 255) // 256 * 256 + 33 * ((B * hw * 4 + 255) // 256 * 256) + 512
     ws = (workspace or _default_ws).get(nbytes, x.device)
     rc = _lib.load().fresco_gram_target(x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, C, hw,
                                         _stream())

@@ -193,7 +193,8 @@ int fresco_opt_loss_grad(const float* cs, const float* fwd_flow, const float* bw
                          int chunk, int N, int C, int h, int w, float intra_weight, void* stream);
 
 /* Gram target of get_intraframe_paras (DH:889-895): T[b] = V V^T, V = rows of x (B,C,h,w)
- * viewed as (B, hw, C) and L2-normalised; fp32 (B,hw,hw).  workspace: B*C*hw + B*hw floats. */
+ * viewed as (B, hw, C) and L2-normalised; fp32 (B,hw,hw).  workspace: B*C*hw + 33*B*hw floats
+ * (each block rounded up to 256 bytes). */
 int fresco_gram_target(const float* x, float* target, void* workspace, size_t workspace_bytes,
                        int B, int C, int hw, void* stream);
 
