@@ -31,8 +31,12 @@ struct AttnCfg {
     static constexpr int NKC = DPK / 8;             // 16-byte chunks per K row
     static constexpr int KROW = DPK * 2 + (((DPK * 2 / 16) % 2 == 0) ? 16 : 0);  // LDS bytes per K row
     static constexpr int VROW = 64 * 2 + 16;                                     // LDS bytes per V^T row
-    static constexpr int KTILE = 64 * KROW;
-    static constexpr int VTILE = DPV * VROW;
+    static constexpr int KCR = KROW / 16;  // 16-byte chunks per LDS K row (data + pad)
+    static constexpr int VCR = VROW / 16;
+    static constexpr int KTILE = 64 * KROW;                          // multiple of 1 KiB (64 rows)
+    static constexpr int VTILE = (DPV * VROW + 1023) / 1024 * 1024;  // rounded up: whole 1 KiB DMA pieces
+    static constexpr int KDMA = KTILE / 1024;                        // wave-level DMA instructions per tile
+    static constexpr int VDMA = VTILE / 1024;
     static constexpr int LDS_BYTES = 2 * (KTILE + VTILE);
     static constexpr int KCH = 64 * NKC;  // 16-byte chunks in a K tile
     static constexpr int VCH = DPV * 8;   // 16-byte chunks in a V^T tile
@@ -170,39 +174,37 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     const char* vg = reinterpret_cast<const char*>(vt + (int64_t)(g * H + h) * Cfg::DPV * Mpad);
     const int nT = Mpad / 64;
 
-    u32x4 kst[Cfg::KPT], vst[Cfg::VPT];
-    auto load_tile = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < Cfg::KPT; ++i) {
-            int c = tid + i * 256;
-            if (Cfg::KCH % 256 != 0) c = c < Cfg::KCH ? c : 0;  // clamp: the load is unconditional
-            kst[i] = *reinterpret_cast<const u32x4*>(kg + ((int64_t)t * Cfg::KCH + c) * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < Cfg::VPT; ++i) {
-            int c = tid + i * 256;
-            if (Cfg::VCH % 256 != 0) c = c < Cfg::VCH ? c : 0;
-            const int d = c >> 3, kc = c & 7;
-            vst[i] = *reinterpret_cast<const u32x4*>(vg + ((int64_t)d * Mpad + t * 64 + kc * 8) * 2);
-        }
-    };
-    auto store_tile = [&](int buf) {
+    // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4), no register round trip ---------
+    // One wave-level instruction fills 1 KiB of LDS: destination = wave-uniform base + lane * 16, the
+    // source address is per lane.  The padded row layout is kept by pointing the pad chunk's lane at a
+    // dummy (valid) source.  Piece i of a tile is issued by wave i % 4.
+    auto stage_tile = [&](int t, int buf) {
         char* kb = smem + buf * (Cfg::KTILE + Cfg::VTILE);
         char* vb = kb + Cfg::KTILE;
+        const char* ksrc = kg + (int64_t)t * Cfg::KCH * 16;
 #pragma unroll
-        for (int i = 0; i < Cfg::KPT; ++i) {
-            const int c = tid + i * 256;
-            if (c < Cfg::KCH) {
-                const int row = c / Cfg::NKC, dc = c % Cfg::NKC;
-                *reinterpret_cast<u32x4*>(kb + row * Cfg::KROW + dc * 16) = kst[i];
+        for (int i = 0; i < (Cfg::KDMA + 3) / 4; ++i) {
+            const int piece = i * 4 + wave;
+            if (piece < Cfg::KDMA) {
+                const int c = piece * 64 + lane;  // linear 16-byte chunk of the LDS tile
+                const int row = c / Cfg::KCR, dc = c % Cfg::KCR;
+                const char* src = ksrc + (dc < Cfg::NKC ? (row * Cfg::NKC + dc) * 16 : 0);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src),
+                    (__attribute__((address_space(3))) void*)(kb + piece * 1024), 16, 0, 0);
             }
         }
 #pragma unroll
-        for (int i = 0; i < Cfg::VPT; ++i) {
-            const int c = tid + i * 256;
-            if (c < Cfg::VCH) {
-                const int d = c >> 3, kc = c & 7;
-                *reinterpret_cast<u32x4*>(vb + d * Cfg::VROW + kc * 16) = vst[i];
+        for (int i = 0; i < (Cfg::VDMA + 3) / 4; ++i) {
+            const int piece = i * 4 + wave;
+            if (piece < Cfg::VDMA) {
+                const int c = piece * 64 + lane;
+                const int d = c / Cfg::VCR, kc = c % Cfg::VCR;
+                const bool real = d < Cfg::DPV && kc < 8;
+                const char* src = vg + (real ? ((int64_t)d * Mpad + t * 64 + kc * 8) * 2 : 0);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src),
+                    (__attribute__((address_space(3))) void*)(vb + piece * 1024), 16, 0, 0);
             }
         }
     };
@@ -219,8 +221,7 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
             for (int r = 0; r < 16; ++r) o[j][db][r] = 0.f;
     }
 
-    load_tile(0);
-    store_tile(0);
+    stage_tile(0, 0);
     __syncthreads();
 
     const bool need_diag = diag_bias_log2 != 0.f;
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     auto tile = [&](int t, auto fix_c) {
         constexpr bool FIX = decltype(fix_c)::value;
         const int buf = (FRESCO_ABL == 5) ? 0 : (t & 1);
-        if (FRESCO_ABL != 5 && t + 1 < nT) load_tile(t + 1);
+        // every wave has left tile t-1 (barrier below), so its buffer can be refilled while tile t runs
+        if (FRESCO_ABL != 5 && t + 1 < nT) stage_tile(t + 1, buf ^ 1);
         const char* kb = smem + buf * (Cfg::KTILE + Cfg::VTILE);
         const char* vb = kb + Cfg::KTILE;
 
@@ -340,10 +342,7 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
                 }
             }
         }
-        if (FRESCO_ABL != 5) {
-            if (t + 1 < nT) store_tile(buf ^ 1);
-            __syncthreads();
-        }
+        if (FRESCO_ABL != 5) __syncthreads();  // also drains this wave's DMA pieces (vmcnt) before release
     };
 
     const std::integral_constant<bool, true> fix_on;
@@ -403,7 +402,7 @@ static int attn_qb_choice(int D, int Lq) {
     return 1;
 }
 
-template <int D, int QB, int MINW = (QB == 1 && D <= 40) ? 3 : (QB == 1 && D <= 80 ? 2 : 1)>
+template <int D, int QB, int MINW>
 static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, half_t* out, int B, int H,
                          int Lq, int M, int Mpad, int n_groups, float scale, float diag_bias,
                          hipStream_t st) {
@@ -417,8 +416,18 @@ static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, ha
     const int nQblk = (Lq + 128 * QB - 1) / (128 * QB);
     const float log2e = 1.4426950408889634f;
     ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
-    hipLaunchKernelGGL((attn_flash_kernel<D, QB, MINW>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q, kp,
-                       vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e);
+    hipLaunchKernelGGL((attn_flash_kernel<D, QB, MINW>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
+                       kp, vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e);
+}
+
+// FRESCO_ATTN_OCC=lo|hi in the environment picks the launch-bounds variant (tuning only)
+static int attn_occ_choice() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FRESCO_ATTN_OCC");
+        v = (e && e[0] == 'h') ? 2 : (e && e[0] == 'l') ? 1 : 0;
+    }
+    return v;
 }
 
 template <int D>
@@ -435,10 +444,15 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
         hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, H, M, Mpad,
                            group_rows);
     }
+    // waves per SIMD the register allocator is asked to make room for (lo / hi variants)
+    constexpr int LO = D <= 40 ? 3 : (D <= 80 ? 2 : 1);
+    constexpr int HI = D <= 40 ? 4 : (D <= 80 ? 3 : 1);
     if (D <= 96 && attn_qb_choice(D, Lq) == 2)
-        launch_flash<D, (D <= 96 ? 2 : 1)>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
+        launch_flash<D, (D <= 96 ? 2 : 1), 1>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
+    else if (attn_occ_choice() == 2)
+        launch_flash<D, 1, HI>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
     else
-        launch_flash<D, 1>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
+        launch_flash<D, 1, LO>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
     return check_launch();
 }
 
