@@ -152,6 +152,29 @@ def cpu_baseline(layers, params, N):
                        "N=%d frames, x3 layers each, weighted by the 15-step schedule: %s" % (N, ", ".join(sample)))
 
 
+def pmc_traffic_bytes(kernel_substr):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/*.csv,
+    written by tools/pmc_attn.sh): FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B,
+    MI355X_MICROARCH.md section HBM) and both counters are in KiB.  None if no profile is committed."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_attn_*.csv")))
+    if not files:
+        return None
+    fetch = write = None
+    for r in csv.DictReader(open(files[-1])):
+        if kernel_substr in r["kernel"]:
+            if r["counter"] == "FETCH_SIZE":
+                fetch = float(r["per_dispatch"])
+            elif r["counter"] == "WRITE_SIZE":
+                write = float(r["per_dispatch"])
+    if fetch is None or write is None:
+        return None
+    return dict(bytes=int((2.0 * fetch + write) * 1024), source=os.path.basename(files[-1]),
+                note="(2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch; separate --pmc passes")
+
+
 def read_prof(lib, cap):
     tags = (ctypes.c_int * cap)()
     dims = (ctypes.c_int * (4 * cap))()
@@ -249,7 +272,9 @@ def main():
         ach = flop / mean_s
         roofline = dict(bound="mfma", kernel="attn_flash_kernel<40> (up_blocks.3 cross-frame pass)",
                         achieved=round(ach / 1e12, 2), peak=PEAK_F16_DENSE / 1e12, unit="TFLOP/s",
-                        frac=round(ach / PEAK_F16_DENSE, 4), traffic=None, launches=len(dom),
+                        frac=round(ach / PEAK_F16_DENSE, 4), traffic=pmc_traffic_bytes("attn_flash_kernelILi40"),
+                        algorithmic_bytes_per_launch=int(2 * B_loc * HW3 * 320 * 2 + 2 * 2 * M3 * 320 * 2),
+                        launches=len(dom),
                         avg_launch_us=round(mean_s * 1e6, 2), algorithmic_flop_per_launch=flop)
     by_tag = {}
     for tag, d, ms in recs:

@@ -17,17 +17,24 @@ for P in "$P1" "$P2" "$P3" "$P4"; do
   timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python $REPO/tools/run_attn_only.py 3 > $OUT/pass$i.log 2>&1
 done
 cd $REPO
-python - <<'PY'
+TAG=$TAG python - <<'PY'
 import csv, glob, collections, os
-out = os.environ.get("OUT", "")
-base = sorted(glob.glob("gpurun_out/pmc_*"))[-1]
+base = "gpurun_out/pmc_" + os.environ["TAG"]
+rows = []
 for f in sorted(glob.glob(base + "/pass*/**/*counter_collection.csv", recursive=True)):
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:60]
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
-    print(f)
+        k = r["Kernel_Name"].split("(")[0][:70]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
     for k, d in agg.items():
         if "fresco" in k:
-            print("  ", k, {c: round(v) for c, v in d.items()})
+            for c, v in d.items():
+                rows.append((k, c, n[(k, c)], v, v / n[(k, c)]))
+with open(base + "/summary.csv", "w") as f:
+    f.write("kernel,counter,dispatches,sum,per_dispatch\n")
+    for r in rows:
+        f.write("%s,%s,%d,%.0f,%.1f\n" % r)
+for r in rows:
+    if "flash" in r[0]:
+        print(r[0][20:52], r[1], round(r[4]))
 PY
