@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
                                                        const half_t* __restrict__ v,
                                                        const int32_t* __restrict__ kv_rows,
                                                        half_t* __restrict__ kp, half_t* __restrict__ vt,
-                                                       int H, int M, int Mpad, int64_t group_rows) {
+                                                       int H, int M, int Mpad, int64_t group_rows,
+                                                       int64_t kv_ld) {
     using Cfg = AttnCfg<D>;
     const int tile = blockIdx.x, h = blockIdx.y, g = blockIdx.z;
-    const int C = H * D;
     __shared__ int32_t rows[64];
     __shared__ __attribute__((aligned(16))) half_t vs[64][D + 8];  // +8 halfs: 16-B aligned rows
 
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
         uint4 val = zero;
         const int32_t r = rows[row];
         if (r >= 0 && dc * 8 < D)
-            val = *reinterpret_cast<const uint4*>(k + ((int64_t)g * group_rows + r) * C + h * D + dc * 8);
+            val = *reinterpret_cast<const uint4*>(k + ((int64_t)g * group_rows + r) * kv_ld + h * D + dc * 8);
         *reinterpret_cast<uint4*>(kdst + (int64_t)c * 8) = val;
     }
     // V: stage the 64 x D slab, then write it transposed
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
         uint4 val = zero;
         const int32_t r = rows[row];
         if (r >= 0)
-            val = *reinterpret_cast<const uint4*>(v + ((int64_t)g * group_rows + r) * C + h * D + dc * 8);
+            val = *reinterpret_cast<const uint4*>(v + ((int64_t)g * group_rows + r) * kv_ld + h * D + dc * 8);
         *reinterpret_cast<uint4*>(&vs[row][dc * 8]) = val;
     }
     __syncthreads();
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
                                                           const half_t* __restrict__ vt,
                                                           half_t* __restrict__ out, int B, int H, int Lq,
                                                           int M, int Mpad, int batch_per_group,
-                                                          float scale_log2, float diag_bias_log2) {
+                                                          float scale_log2, float diag_bias_log2, int64_t q_ld) {
     using Cfg = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = 128 * QB;  // query rows per workgroup
@@ -160,12 +160,16 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         const int qr = qrow0 + 32 * j;
-        const half_t* qp = q + ((int64_t)b * Lq + (qr < Lq ? qr : Lq - 1)) * C + h * D;
+        const half_t* qp = q + ((int64_t)b * Lq + (qr < Lq ? qr : Lq - 1)) * q_ld + h * D;
 #pragma unroll
         for (int ks = 0; ks < Cfg::NKS; ++ks) {
             const int d0 = ks * 16 + hi * 8;
             half8_t t = {0, 0, 0, 0, 0, 0, 0, 0};
             if (d0 < D) t = *reinterpret_cast<const half8_t*>(qp + d0);
+            // the logit scale (softmax scale * log2 e) is folded into Q once per wave (one fp16 rounding of
+            // q*c, the same order as the fp16 rounding of P): the MFMA then delivers exponent arguments
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (half_t)((float)t[e] * scale_log2);
             qf[j][ks] = t;
         }
     }
@@ -210,11 +214,15 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     };
 
     floatx16 o[QB][Cfg::NDB];
+    floatx16 negm[QB];  // -m_run in all 16 registers: the C operand of the first QK MFMA, so that the
+                        // accumulators come out as  c*s - m_run  (no per-score subtraction)
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
-        m_run[j] = -1e30f;  // reference max of the exponent, scaled log2 domain (>= true max - RESCALE_THR)
-        l_run[j] = 0.f;     // row sum when V^T has no spare row for the ones-trick (this lane's keys)
+        m_run[j] = 0.f;  // reference point of the exponent (log2 domain); tile 0 moves it to the row max
+        l_run[j] = 0.f;  // row sum when V^T has no spare row for the ones-trick (this lane's keys)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[j][r] = 0.f;
 #pragma unroll
         for (int db = 0; db < Cfg::NDB; ++db)
 #pragma unroll
@@ -239,12 +247,10 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
         // ---- S^T = K Q^T : per query block two independent 32-key accumulators ------------------
         floatx16 s[QB][2];
 #pragma unroll
-        for (int j = 0; j < QB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[j][0][r] = 0.f;
-                s[j][1][r] = 0.f;
-            }
+        for (int j = 0; j < QB; ++j) {
+            s[j][0] = negm[j];
+            s[j][1] = negm[j];
+        }
         const char* kr = kb + krow * Cfg::KROW + hi * 16;
 #pragma unroll
         for (int ks = 0; ks < Cfg::NKS; ++ks) {
@@ -285,40 +291,43 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key0 = t * 64 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (need_diag && key0 == qr) s[j][0][r] += diag_bias_log2 / scale_log2;
-                    if (need_diag && key0 + 32 == qr) s[j][1][r] += diag_bias_log2 / scale_log2;
-                    if (key0 >= M) s[j][0][r] = -1e30f / scale_log2;
-                    if (key0 + 32 >= M) s[j][1][r] = -1e30f / scale_log2;
+                    if (need_diag && key0 == qr) s[j][0][r] += diag_bias_log2;
+                    if (need_diag && key0 + 32 == qr) s[j][1][r] += diag_bias_log2;
+                    if (key0 >= M) s[j][0][r] = -1e30f;
+                    if (key0 + 32 >= M) s[j][1][r] = -1e30f;
                 }
             }
-            // ---- online softmax, one query per lane; rescale only when the max grew by > RESCALE_THR
+            // ---- online softmax, one query per lane.  s = exponent argument relative to m_run; the
+            // reference point moves (and O, l are rescaled) only when the tile max exceeds it by more than
+            // RESCALE_THR -- or on tile 0, which anchors it at the row's first-tile max.
             float mt = fmaxf(s[j][0][0], s[j][1][0]);
 #pragma unroll
             for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[j][0][r]), s[j][1][r]);  // v_max3_f32
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2;
-            if (__any(mt > m_run[j] + RESCALE_THR)) {
-                const float m_new = fmaxf(m_run[j], mt);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
-                m_run[j] = m_new;
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            if (t == 0 || __any(mt > RESCALE_THR)) {
+                const float delta = (t == 0) ? mt : fmaxf(mt, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_run[j] += delta;
                 l_run[j] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    negm[j][r] = -m_run[j];
+                    s[j][0][r] -= delta;
+                    s[j][1][r] -= delta;
+                }
 #pragma unroll
                 for (int db = 0; db < Cfg::NDB; ++db)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[j][db][r] *= alpha;
             }
             float psum = 0.f;
-            // exponent arguments two at a time (v_pk_fma_f32 on adjacent accumulator registers:
-            // one issue slot per pair)
-            const floatx2 sc2 = {scale_log2, scale_log2};
-            const floatx2 nm2 = {-m_run[j], -m_run[j]};
 #pragma unroll
             for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const floatx2 sv = {s[j][kbk][r], s[j][kbk][r + 1]};
-                    const floatx2 x = __builtin_elementwise_fma(sv, sc2, nm2);
-                    const float p0 = (FRESCO_ABL == 1) ? x[0] : __builtin_amdgcn_exp2f(x[0]);
-                    const float p1 = (FRESCO_ABL == 1) ? x[1] : __builtin_amdgcn_exp2f(x[1]);
+                    const float x0 = s[j][kbk][r], x1 = s[j][kbk][r + 1];
+                    const float p0 = (FRESCO_ABL == 1) ? x0 : __builtin_amdgcn_exp2f(x0);
+                    const float p1 = (FRESCO_ABL == 1) ? x1 : __builtin_amdgcn_exp2f(x1);
                     if (!Cfg::ONES) psum += p0 + p1;
                     pf[j][kbk * 2 + (r >> 3)][r & 7] = (half_t)p0;
                     pf[j][kbk * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
@@ -404,7 +413,7 @@ static int attn_qb_choice(int D, int Lq) {
 
 template <int D, int QB, int MINW>
 static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, half_t* out, int B, int H,
-                         int Lq, int M, int Mpad, int n_groups, float scale, float diag_bias,
+                         int Lq, int M, int Mpad, int n_groups, float scale, float diag_bias, int64_t q_ld,
                          hipStream_t st) {
     using Cfg = AttnCfg<D>;
     static bool attr_set = false;
@@ -417,7 +426,7 @@ static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, ha
     const float log2e = 1.4426950408889634f;
     ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
     hipLaunchKernelGGL((attn_flash_kernel<D, QB, MINW>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
-                       kp, vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e);
+                       kp, vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
 }
 
 // FRESCO_ATTN_OCC=lo|hi in the environment picks the launch-bounds variant (tuning only)
@@ -433,7 +442,8 @@ static int attn_occ_choice() {
 template <int D>
 static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const int32_t* kv_rows,
                        half_t* out, char* ws, int B, int H, int Lq, int n_groups, int M,
-                       int64_t group_rows, float scale, float diag_bias, hipStream_t st) {
+                       int64_t group_rows, float scale, float diag_bias, int64_t q_ld, int64_t kv_ld,
+                       hipStream_t st) {
     using Cfg = AttnCfg<D>;
     const int Mpad = mpad_of(M);
     half_t* kp = reinterpret_cast<half_t*>(ws);
@@ -442,17 +452,17 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
     {
         ProfScope ps(FRESCO_PROF_KV_PACK, n_groups, H, M, D, st);
         hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, H, M, Mpad,
-                           group_rows);
+                           group_rows, kv_ld);
     }
     // waves per SIMD the register allocator is asked to make room for (lo / hi variants)
     constexpr int LO = D <= 40 ? 3 : (D <= 80 ? 2 : 1);
     constexpr int HI = D <= 40 ? 4 : (D <= 80 ? 3 : 1);
     if (D <= 96 && attn_qb_choice(D, Lq) == 2)
-        launch_flash<D, (D <= 96 ? 2 : 1), 1>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
+        launch_flash<D, (D <= 96 ? 2 : 1), 1>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, st);
     else if (attn_occ_choice() == 2)
-        launch_flash<D, 1, HI>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
+        launch_flash<D, 1, HI>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, st);
     else
-        launch_flash<D, 1, LO>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, st);
+        launch_flash<D, 1, LO>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, st);
     return check_launch();
 }
 
@@ -471,11 +481,12 @@ extern "C" size_t fresco_attn_workspace_bytes(int n_groups, int H, int M, int D)
     return attn_ws_bytes(n_groups, H, M, D);
 }
 
-extern "C" int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* kv_rows,
-                               void* out, void* workspace, size_t workspace_bytes, int B, int H,
-                               int Lq, int D, int n_groups, int M, int64_t group_rows, float scale,
-                               float diag_bias, void* stream) {
+extern "C" int fresco_attn_fwd_ld(const void* q, const void* k, const void* v, const int32_t* kv_rows,
+                                  void* out, void* workspace, size_t workspace_bytes, int B, int H,
+                                  int Lq, int D, int n_groups, int M, int64_t group_rows, float scale,
+                                  float diag_bias, int64_t q_ld, int64_t kv_ld, void* stream) {
     if (!q || !k || !v || !out || !workspace) return FRESCO_EINVAL;
+    if (q_ld < (int64_t)H * D || kv_ld < (int64_t)H * D || q_ld % 8 != 0 || kv_ld % 8 != 0) return FRESCO_EINVAL;
     if (B <= 0 || H <= 0 || Lq <= 0 || D <= 0 || n_groups <= 0 || M <= 0 || group_rows <= 0)
         return FRESCO_EINVAL;
     if (B % n_groups != 0 || !(scale > 0.f)) return FRESCO_EINVAL;
@@ -489,7 +500,7 @@ extern "C" int fresco_attn_fwd(const void* q, const void* k, const void* v, cons
 #define FRESCO_ATTN_CASE(DD)                                                                       \
     case DD:                                                                                       \
         return launch_attn<DD>(qh, kh, vh, kv_rows, oh, ws, B, H, Lq, n_groups, M, group_rows, scale, \
-                               diag_bias, st);
+                               diag_bias, q_ld, kv_ld, st);
     switch (D) {
         FRESCO_ATTN_CASE(8)
         FRESCO_ATTN_CASE(16)
@@ -503,4 +514,12 @@ extern "C" int fresco_attn_fwd(const void* q, const void* k, const void* v, cons
             return FRESCO_EUNSUPPORTED;
     }
 #undef FRESCO_ATTN_CASE
+}
+
+extern "C" int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* kv_rows,
+                               void* out, void* workspace, size_t workspace_bytes, int B, int H,
+                               int Lq, int D, int n_groups, int M, int64_t group_rows, float scale,
+                               float diag_bias, void* stream) {
+    return fresco_attn_fwd_ld(q, k, v, kv_rows, out, workspace, workspace_bytes, B, H, Lq, D, n_groups, M,
+                              group_rows, scale, diag_bias, (int64_t)H * D, (int64_t)H * D, stream);
 }

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v,
     const int64_t* __restrict__ fwd_map, const uint8_t* __restrict__ mask, half_t* __restrict__ out,
     int N, int HW, int H, int PB, float scale_log2, int n_loc, int f0, int k_rank_stride,
-    int v_rank_stride) {
+    int v_rank_stride, int64_t q_ld, int64_t k_ld, int64_t v_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = H * D;
     const int CC = C / 8;  // 16-byte chunks per row
@@ -48,9 +48,10 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(
         if (row >= 0) {
             // frame g lives on shard g / n_loc as local frame g % n_loc (single GPU: n_loc = N)
             const int sh = g / n_loc, gl = g - sh * n_loc;
-            const int64_t roff = (int64_t)row * C + cc * 8;
-            kv = *reinterpret_cast<const uint4*>(k + ((int64_t)(sh * k_rank_stride + c * n_loc + gl)) * HW * C + roff);
-            vv = *reinterpret_cast<const uint4*>(v + ((int64_t)(sh * v_rank_stride + c * n_loc + gl)) * HW * C + roff);
+            kv = *reinterpret_cast<const uint4*>(
+                k + (((int64_t)(sh * k_rank_stride + c * n_loc + gl)) * HW + row) * k_ld + cc * 8);
+            vv = *reinterpret_cast<const uint4*>(
+                v + (((int64_t)(sh * v_rank_stride + c * n_loc + gl)) * HW + row) * v_ld + cc * 8);
         }
         *reinterpret_cast<uint4*>(ks + (size_t)r * C + cc * 8) = kv;
         *reinterpret_cast<uint4*>(vs + (size_t)r * C + cc * 8) = vv;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(
     if (pl >= PB || p >= HW) return;
 
     const int myrow = rows[pl * N + f];
-    const int64_t qoff = (((int64_t)(c * n_loc + fl)) * HW + myrow) * C + h * D;
+    const int64_t qoff = (((int64_t)(c * n_loc + fl)) * HW + myrow) * q_ld + h * D;
+    const int64_t ooff = (((int64_t)(c * n_loc + fl)) * HW + myrow) * C + h * D;
     float qf[D];
 #pragma unroll
     for (int j = 0; j < D / 8; ++j) {
@@ -108,14 +110,15 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(
         half8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)(acc[j * 8 + e] * inv);
-        *reinterpret_cast<half8_t*>(out + qoff + j * 8) = o;
+        *reinterpret_cast<half8_t*>(out + ooff + j * 8) = o;
     }
 }
 
 template <int D>
 static int launch_temporal(const half_t* q, const half_t* k, const half_t* v, const int64_t* fwd_map,
                            const uint8_t* mask, half_t* out, int chunk, int N, int HW, int H,
-                           float scale, int n_loc, int f0, int krs, int vrs, hipStream_t st) {
+                           float scale, int n_loc, int f0, int krs, int vrs, int64_t q_ld, int64_t k_ld,
+                           int64_t v_ld, hipStream_t st) {
     const int tpp = n_loc * H;  // threads per trajectory
     if (tpp > 256) return FRESCO_EUNSUPPORTED;
     int PB = 256 / tpp;
@@ -133,7 +136,7 @@ static int launch_temporal(const half_t* q, const half_t* k, const half_t* v, co
     dim3 grid((HW + PB - 1) / PB, chunk);
     ProfScope ps(FRESCO_PROF_TEMPORAL, chunk * N, HW, H, D, st);
     hipLaunchKernelGGL((temporal_attn_kernel<D>), grid, dim3(256), lds, st, q, k, v, fwd_map, mask, out,
-                       N, HW, H, PB, scale * 1.4426950408889634f, n_loc, f0, krs, vrs);
+                       N, HW, H, PB, scale * 1.4426950408889634f, n_loc, f0, krs, vrs, q_ld, k_ld, v_ld);
     return check_launch();
 }
 
@@ -141,14 +144,16 @@ static int launch_temporal(const half_t* q, const half_t* k, const half_t* v, co
 
 using namespace fresco;
 
-extern "C" int fresco_temporal_attn_sharded(const void* q, const void* k, const void* v,
-                                            const int64_t* fwd_map, const uint8_t* mask, void* out,
-                                            int chunk, int N, int HW, int H, int D, float scale, int n_loc,
-                                            int f0, int k_rank_stride, int v_rank_stride, void* stream) {
+static int temporal_dispatch(const void* q, const void* k, const void* v, const int64_t* fwd_map,
+                             const uint8_t* mask, void* out, int chunk, int N, int HW, int H, int D, float scale,
+                             int n_loc, int f0, int k_rank_stride, int v_rank_stride, int64_t q_ld, int64_t k_ld,
+                             int64_t v_ld, void* stream) {
     if (!q || !k || !v || !fwd_map || !mask || !out) return FRESCO_EINVAL;
     if (chunk <= 0 || N <= 0 || HW <= 0 || H <= 0 || D <= 0) return FRESCO_EINVAL;
     if (n_loc <= 0 || N % n_loc != 0 || f0 < 0 || f0 + n_loc > N || f0 % n_loc != 0) return FRESCO_EINVAL;
     if (k_rank_stride < 0 || v_rank_stride < 0) return FRESCO_EINVAL;
+    const int64_t Cw = (int64_t)H * D;
+    if (q_ld < Cw || k_ld < Cw || v_ld < Cw || q_ld % 8 || k_ld % 8 || v_ld % 8) return FRESCO_EINVAL;
     hipStream_t st = as_stream(stream);
     const half_t* qh = static_cast<const half_t*>(q);
     const half_t* kh = static_cast<const half_t*>(k);
@@ -157,7 +162,7 @@ extern "C" int fresco_temporal_attn_sharded(const void* q, const void* k, const 
 #define FRESCO_T_CASE(DD) \
     case DD:              \
         return launch_temporal<DD>(qh, kh, vh, fwd_map, mask, oh, chunk, N, HW, H, scale, n_loc, f0, \
-                                   k_rank_stride, v_rank_stride, st);
+                                   k_rank_stride, v_rank_stride, q_ld, k_ld, v_ld, st);
     switch (D) {
         FRESCO_T_CASE(8)
         FRESCO_T_CASE(16)
@@ -171,9 +176,26 @@ extern "C" int fresco_temporal_attn_sharded(const void* q, const void* k, const 
 #undef FRESCO_T_CASE
 }
 
+extern "C" int fresco_temporal_attn_sharded(const void* q, const void* k, const void* v,
+                                            const int64_t* fwd_map, const uint8_t* mask, void* out,
+                                            int chunk, int N, int HW, int H, int D, float scale, int n_loc,
+                                            int f0, int k_rank_stride, int v_rank_stride, void* stream) {
+    const int64_t Cw = (int64_t)H * D;
+    return temporal_dispatch(q, k, v, fwd_map, mask, out, chunk, N, HW, H, D, scale, n_loc, f0, k_rank_stride,
+                             v_rank_stride, Cw, Cw, Cw, stream);
+}
+
 extern "C" int fresco_temporal_attn(const void* q, const void* k, const void* v, const int64_t* fwd_map,
                                     const uint8_t* mask, void* out, int chunk, int N, int HW, int H,
                                     int D, float scale, void* stream) {
-    return fresco_temporal_attn_sharded(q, k, v, fwd_map, mask, out, chunk, N, HW, H, D, scale, N, 0, 0, 0,
-                                        stream);
+    const int64_t Cw = (int64_t)H * D;
+    return temporal_dispatch(q, k, v, fwd_map, mask, out, chunk, N, HW, H, D, scale, N, 0, 0, 0, Cw, Cw, Cw,
+                             stream);
+}
+
+extern "C" int fresco_temporal_attn_ld(const void* q, const void* k, const void* v, const int64_t* fwd_map,
+                                       const uint8_t* mask, void* out, int chunk, int N, int HW, int H, int D,
+                                       float scale, int64_t q_ld, int64_t k_ld, int64_t v_ld, void* stream) {
+    return temporal_dispatch(q, k, v, fwd_map, mask, out, chunk, N, HW, H, D, scale, N, 0, 0, 0, q_ld, k_ld,
+                             v_ld, stream);
 }

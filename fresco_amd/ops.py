@@ -31,6 +31,27 @@ def _f32c(t):
     return t.to(torch.float32).contiguous()
 
 
+def _rows(t):
+    """(tensor, row stride in elements, rows) for a (..., C) tensor whose rows are uniformly strided
+    (dense, or a column slice of a dense (..., k*C) tensor such as a fused projection output);
+    anything else is made dense first."""
+    C = t.shape[-1]
+    ok = t.stride(-1) == 1 and t.dim() >= 2
+    if ok:
+        ld = t.stride(-2)
+        exp = ld
+        for d in range(t.dim() - 2, -1, -1):  # leading dims must nest without gaps
+            if t.shape[d] != 1 and t.stride(d) != exp:
+                ok = False
+                break
+            exp *= t.shape[d]
+        ok = ok and ld >= C and ld % 8 == 0 and t.data_ptr() % 16 == 0
+    if not ok:
+        t = t.contiguous()
+        ld = C
+    return t, ld, t.numel() // C
+
+
 class Workspace:
     """Grow-only device scratch buffer (the C ABI never allocates)."""
 
@@ -64,30 +85,33 @@ def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, gro
     D = C // heads
     if D * heads != C:
         raise ValueError("channels %d not divisible by heads %d" % (C, heads))
-    q = q.contiguous()
-    k = k.contiguous().view(-1, C)
-    v = v.contiguous().view(-1, C)
+    q, q_ld, _ = _rows(q)
+    k, kv_ld, k_rows = _rows(k)
+    v, v_ld, v_rows = _rows(v)
+    if v_ld != kv_ld:
+        v = v.contiguous()
+        k = k.contiguous()
+        kv_ld = C
     if n_groups is None:
-        if k.shape != v.shape:
-            raise ValueError("k and v must have the same shape")
+        if k_rows != v_rows or k_rows % B != 0:
+            raise ValueError("k and v must have the same number of rows, a multiple of the batch")
         n_groups = B
-        group_rows = k.shape[0] // B
+        group_rows = k_rows // B
         M = group_rows
     if kv_rows is not None:
         if kv_rows.dtype != torch.int32:
             raise TypeError("kv_rows must be int32")
         kv_rows = kv_rows.contiguous()
         M = kv_rows.numel()
-    if kv_rows is None and ((n_groups - 1) * group_rows + M > min(k.shape[0], v.shape[0])):
-        raise ValueError("k/v have %d/%d rows, grouping needs %d" % (k.shape[0], v.shape[0],
-                                                                     (n_groups - 1) * group_rows + M))
+    if kv_rows is None and ((n_groups - 1) * group_rows + M > min(k_rows, v_rows)):
+        raise ValueError("k/v have %d/%d rows, grouping needs %d" % (k_rows, v_rows, (n_groups - 1) * group_rows + M))
     lib = _lib.load()
     ws_bytes = lib.fresco_attn_workspace_bytes(n_groups, heads, M, D)
     ws = (workspace or _default_ws).get(ws_bytes, q.device)
-    out = torch.empty_like(q)
-    rc = lib.fresco_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(kv_rows), out.data_ptr(),
-                             ws.data_ptr(), ws.numel(), B, heads, Lq, D, n_groups, M, group_rows,
-                             float(scale), float(diag_bias), _stream())
+    out = torch.empty((B, Lq, C), dtype=q.dtype, device=q.device)
+    rc = lib.fresco_attn_fwd_ld(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(kv_rows), out.data_ptr(),
+                                ws.data_ptr(), ws.numel(), B, heads, Lq, D, n_groups, M, group_rows,
+                                float(scale), float(diag_bias), q_ld, kv_ld, _stream())
     _lib.check(rc, "fresco_attn_fwd(B=%d,H=%d,Lq=%d,D=%d,groups=%d,M=%d)" % (B, heads, Lq, D, n_groups, M))
     return out
 
@@ -109,7 +133,12 @@ def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk, shard=None):
         N, n_loc, f0, krs, vrs = shard
         assert Bt == chunk * n_loc
     D = C // heads
-    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    if shard is None:
+        q, q_ld, _ = _rows(q)
+        k, k_ld, _ = _rows(k)
+        v, v_ld, _ = _rows(v)
+    else:
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     fwd_map = fwd_map.reshape(N, HW)
     if fwd_map.dtype != torch.int64:
         fwd_map = fwd_map.to(torch.int64)
@@ -120,10 +149,16 @@ def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk, shard=None):
     elif mask.dtype != torch.uint8:
         mask = (mask != 0).contiguous().view(torch.uint8)
     mask = mask.contiguous()
-    out = torch.empty_like(q)
-    rc = _lib.load().fresco_temporal_attn_sharded(q.data_ptr(), k.data_ptr(), v.data_ptr(), fwd_map.data_ptr(),
-                                                  mask.data_ptr(), out.data_ptr(), chunk, N, HW, heads, D,
-                                                  float(scale), n_loc, f0, krs, vrs, _stream())
+    out = torch.empty((Bt, HW, C), dtype=q.dtype, device=q.device)
+    if shard is None:
+        rc = _lib.load().fresco_temporal_attn_ld(q.data_ptr(), k.data_ptr(), v.data_ptr(), fwd_map.data_ptr(),
+                                                 mask.data_ptr(), out.data_ptr(), chunk, N, HW, heads, D,
+                                                 float(scale), q_ld, k_ld, v_ld, _stream())
+    else:
+        rc = _lib.load().fresco_temporal_attn_sharded(q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                      fwd_map.data_ptr(), mask.data_ptr(), out.data_ptr(), chunk,
+                                                      N, HW, heads, D, float(scale), n_loc, f0, krs, vrs,
+                                                      _stream())
     _lib.check(rc, "fresco_temporal_attn(chunk=%d,N=%d,n_loc=%d,HW=%d,H=%d,D=%d)" % (chunk, N, n_loc, HW, heads, D))
     return out
 

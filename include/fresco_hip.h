@@ -93,6 +93,15 @@ int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* 
                     int n_groups, int M, int64_t group_rows,
                     float scale, float diag_bias, void* stream);
 
+/* Same with explicit row strides (in halfs, multiples of 8, >= H*D): q row r starts at q + r*q_ld,
+ * k / v row r at k + r*kv_ld -- for q, k, v that are column slices of one fused projection output
+ * (B, HW, 3*H*D).  `out` is always dense (B, Lq, H*D). */
+int fresco_attn_fwd_ld(const void* q, const void* k, const void* v, const int32_t* kv_rows,
+                       void* out, void* workspace, size_t workspace_bytes,
+                       int B, int H, int Lq, int D,
+                       int n_groups, int M, int64_t group_rows,
+                       float scale, float diag_bias, int64_t q_ld, int64_t kv_ld, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * (a4)  Temporal-guided (FLATTEN) attention -- replaces DH:309-367: 3 rearrange+gather round
  * trips, the per-pixel N x N masked SDPA and the inverse gather.
@@ -108,6 +117,12 @@ int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* 
 int fresco_temporal_attn(const void* q, const void* k, const void* v, const int64_t* fwd_map,
                          const uint8_t* mask, void* out,
                          int chunk, int N, int HW, int H, int D, float scale, void* stream);
+
+/* Row-strided form (q, k, v rows start every q_ld / k_ld / v_ld halfs; out dense). */
+int fresco_temporal_attn_ld(const void* q, const void* k, const void* v, const int64_t* fwd_map,
+                            const uint8_t* mask, void* out,
+                            int chunk, int N, int HW, int H, int D, float scale,
+                            int64_t q_ld, int64_t k_ld, int64_t v_ld, void* stream);
 
 /* Frame-sharded form (multi-GPU): this rank owns the n_loc frames [f0, f0+n_loc) of
  * both CFG halves.  q, out : (chunk*n_loc, HW, H*D) local.  k, v hold ALL N frames as written by an
