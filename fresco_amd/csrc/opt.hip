@@ -370,7 +370,10 @@ __device__ __forceinline__ void store_rowmajor_tile(float (*S)[GT], int tid, con
 }
 
 // G = V V^T tile.  MODE 0: write int8 sign(G - T) (+ optional loss += sum|G - T|); MODE 1: write G.
-// grid (ceil(hw/128), ceil(hw/128), B)
+// MODE 0 exploits the symmetry of G (bitwise: the same k-ordered fma chain for (p,q) and (q,p)) and of
+// the target: only tiles on or above the diagonal are computed -- grid (nt*(nt+1)/2, 1, B) -- and the
+// sign tile is also written transposed to its mirror position through LDS, so sv_kernel still reads
+// full rows.  Halves the MFMA work and the T stream of the Gram step.  MODE 1: grid (nt, nt, B).
 template <int MODE>
 __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ vt,
                                                     const float* __restrict__ target,
@@ -381,7 +384,21 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ vt,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int b = blockIdx.z;
-    const int p0 = blockIdx.y * GT, q0 = blockIdx.x * GT;
+    int ti, tj;
+    if (MODE == 0) {
+        const int nt = (hw + GT - 1) / GT;
+        int rem = blockIdx.x;
+        ti = 0;
+        while (rem >= nt - ti) {
+            rem -= nt - ti;
+            ++ti;
+        }
+        tj = ti + rem;
+    } else {
+        ti = blockIdx.y;
+        tj = blockIdx.x;
+    }
+    const int p0 = ti * GT, q0 = tj * GT;
     const float* v = vt + (int64_t)b * C * hw;
     const bool vec_ok = (hw % 4 == 0);
 
@@ -409,21 +426,28 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ vt,
     }
 
     const int l31 = lane & 31, hi = lane >> 5;
+    const bool mirror = (MODE == 0) && (ti != tj);
+    int8_t* tr = reinterpret_cast<int8_t*>(&As[0][0][0]);  // [128 cols][TRS] transposed sign tile (LDS is free now)
+    constexpr int TRS = GT + 16;
     float lsum = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const int col = q0 + wn * 64 + ni * 32 + l31;
+            const int cl = wn * 64 + ni * 32 + l31;
+            const int col = q0 + cl;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = p0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int row = p0 + rl;
                 if (row < hw && col < hw) {
                     const int64_t o = ((int64_t)b * hw + row) * hw + col;
                     const float gval = acc.a[mi][ni][r];
                     if (MODE == 0) {
                         const float d = gval - target[o];
-                        sgn_out[o] = (int8_t)sgn(d);
+                        const int8_t sg = (int8_t)sgn(d);
+                        sgn_out[o] = sg;
+                        if (mirror) tr[cl * TRS + rl] = sg;
                         lsum += fabsf(d);
                     } else {
                         g_out[o] = gval;
@@ -431,9 +455,27 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ vt,
                 }
             }
         }
+    if (mirror) {
+        __syncthreads();
+        // rows of the mirror tile = columns of this one; 128 bytes per row, 16 bytes per thread and step
+        const bool v16 = (hw % 16 == 0);
+        for (int i = tid; i < GT * (GT / 16); i += 256) {
+            const int cl = i / (GT / 16), ch = i % (GT / 16);
+            const int grow = q0 + cl, gcol = p0 + ch * 16;
+            if (grow >= hw) continue;
+            int8_t* dst = sgn_out + ((int64_t)b * hw + grow) * hw + gcol;
+            const int8_t* src = tr + cl * TRS + ch * 16;
+            if (v16 && gcol + 15 < hw) {
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+            } else {
+                for (int e = 0; e < 16; ++e)
+                    if (gcol + e < hw) dst[e] = src[e];
+            }
+        }
+    }
     if (MODE == 0 && loss) {
         __shared__ float red[4];
-        const float tot = block_sum_256(lsum, red);
+        const float tot = block_sum_256(mirror ? 2.f * lsum : lsum, red);
         if (tid == 0) atomicAdd(loss, tot);
     }
 }
@@ -650,7 +692,7 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         const int nt = (hw + GT - 1) / GT;
         {
             ProfScope ps(FRESCO_PROF_OPT_GRAM, B, C, hw, 0, st);
-            hipLaunchKernelGGL((gram_kernel<0>), dim3(nt, nt, B), dim3(256), 0, st, w.vt, target, w.ssign,
+            hipLaunchKernelGGL((gram_kernel<0>), dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vt, target, w.ssign,
                                (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
         }
         const float coef = intra_weight / ((float)B * (float)hw * (float)hw);
