@@ -129,3 +129,43 @@ def test_forward_hook_semantics(monkeypatch):
     calls.clear()
     out = pipe.unet(x, 800, return_dict=False)
     assert float(out[0]) == 111.0 and not calls and len(out) == 1 + 3  # default layers [0,1,2,3] -> 3 blocks here
+
+
+def test_capi_argument_validation_without_gpu():
+    """Argument checks run before any launch, so the error codes can be exercised on the CPU with
+    dummy non-null pointers (nothing is dereferenced)."""
+    from fresco_amd import _lib
+    lib = _lib.load()
+    p = 4096  # fake, aligned, never touched
+    EINVAL, EUNSUP, EWS = -1, -2, -3
+    ws = lib.fresco_attn_workspace_bytes(2, 8, 100, 40)
+    ok_args = dict(B=4, H=8, Lq=64, D=40, G=2, M=100, rows=200)
+
+    def attn(q=p, k=p, v=p, out=p, w=p, wsb=ws, B=4, H=8, Lq=64, D=40, G=2, M=100, rows=200, scale=0.1):
+        return lib.fresco_attn_fwd(q, k, v, None, out, w, wsb, B, H, Lq, D, G, M, rows, scale, 0.0, None)
+
+    assert attn(q=None) == EINVAL and attn(out=None) == EINVAL and attn(w=None) == EINVAL
+    assert attn(B=5) == EINVAL            # batch not divisible by the number of key groups
+    assert attn(scale=0.0) == EINVAL and attn(M=0) == EINVAL and attn(Lq=0) == EINVAL
+    assert attn(wsb=ws - 1) == EWS
+    assert attn(D=24, wsb=1 << 30) == EUNSUP    # head dims are instantiated for 8,16,32,40,64,80,96,128
+    assert lib.fresco_attn_fwd_ld(p, p, p, None, p, p, ws, 4, 8, 64, 40, 2, 100, 200, 0.1, 0.0, 300, 320, None) == EINVAL
+    # temporal pass: N*H > 256 threads per trajectory, head dim without an instantiation, bad sharding
+    assert lib.fresco_temporal_attn(p, p, p, p, p, p, 2, 40, 64, 8, 40, 0.1, None) == EUNSUP
+    assert lib.fresco_temporal_attn(p, p, p, p, p, p, 2, 8, 64, 8, 24, 0.1, None) == EUNSUP
+    assert lib.fresco_temporal_attn(p, p, p, None, p, p, 2, 8, 64, 8, 40, 0.1, None) == EINVAL
+    assert lib.fresco_temporal_attn_sharded(p, p, p, p, p, p, 2, 8, 64, 8, 40, 0.1, 3, 0, 0, 0, None) == EINVAL
+    # warp chain needs two frames; dilate needs an odd kernel; AdaIN needs >= 2 elements per row and a known dtype
+    assert lib.fresco_warp_fuse_chain(p, p, p, p, p, p, p, p, 2, 1, 4, 8, 8, None) == EUNSUP
+    assert lib.fresco_dilate(p, p, 1, 8, 8, 4, None) == EINVAL
+    assert lib.fresco_adain(p, p, p, 4, 1, 1e-5, 1.0, 0, None) == EINVAL
+    assert lib.fresco_adain(p, p, p, 4, 16, 1e-5, 1.0, 7, None) == EUNSUP
+    assert lib.fresco_flow_warp(p, p, p, 1, 1, 4, 4, 1, None) == EINVAL   # in-place warp is refused
+    # feature optimisation: flows without occlusions, no active term, workspace too small
+    need = lib.fresco_opt_workspace_bytes(2, 4, 16, 8, 8, 1, 1)
+    run = lambda fwd_flow=p, bwd_flow=p, fwd_occ=p, bwd_occ=p, target=p, wsb=need, iw=100.0: lib.fresco_opt_run(
+        p, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, p, wsb, 2, 4, 16, 8, 8, iw, 3, 0.2, 0.9, 0.999, 1e-8, None)
+    assert run(fwd_occ=None) == EINVAL
+    assert run(fwd_flow=None, bwd_flow=None, fwd_occ=None, bwd_occ=None, target=None) == EINVAL
+    assert run(fwd_flow=None, bwd_flow=None, fwd_occ=None, bwd_occ=None, iw=0.0) == EINVAL
+    assert run(wsb=need - 1) == EWS
