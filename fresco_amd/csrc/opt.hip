@@ -21,6 +21,7 @@
 //   sv             dV^T = 2 coef V^T S on the same MFMA (S in {-1,0,1}, exact)
 //   adam_update    norm backward + Adam step, fused, fp32 state
 #include "common.h"
+#include <stdlib.h>
 
 namespace fresco {
 
@@ -280,7 +281,8 @@ constexpr int ECPT = 8;  // channels per thread in the elementwise kernels
 // vt = x / |x[p]|, nrm[b][p] = |x[p]|.  grid (ceil(hw/256), ceil(C/ECPT), B)
 __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ cs,
                                                          const float* __restrict__ part, float* __restrict__ vt,
-                                                         float* __restrict__ nrm, int C, int hw, int S) {
+                                                         float* __restrict__ nrm, half_t* __restrict__ vh,
+                                                         half_t* __restrict__ vl, int C, int hw, int S) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= hw) return;
     const int b = blockIdx.z, c0 = blockIdx.y * ECPT, cend = min(c0 + ECPT, C);
@@ -290,7 +292,13 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
     if (blockIdx.y == 0) nrm[(int64_t)b * hw + p] = n;
     for (int c = c0; c < cend; ++c) {
         const int64_t o = ((int64_t)b * C + c) * hw + p;
-        vt[o] = cs[o] / n;
+        const float val = cs[o] / n;
+        vt[o] = val;
+        if (vh) {  // V = vh + vl to ~2^-22 (|V| <= 1): operands of the fp16-MFMA form of S V
+            const half_t hi16 = (half_t)val;
+            vh[o] = hi16;
+            vl[o] = (half_t)(val - (float)hi16);
+        }
     }
 }
 
@@ -369,65 +377,18 @@ __device__ __forceinline__ void store_rowmajor_tile(float (*S)[GT], int tid, con
         *reinterpret_cast<floatx4*>(&S[(tid >> 5) + 8 * i][(tid & 31) * 4]) = src[i];
 }
 
-// G = V V^T tile.  MODE 0: write int8 sign(G - T) (+ optional loss += sum|G - T|); MODE 1: write G.
-// MODE 0 exploits the symmetry of G (bitwise: the same k-ordered fma chain for (p,q) and (q,p)) and of
-// the target: only tiles on or above the diagonal are computed -- grid (nt*(nt+1)/2, 1, B) -- and the
-// sign tile is also written transposed to its mirror position through LDS, so sv_kernel still reads
-// full rows.  Halves the MFMA work and the T stream of the Gram step.  MODE 1: grid (nt, nt, B).
+// Epilogue shared by the fp32 and the fp16-split Gram kernels: MODE 0 writes sign(G - T) (and, for an
+// off-diagonal tile, the transposed tile to the mirror position, staged through `tr` = >= 18 KB of LDS
+// that is free once the main loop is done); MODE 1 writes G.
 template <int MODE>
-__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ vt,
-                                                    const float* __restrict__ target,
-                                                    int8_t* __restrict__ sgn_out, float* __restrict__ g_out,
-                                                    float* __restrict__ loss, int C, int hw) {
-    __shared__ __attribute__((aligned(16))) float As[2][GK][GT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void gram_epilogue(const GemmAcc& acc, int8_t* tr, const float* __restrict__ target,
+                                              int8_t* __restrict__ sgn_out, float* __restrict__ g_out,
+                                              float* __restrict__ loss, int b, int ti, int tj, int hw, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z;
-    int ti, tj;
-    if (MODE == 0) {
-        const int nt = (hw + GT - 1) / GT;
-        int rem = blockIdx.x;
-        ti = 0;
-        while (rem >= nt - ti) {
-            rem -= nt - ti;
-            ++ti;
-        }
-        tj = ti + rem;
-    } else {
-        ti = blockIdx.y;
-        tj = blockIdx.x;
-    }
     const int p0 = ti * GT, q0 = tj * GT;
-    const float* v = vt + (int64_t)b * C * hw;
-    const bool vec_ok = (hw % 4 == 0);
-
-    GemmAcc acc;
-    gemm_zero(acc);
-    floatx4 ra[2], rb[2];
-    const int nk = (C + GK - 1) / GK;
-    load_rowmajor_tile(v, hw, 0, p0, C, hw, vec_ok, tid, ra);
-    load_rowmajor_tile(v, hw, 0, q0, C, hw, vec_ok, tid, rb);
-    store_rowmajor_tile(As[0], tid, ra);
-    store_rowmajor_tile(Bs[0], tid, rb);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) {
-            load_rowmajor_tile(v, hw, (kc + 1) * GK, p0, C, hw, vec_ok, tid, ra);
-            load_rowmajor_tile(v, hw, (kc + 1) * GK, q0, C, hw, vec_ok, tid, rb);
-        }
-        gemm_chunk(acc, As[buf], Bs[buf], wm, wn, lane);
-        if (kc + 1 < nk) {
-            store_rowmajor_tile(As[buf ^ 1], tid, ra);
-            store_rowmajor_tile(Bs[buf ^ 1], tid, rb);
-        }
-        __syncthreads();
-    }
-
     const int l31 = lane & 31, hi = lane >> 5;
     const bool mirror = (MODE == 0) && (ti != tj);
-    int8_t* tr = reinterpret_cast<int8_t*>(&As[0][0][0]);  // [128 cols][TRS] transposed sign tile (LDS is free now)
     constexpr int TRS = GT + 16;
     float lsum = 0.f;
 #pragma unroll
@@ -478,6 +439,68 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ vt,
         const float tot = block_sum_256(mirror ? 2.f * lsum : lsum, red);
         if (tid == 0) atomicAdd(loss, tot);
     }
+}
+
+__device__ __forceinline__ void tri_tile(int bid, int nt, int& ti, int& tj) {
+    ti = 0;
+    while (bid >= nt - ti) {
+        bid -= nt - ti;
+        ++ti;
+    }
+    tj = ti + bid;
+}
+
+// G = V V^T tile.  MODE 0: write int8 sign(G - T) (+ optional loss += sum|G - T|); MODE 1: write G.
+// MODE 0 exploits the symmetry of G (bitwise: the same k-ordered fma chain for (p,q) and (q,p)) and of
+// the target: only tiles on or above the diagonal are computed -- grid (nt*(nt+1)/2, 1, B) -- and the
+// sign tile is also written transposed to its mirror position through LDS, so sv_kernel still reads
+// full rows.  Halves the MFMA work and the T stream of the Gram step.  MODE 1: grid (nt, nt, B).
+template <int MODE>
+__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ vt,
+                                                    const float* __restrict__ target,
+                                                    int8_t* __restrict__ sgn_out, float* __restrict__ g_out,
+                                                    float* __restrict__ loss, int C, int hw) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK][GT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z;
+    int ti, tj;
+    if (MODE == 0) {
+        tri_tile(blockIdx.x, (hw + GT - 1) / GT, ti, tj);
+    } else {
+        ti = blockIdx.y;
+        tj = blockIdx.x;
+    }
+    const int p0 = ti * GT, q0 = tj * GT;
+    const float* v = vt + (int64_t)b * C * hw;
+    const bool vec_ok = (hw % 4 == 0);
+
+    GemmAcc acc;
+    gemm_zero(acc);
+    floatx4 ra[2], rb[2];
+    const int nk = (C + GK - 1) / GK;
+    load_rowmajor_tile(v, hw, 0, p0, C, hw, vec_ok, tid, ra);
+    load_rowmajor_tile(v, hw, 0, q0, C, hw, vec_ok, tid, rb);
+    store_rowmajor_tile(As[0], tid, ra);
+    store_rowmajor_tile(Bs[0], tid, rb);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) {
+            load_rowmajor_tile(v, hw, (kc + 1) * GK, p0, C, hw, vec_ok, tid, ra);
+            load_rowmajor_tile(v, hw, (kc + 1) * GK, q0, C, hw, vec_ok, tid, rb);
+        }
+        gemm_chunk(acc, As[buf], Bs[buf], wm, wn, lane);
+        if (kc + 1 < nk) {
+            store_rowmajor_tile(As[buf ^ 1], tid, ra);
+            store_rowmajor_tile(Bs[buf ^ 1], tid, rb);
+        }
+        __syncthreads();
+    }
+
+    gram_epilogue<MODE>(acc, reinterpret_cast<int8_t*>(&As[0][0][0]), target, sgn_out, g_out, loss, b, ti, tj, hw,
+                        tid);
 }
 
 // dV^T[c][p] = alpha * sum_q V^T[c][q] * S[q][p]   (S symmetric sign matrix, int8)
@@ -581,6 +604,125 @@ __global__ __launch_bounds__(256) void sv_kernel(const float* __restrict__ vt,
 }
 
 // ------------------------------------------------------------------------------------------------
+// dV^T = alpha * V^T S on fp16 MFMA with V split into two halfs:  V = Vh + Vl,  |V| <= 1, so the pair
+// carries V to an absolute 2^-25 -- fp32 class -- and S in {-1,0,1} is exact in fp16; every product
+// is exact in the fp32 accumulator.  2 x v_mfma_f32_32x32x16_f16 replace 8 x v_mfma_f32_32x32x2_f32:
+// 1/8 of the matrix-pipe time of sv_kernel.  Both operands are read k-contiguous: A = rows c of
+// V^T (k = pixel q), B = rows p of the SYMMETRIC sign matrix (S[q][p] = S[p][q]).
+// Block tile 128 (c) x 128 (p), K chunk 32, LDS rows of 64 B + 16 B pad (conflict-free ds_read_b128).
+// Requires hw % 16 == 0 (16-byte aligned rows); other sizes use sv_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int SK = 32;             // K chunk (pixels)
+constexpr int SROW = SK * 2 + 16;  // LDS bytes per tile row
+
+__global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
+                                                    const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
+                                                    int C, int hw, float alpha) {
+    __shared__ __attribute__((aligned(16))) char lds[2][3][GT * SROW];  // [stage][Vh, Vl, S][row]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * GT, p0 = blockIdx.x * GT;
+    const half_t* vhb = vh + (int64_t)b * C * hw;
+    const half_t* vlb = vl + (int64_t)b * C * hw;
+    const int8_t* sb = sgn_in + (int64_t)b * hw * hw;
+
+    // staging: V tiles 128 rows x 4 chunks of 8 halfs -> 2 chunks per thread and array; S tile 128 rows x
+    // 2 chunks of 16 int8 -> 1 chunk per thread, widened to 16 halfs when written to LDS
+    uint4 rvh[2], rvl[2], rs;
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + i * 256;
+            const int row = ch >> 2, kc = ch & 3;
+            const int c = c0 + row, k = k0 + kc * 8;
+            uint4 a = make_uint4(0, 0, 0, 0), l = a;
+            if (c < C && k < hw) {
+                a = *reinterpret_cast<const uint4*>(vhb + (int64_t)c * hw + k);
+                l = *reinterpret_cast<const uint4*>(vlb + (int64_t)c * hw + k);
+            }
+            rvh[i] = a;
+            rvl[i] = l;
+        }
+        const int row = tid >> 1, kc = tid & 1;
+        const int p = p0 + row, k = k0 + kc * 16;
+        rs = make_uint4(0, 0, 0, 0);
+        if (p < hw && k < hw) rs = *reinterpret_cast<const uint4*>(sb + (int64_t)p * hw + k);
+    };
+    auto store = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + i * 256;
+            const int row = ch >> 2, kc = ch & 3;
+            *reinterpret_cast<uint4*>(&lds[st][0][row * SROW + kc * 16]) = rvh[i];
+            *reinterpret_cast<uint4*>(&lds[st][1][row * SROW + kc * 16]) = rvl[i];
+        }
+        const int row = tid >> 1, kc = tid & 1;
+        const unsigned w4[4] = {rs.x, rs.y, rs.z, rs.w};
+        half8_t h0, h1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h0[e] = (half_t)(float)(int8_t)((w4[e >> 2] >> (8 * (e & 3))) & 0xff);
+            h1[e] = (half_t)(float)(int8_t)((w4[2 + (e >> 2)] >> (8 * (e & 3))) & 0xff);
+        }
+        *reinterpret_cast<half8_t*>(&lds[st][2][row * SROW + kc * 32]) = h0;
+        *reinterpret_cast<half8_t*>(&lds[st][2][row * SROW + kc * 32 + 16]) = h1;
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (hw + SK - 1) / SK;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int st = kc & 1;
+        if (kc + 1 < nk) load((kc + 1) * SK);
+        const char* ah = &lds[st][0][0];
+        const char* al = &lds[st][1][0];
+        const char* bs = &lds[st][2][0];
+#pragma unroll
+        for (int ks = 0; ks < SK / 16; ++ks) {
+            half8_t fa[2][2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + l31) * SROW + ks * 32 + hi * 16;
+                fa[i][0] = *reinterpret_cast<const half8_t*>(ah + off);
+                fa[i][1] = *reinterpret_cast<const half8_t*>(al + off);
+                fb[i] = *reinterpret_cast<const half8_t*>(bs + (wn * 64 + i * 32 + l31) * SROW + ks * 32 + hi * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < nk) store(st ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = p0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < C && col < hw) dvt[((int64_t)b * C + row) * hw + col] = acc[mi][ni][r] * alpha;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // norm backward + Adam, elementwise.  grid (ceil(hw/256), ceil(C/ECPT), B)
 //   g = grad_t (if has_t) + (dV - V <V,dV>)/|X| (if has_s);  <V,dV>[b][p] = sum of the S partials
 // mode 0: Adam update of cs, m, v;  mode 1: write g to gout (loss_grad entry)
@@ -628,6 +770,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
 // ------------------------------------------------------------------------------------------------
 struct OptWs {
     float *grad, *m, *v, *vt, *dvt, *nrm, *wgt, *part;
+    half_t *vh, *vl;
     int8_t *sgn1, *sgn2, *ssign;
     int *rowptr, *cursor, *src;
 };
@@ -652,6 +795,8 @@ static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int 
     tmp.dvt = has_s ? carve<float>(p, E) : nullptr;
     tmp.nrm = has_s ? carve<float>(p, B * hw) : nullptr;
     tmp.part = has_s ? carve<float>(p, B * 32 * hw) : nullptr;
+    tmp.vh = has_s ? carve<half_t>(p, E) : nullptr;
+    tmp.vl = has_s ? carve<half_t>(p, E) : nullptr;
     tmp.ssign = has_s ? carve<int8_t>(p, B * hw * hw) : nullptr;
     if (w) *w = tmp;
     return (size_t)(p - basep);
@@ -671,6 +816,14 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
     const float kscale = 2.f / ((float)B * (float)C * (float)hw);
     const int S = chan_slices(hw, B, C);
     const dim3 egrid((hw + 255) / 256, (C + ECPT - 1) / ECPT, B);
+    // S V on fp16 MFMA (V = Vh + Vl) whenever rows are 16-byte aligned; FRESCO_OPT_SV=f32 forces the
+    // fp32-MFMA kernel (A/B measurements)
+    static int sv_mode = -1;
+    if (sv_mode < 0) {
+        const char* e = getenv("FRESCO_OPT_SV");
+        sv_mode = (e && e[0] == 'f' && e[1] == '3') ? 1 : 0;
+    }
+    const bool f16_sv = (hw % 16 == 0) && sv_mode == 0;
     if (has_t) {
         dim3 grid((hw + 255) / 256, (C + OCPT - 1) / OCPT, B);
         {
@@ -687,19 +840,26 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
             ProfScope ps(FRESCO_PROF_OPT_COLNORM, B, C, hw, 0, st);
             hipLaunchKernelGGL((chan_partial_kernel<0>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, cs,
                                (const float*)nullptr, w.part, C, hw, S);
-            hipLaunchKernelGGL(normalize_kernel, egrid, dim3(256), 0, st, cs, w.part, w.vt, w.nrm, C, hw, S);
+            hipLaunchKernelGGL(normalize_kernel, egrid, dim3(256), 0, st, cs, w.part, w.vt, w.nrm,
+                               f16_sv ? w.vh : (half_t*)nullptr, f16_sv ? w.vl : (half_t*)nullptr, C, hw, S);
         }
         const int nt = (hw + GT - 1) / GT;
         {
             ProfScope ps(FRESCO_PROF_OPT_GRAM, B, C, hw, 0, st);
-            hipLaunchKernelGGL((gram_kernel<0>), dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vt, target, w.ssign,
-                               (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
+            // (an fp16-split form of this step, Vph Vph^T + Vph Vpl^T + Vpl Vph^T on pixel-major copies, was
+            // built and measured in round 1: 3.1 ms vs 1.74 ms here -- latency-bound at one block per CU)
+            hipLaunchKernelGGL((gram_kernel<0>), dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vt, target,
+                               w.ssign, (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
         }
         const float coef = intra_weight / ((float)B * (float)hw * (float)hw);
         {
             ProfScope ps(FRESCO_PROF_OPT_SV, B, C, hw, 0, st);
-            hipLaunchKernelGGL(sv_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vt, w.ssign, w.dvt,
-                               C, hw, 2.f * coef);
+            if (f16_sv)
+                hipLaunchKernelGGL(sv16_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vh, w.vl,
+                                   w.ssign, w.dvt, C, hw, 2.f * coef);
+            else
+                hipLaunchKernelGGL(sv_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vt, w.ssign,
+                                   w.dvt, C, hw, 2.f * coef);
         }
     }
     ProfScope ps(FRESCO_PROF_OPT_ADAM, B, C, hw, 0, st);
@@ -828,7 +988,7 @@ extern "C" int fresco_gram_target(const float* x, float* target, void* workspace
     hipLaunchKernelGGL((chan_partial_kernel<0>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, x,
                        (const float*)nullptr, part, C, hw, S);
     hipLaunchKernelGGL(normalize_kernel, dim3((hw + 255) / 256, (C + ECPT - 1) / ECPT, B), dim3(256), 0, st, x, part,
-                       vt, nrm, C, hw, S);
+                       vt, nrm, (half_t*)nullptr, (half_t*)nullptr, C, hw, S);
     const int nt = (hw + GT - 1) / GT;
     hipLaunchKernelGGL((gram_kernel<1>), dim3(nt, nt, B), dim3(256), 0, st, vt, (const float*)nullptr,
                        (int8_t*)nullptr, target, (float*)nullptr, C, hw);

@@ -114,8 +114,26 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     out[(int64_t)blockIdx.y * ho * wo + o] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
 }
 
+// F.max_pool2d(k): one wave per output element, lanes strided over the k x k window (k is 8..64 on
+// this path: a thread-per-output loop would serialise up to 4096 loads)
 __global__ __launch_bounds__(256) void max_pool_kernel(const float* __restrict__ x,
                                                         float* __restrict__ out, int H, int W, int k) {
+    const int ho = H / k, wo = W / k;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= ho * wo) return;
+    const int lane = threadIdx.x & 63;
+    const int oy = o / wo, ox = o % wo;
+    const float* p = x + (int64_t)blockIdx.y * H * W + (int64_t)oy * k * W + ox * k;
+    float m = p[0];
+    for (int i = lane; i < k * k; i += 64) m = fmaxf(m, p[(i / k) * W + (i % k)]);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if (lane == 0) out[(int64_t)blockIdx.y * ho * wo + o] = m;
+}
+
+// small windows (k < 8): one thread per output element
+__global__ __launch_bounds__(256) void max_pool_small_kernel(const float* __restrict__ x,
+                                                              float* __restrict__ out, int H, int W, int k) {
     const int ho = H / k, wo = W / k;
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= ho * wo) return;
@@ -197,8 +215,13 @@ extern "C" int fresco_resize_bilinear(const float* x, float* out, int BC, int H,
 extern "C" int fresco_max_pool(const float* x, float* out, int BC, int H, int W, int k, void* stream) {
     if (!x || !out || BC <= 0 || H <= 0 || W <= 0 || k <= 0 || H / k <= 0 || W / k <= 0) return FRESCO_EINVAL;
     if (BC > 65535) return FRESCO_EUNSUPPORTED;
-    dim3 grid(((H / k) * (W / k) + 255) / 256, BC);
-    hipLaunchKernelGGL(max_pool_kernel, grid, dim3(256), 0, as_stream(stream), x, out, H, W, k);
+    if (k < 8) {
+        dim3 grid(((H / k) * (W / k) + 255) / 256, BC);
+        hipLaunchKernelGGL(max_pool_small_kernel, grid, dim3(256), 0, as_stream(stream), x, out, H, W, k);
+    } else {
+        dim3 grid(((H / k) * (W / k) + 3) / 4, BC);
+        hipLaunchKernelGGL(max_pool_kernel, grid, dim3(256), 0, as_stream(stream), x, out, H, W, k);
+    }
     return check_launch();
 }
 
