@@ -21,6 +21,7 @@
 //   sv             dV^T = 2 coef V^T S on the same MFMA (S in {-1,0,1}, exact)
 //   adam_update    norm backward + Adam step, fused, fp32 state
 #include "common.h"
+#include <math.h>
 #include <stdlib.h>
 
 namespace fresco {
@@ -157,28 +158,47 @@ __global__ __launch_bounds__(1024) void csr_build_kernel(const float* __restrict
 
 constexpr int OCPT = 8;  // channels per thread in the temporal kernels
 
-// grid (ceil(hw/256), ceil(C/OCPT), chunk*N).  sgn1/sgn2: (chunk*N, C, hw) int8.
-// loss (optional): loss[0] += sum |r1| + |r2|  (unscaled)
+// Frame layout of the temporal term.  Single GPU: the n_loc = N frames of a CFG half form a ring,
+// pair j = (frame j, frame (j+1) % N), n_pairs = N.  Frame-sharded (multi-GPU): the rank owns n_loc
+// consecutive frames and receives the frame before (halo_l) and after (halo_r) them each iteration;
+// slots 0 .. n_loc+1 = halo_l, local frames, halo_r; pair j = (slot j, slot j+1), n_pairs = n_loc + 1
+// (the pair straddling the left boundary is evaluated redundantly by both neighbours).
+struct TLayout {
+    int n_loc, n_pairs, circular;
+    const float* halo_l;  // (chunk, C, hw)
+    const float* halo_r;
+};
+
+__device__ __forceinline__ const float* frame_plane(const float* cs, const TLayout& L, int ck, int slot, int c, int C,
+                                                    int hw) {
+    if (L.circular) return cs + ((int64_t)(ck * L.n_loc + slot) * C + c) * hw;
+    if (slot == 0) return L.halo_l + ((int64_t)ck * C + c) * hw;
+    if (slot == L.n_loc + 1) return L.halo_r + ((int64_t)ck * C + c) * hw;
+    return cs + ((int64_t)(ck * L.n_loc + slot - 1) * C + c) * hw;
+}
+
+// grid (ceil(hw/256), ceil(C/OCPT), chunk*n_pairs).  sgn1/sgn2: (chunk*n_pairs, C, hw) int8; flows / occs
+// are indexed by pair.  loss (optional): loss[0] += sum |r1| + |r2|  (unscaled; circular layout only)
 __global__ __launch_bounds__(256) void temporal_sign_kernel(
     const float* __restrict__ cs, const float* __restrict__ bwd_flow, const float* __restrict__ fwd_flow,
     const float* __restrict__ bwd_occ, const float* __restrict__ fwd_occ, int8_t* __restrict__ sgn1,
-    int8_t* __restrict__ sgn2, float* __restrict__ loss, int N, int C, int h, int w) {
+    int8_t* __restrict__ sgn2, float* __restrict__ loss, TLayout L, int C, int h, int w) {
     const int hw = h * w;
     const int p = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.z, ck = b / N, f = b % N;
-    const int fn = (f + 1) % N;
+    const int b = blockIdx.z, ck = b / L.n_pairs, j = b % L.n_pairs;
+    const int sa = j, sb = L.circular ? (j + 1) % L.n_loc : j + 1;
     const int c0 = blockIdx.y * OCPT, cend = min(c0 + OCPT, C);
     float lsum = 0.f;
     if (p < hw) {
-        const float* fb = bwd_flow + (int64_t)f * 2 * hw;
-        const float* ff = fwd_flow + (int64_t)f * 2 * hw;
+        const float* fb = bwd_flow + (int64_t)j * 2 * hw;
+        const float* ff = fwd_flow + (int64_t)j * 2 * hw;
         const OTaps tb = otaps(fb[p], fb[hw + p], p % w, p / w, h, w);
         const OTaps tf = otaps(ff[p], ff[hw + p], p % w, p / w, h, w);
-        const float mb = 1.f - bwd_occ[(int64_t)f * hw + p];
-        const float mf = 1.f - fwd_occ[(int64_t)f * hw + p];
+        const float mb = 1.f - bwd_occ[(int64_t)j * hw + p];
+        const float mf = 1.f - fwd_occ[(int64_t)j * hw + p];
         for (int c = c0; c < cend; ++c) {
-            const float* c1 = cs + ((int64_t)(ck * N + f) * C + c) * hw;
-            const float* c2 = cs + ((int64_t)(ck * N + fn) * C + c) * hw;
+            const float* c1 = frame_plane(cs, L, ck, sa, c, C, hw);
+            const float* c2 = frame_plane(cs, L, ck, sb, c, C, hw);
             const float r1 = (c2[p] - osample(c1, tb)) * mb;
             const float r2 = (c1[p] - osample(c2, tf)) * mf;
             const int64_t o = ((int64_t)b * C + c) * hw + p;
@@ -194,32 +214,36 @@ __global__ __launch_bounds__(256) void temporal_sign_kernel(
     }
 }
 
-// grad[b][c][p] = k mf[f][p] sgn2[f] + k mb[f-1][p] sgn1[f-1] - sum_rowB[f][p] w*sgn1[f][src]
-//                                                         - sum_rowF[f-1][p] w*sgn2[f-1][src]
+// For local frame fl with pairs  jf = the pair whose FIRST frame it is, jp = the pair whose SECOND:
+// grad[fl][c][p] = k mf[jf][p] sgn2[jf] + k mb[jp][p] sgn1[jp] - sum_rowB[jf][p] w*sgn1[jf][src]
+//                                                           - sum_rowF[jp][p] w*sgn2[jp][src]
 // The two CSR rows of a pixel are shared by all channels: their first TG_MAXE entries are held in
 // registers (a smooth flow gives ~4 entries per row), longer rows continue from memory.
 constexpr int TG_MAXE = 6;
 
+// grid (ceil(hw/256), ceil(C/OCPT), chunk*n_loc)
 __global__ __launch_bounds__(256) void temporal_grad_kernel(
     const int8_t* __restrict__ sgn1, const int8_t* __restrict__ sgn2, const float* __restrict__ bwd_occ,
     const float* __restrict__ fwd_occ, const int* __restrict__ rowptr, const int* __restrict__ src,
-    const float* __restrict__ wgt, float* __restrict__ grad, int N, int C, int hw, float kscale) {
+    const float* __restrict__ wgt, float* __restrict__ grad, TLayout L, int C, int hw, float kscale) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= hw) return;
-    const int b = blockIdx.z, ck = b / N, f = b % N;
-    const int fp = (f + N - 1) % N;
-    const int bp = ck * N + fp;
+    const int b = blockIdx.z, ck = b / L.n_loc, fl = b % L.n_loc;
+    const int NP = L.n_pairs;
+    const int jf = L.circular ? fl : fl + 1;
+    const int jp = L.circular ? (fl + L.n_loc - 1) % L.n_loc : fl;
+    const int bf = ck * NP + jf, bp = ck * NP + jp;
     const int c0 = blockIdx.y * OCPT, cend = min(c0 + OCPT, C);
-    const float a2 = kscale * (1.f - fwd_occ[(int64_t)f * hw + p]);
-    const float a1 = kscale * (1.f - bwd_occ[(int64_t)fp * hw + p]);
-    const int* rpB = rowptr + (int64_t)(0 * N + f) * (hw + 1);
-    const int* rpF = rowptr + (int64_t)(1 * N + fp) * (hw + 1);
+    const float a2 = kscale * (1.f - fwd_occ[(int64_t)jf * hw + p]);
+    const float a1 = kscale * (1.f - bwd_occ[(int64_t)jp * hw + p]);
+    const int* rpB = rowptr + (int64_t)(0 * NP + jf) * (hw + 1);
+    const int* rpF = rowptr + (int64_t)(1 * NP + jp) * (hw + 1);
     const int bB = rpB[p], eB = rpB[p + 1];
     const int bF = rpF[p], eF = rpF[p + 1];
-    const int* sB = src + (int64_t)(0 * N + f) * 4 * hw;
-    const float* wB = wgt + (int64_t)(0 * N + f) * 4 * hw;
-    const int* sF = src + (int64_t)(1 * N + fp) * 4 * hw;
-    const float* wF = wgt + (int64_t)(1 * N + fp) * 4 * hw;
+    const int* sB = src + (int64_t)(0 * NP + jf) * 4 * hw;
+    const float* wB = wgt + (int64_t)(0 * NP + jf) * 4 * hw;
+    const int* sF = src + (int64_t)(1 * NP + jp) * 4 * hw;
+    const float* wF = wgt + (int64_t)(1 * NP + jp) * 4 * hw;
     int iB[TG_MAXE], iF[TG_MAXE];
     float vB[TG_MAXE], vF[TG_MAXE];
 #pragma unroll
@@ -231,8 +255,8 @@ __global__ __launch_bounds__(256) void temporal_grad_kernel(
         vF[e] = okF ? wF[bF + e] : 0.f;
     }
     for (int c = c0; c < cend; ++c) {
-        const int8_t* s1f = sgn1 + ((int64_t)b * C + c) * hw;
-        const int8_t* s2f = sgn2 + ((int64_t)b * C + c) * hw;
+        const int8_t* s1f = sgn1 + ((int64_t)bf * C + c) * hw;
+        const int8_t* s2f = sgn2 + ((int64_t)bf * C + c) * hw;
         const int8_t* s1p = sgn1 + ((int64_t)bp * C + c) * hw;
         const int8_t* s2p = sgn2 + ((int64_t)bp * C + c) * hw;
         const float g = a2 * (float)s2f[p] + a1 * (float)s1p[p];
@@ -776,8 +800,10 @@ struct OptWs {
 };
 
 static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int h, int wd, int has_t,
-                            int has_s) {
-    const size_t B = (size_t)chunk * N, hw = (size_t)h * wd, E = B * C * hw;
+                            int has_s, int n_pairs = 0) {
+    // N = frames owned per CFG half; n_pairs = temporal pairs evaluated (N for the single-GPU ring)
+    const size_t NP = n_pairs > 0 ? n_pairs : N;
+    const size_t B = (size_t)chunk * N, hw = (size_t)h * wd, E = B * C * hw, EP = (size_t)chunk * NP * C * hw;
     // size query: lay out from a fake non-null base (no memory is touched)
     if (!basep) basep = reinterpret_cast<char*>(static_cast<uintptr_t>(4096));
     char* p = basep;
@@ -785,12 +811,12 @@ static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int 
     tmp.m = carve<float>(p, E);
     tmp.v = carve<float>(p, E);
     tmp.grad = has_t ? carve<float>(p, E) : nullptr;
-    tmp.sgn1 = has_t ? carve<int8_t>(p, E) : nullptr;
-    tmp.sgn2 = has_t ? carve<int8_t>(p, E) : nullptr;
-    tmp.rowptr = has_t ? carve<int>(p, (size_t)2 * N * (hw + 1)) : nullptr;
-    tmp.cursor = has_t ? carve<int>(p, (size_t)2 * N * hw) : nullptr;
-    tmp.src = has_t ? carve<int>(p, (size_t)2 * N * 4 * hw) : nullptr;
-    tmp.wgt = has_t ? carve<float>(p, (size_t)2 * N * 4 * hw) : nullptr;
+    tmp.sgn1 = has_t ? carve<int8_t>(p, EP) : nullptr;
+    tmp.sgn2 = has_t ? carve<int8_t>(p, EP) : nullptr;
+    tmp.rowptr = has_t ? carve<int>(p, (size_t)2 * NP * (hw + 1)) : nullptr;
+    tmp.cursor = has_t ? carve<int>(p, (size_t)2 * NP * hw) : nullptr;
+    tmp.src = has_t ? carve<int>(p, (size_t)2 * NP * 4 * hw) : nullptr;
+    tmp.wgt = has_t ? carve<float>(p, (size_t)2 * NP * 4 * hw) : nullptr;
     tmp.vt = has_s ? carve<float>(p, E) : nullptr;
     tmp.dvt = has_s ? carve<float>(p, E) : nullptr;
     tmp.nrm = has_s ? carve<float>(p, B * hw) : nullptr;
@@ -808,12 +834,14 @@ static int opt_check_grid(int chunk, int N, int C) {
 }
 
 // one closure evaluation; mode 0 = Adam step, mode 1 = write gradient to gout
+// (N = frames owned per CFG half; L describes the temporal layout; Bg = global batch 2*N_total, which
+// normalises both loss terms)
 static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const float* bwd_flow,
                         const float* fwd_occ, const float* bwd_occ, const float* target, int chunk, int N,
                         int C, int h, int wd, float intra_weight, int has_t, int has_s, int mode,
-                        float* gout, float* loss, AdamArgs a, hipStream_t st) {
+                        float* gout, float* loss, AdamArgs a, hipStream_t st, const TLayout& L, int Bg) {
     const int B = chunk * N, hw = h * wd;
-    const float kscale = 2.f / ((float)B * (float)C * (float)hw);
+    const float kscale = 2.f / ((float)Bg * (float)C * (float)hw);
     const int S = chan_slices(hw, B, C);
     const dim3 egrid((hw + 255) / 256, (C + ECPT - 1) / ECPT, B);
     // S V on fp16 MFMA (V = Vh + Vl) whenever rows are 16-byte aligned; FRESCO_OPT_SV=f32 forces the
@@ -826,14 +854,15 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
     const bool f16_sv = (hw % 16 == 0) && sv_mode == 0;
     if (has_t) {
         dim3 grid((hw + 255) / 256, (C + OCPT - 1) / OCPT, B);
+        dim3 sgrid(grid.x, grid.y, chunk * L.n_pairs);
         {
             ProfScope ps(FRESCO_PROF_OPT_TSIGN, B, C, hw, 0, st);
-            hipLaunchKernelGGL(temporal_sign_kernel, grid, dim3(256), 0, st, cs, bwd_flow, fwd_flow, bwd_occ,
-                               fwd_occ, w.sgn1, w.sgn2, loss, N, C, h, wd);
+            hipLaunchKernelGGL(temporal_sign_kernel, sgrid, dim3(256), 0, st, cs, bwd_flow, fwd_flow, bwd_occ,
+                               fwd_occ, w.sgn1, w.sgn2, loss, L, C, h, wd);
         }
         ProfScope ps(FRESCO_PROF_OPT_TGRAD, B, C, hw, 0, st);
         hipLaunchKernelGGL(temporal_grad_kernel, grid, dim3(256), 0, st, w.sgn1, w.sgn2, bwd_occ, fwd_occ,
-                           w.rowptr, w.src, w.wgt, w.grad, N, C, hw, kscale);
+                           w.rowptr, w.src, w.wgt, w.grad, L, C, hw, kscale);
     }
     if (has_s) {
         {
@@ -851,7 +880,7 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
             hipLaunchKernelGGL((gram_kernel<0>), dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vt, target,
                                w.ssign, (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
         }
-        const float coef = intra_weight / ((float)B * (float)hw * (float)hw);
+        const float coef = intra_weight / ((float)Bg * (float)hw * (float)hw);
         {
             ProfScope ps(FRESCO_PROF_OPT_SV, B, C, hw, 0, st);
             if (f16_sv)
@@ -903,14 +932,25 @@ static int opt_common_checks(const float* cs, const float* fwd_flow, const float
     return FRESCO_OK;
 }
 
+// CSR of the warp adjoints of `n_pairs` pairs (flows / occs indexed by pair); Bg = global batch
 static void opt_prepare(const OptWs& ws, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
-                        const float* bwd_occ, int chunk, int N, int C, int h, int w, int has_t,
+                        const float* bwd_occ, int n_pairs, int Bg, int C, int h, int w, int has_t,
                         hipStream_t st) {
     if (!has_t) return;
-    const int B = chunk * N, hw = h * w;
-    const float kscale = 2.f / ((float)B * (float)C * (float)hw);
-    hipLaunchKernelGGL(csr_build_kernel, dim3(N, 2), dim3(1024), 0, st, bwd_flow, fwd_flow, bwd_occ, fwd_occ,
-                       ws.rowptr, ws.cursor, ws.src, ws.wgt, N, h, w, kscale);
+    const int hw = h * w;
+    const float kscale = 2.f / ((float)Bg * (float)C * (float)hw);
+    hipLaunchKernelGGL(csr_build_kernel, dim3(n_pairs, 2), dim3(1024), 0, st, bwd_flow, fwd_flow, bwd_occ, fwd_occ,
+                       ws.rowptr, ws.cursor, ws.src, ws.wgt, n_pairs, h, w, kscale);
+}
+
+static AdamArgs adam_args(int it, float lr, float beta1, float beta2, float eps) {
+    AdamArgs a;
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, it)));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, it));
+    a.eps = eps;
+    return a;
 }
 
 extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
@@ -929,20 +969,11 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
     const size_t E = (size_t)chunk * N * C * h * w;
     (void)hipMemsetAsync(ws.m, 0, E * sizeof(float), st);
     (void)hipMemsetAsync(ws.v, 0, E * sizeof(float), st);
-    opt_prepare(ws, fwd_flow, bwd_flow, fwd_occ, bwd_occ, chunk, N, C, h, w, has_t, st);
-    double b1t = 1.0, b2t = 1.0;
-    for (int it = 1; it <= iters; ++it) {
-        b1t *= (double)beta1;
-        b2t *= (double)beta2;
-        AdamArgs a;
-        a.beta1 = beta1;
-        a.beta2 = beta2;
-        a.step_size = (float)((double)lr / (1.0 - b1t));
-        a.bc2_sqrt = (float)sqrt(1.0 - b2t);
-        a.eps = eps;
+    opt_prepare(ws, fwd_flow, bwd_flow, fwd_occ, bwd_occ, N, chunk * N, C, h, w, has_t, st);
+    const TLayout L = {N, N, 1, nullptr, nullptr};
+    for (int it = 1; it <= iters; ++it)
         opt_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, N, C, h, w, intra_weight,
-                    has_t, has_s, 0, nullptr, nullptr, a, st);
-    }
+                    has_t, has_s, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N);
     return check_launch();
 }
 
@@ -959,16 +990,71 @@ extern "C" int fresco_opt_loss_grad(const float* cs, const float* fwd_flow, cons
     hipStream_t st = as_stream(stream);
     OptWs ws;
     opt_ws_layout(&ws, static_cast<char*>(workspace), chunk, N, C, h, w, has_t, has_s);
-    opt_prepare(ws, fwd_flow, bwd_flow, fwd_occ, bwd_occ, chunk, N, C, h, w, has_t, st);
+    opt_prepare(ws, fwd_flow, bwd_flow, fwd_occ, bwd_occ, N, chunk * N, C, h, w, has_t, st);
     if (loss) (void)hipMemsetAsync(loss, 0, 2 * sizeof(float), st);
     AdamArgs a = {0.f, 0.f, 0.f, 1.f, 0.f};
+    const TLayout L = {N, N, 1, nullptr, nullptr};
     opt_closure(ws, const_cast<float*>(cs), fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, N, C, h, w,
-                intra_weight, has_t, has_s, 1, grad, loss, a, st);
+                intra_weight, has_t, has_s, 1, grad, loss, a, st, L, chunk * N);
     if (loss) {
         const double B = (double)chunk * N, hw = (double)h * w;
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, loss, (float)(2.0 / (B * C * hw)),
                            (float)((double)intra_weight / (B * hw * hw)));
     }
+    return check_launch();
+}
+
+// ---- frame-sharded form (multi-GPU): begin once per optimize_feature call, then one step per Adam
+// iteration with the neighbours' boundary frames exchanged by the host in between -------------------
+extern "C" size_t fresco_opt_sharded_workspace_bytes(int chunk, int n_loc, int C, int h, int w, int has_temporal,
+                                                     int has_target) {
+    if (chunk <= 0 || n_loc <= 0 || C <= 0 || h <= 0 || w <= 0) return 0;
+    return opt_ws_layout(nullptr, nullptr, chunk, n_loc, C, h, w, has_temporal, has_target, n_loc + 1);
+}
+
+extern "C" int fresco_opt_sharded_begin(const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                                        const float* bwd_occ, void* workspace, size_t workspace_bytes, int chunk,
+                                        int n_loc, int N_total, int C, int h, int w, int has_target,
+                                        void* stream) {
+    if (!workspace || chunk <= 0 || n_loc <= 0 || N_total < n_loc || C <= 0 || h <= 1 || w <= 1) return FRESCO_EINVAL;
+    const bool any_t = fwd_flow || bwd_flow || fwd_occ || bwd_occ;
+    const bool all_t = fwd_flow && bwd_flow && fwd_occ && bwd_occ;
+    if (any_t && !all_t) return FRESCO_EINVAL;
+    const int has_t = all_t ? 1 : 0, has_s = has_target ? 1 : 0;
+    if (!has_t && !has_s) return FRESCO_EINVAL;
+    if (int rc = opt_check_grid(chunk, n_loc + 1, C)) return rc;
+    if (workspace_bytes < opt_ws_layout(nullptr, nullptr, chunk, n_loc, C, h, w, has_t, has_s, n_loc + 1))
+        return FRESCO_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    OptWs ws;
+    opt_ws_layout(&ws, static_cast<char*>(workspace), chunk, n_loc, C, h, w, has_t, has_s, n_loc + 1);
+    const size_t E = (size_t)chunk * n_loc * C * h * w;
+    (void)hipMemsetAsync(ws.m, 0, E * sizeof(float), st);
+    (void)hipMemsetAsync(ws.v, 0, E * sizeof(float), st);
+    opt_prepare(ws, fwd_flow, bwd_flow, fwd_occ, bwd_occ, n_loc + 1, chunk * N_total, C, h, w, has_t, st);
+    return check_launch();
+}
+
+extern "C" int fresco_opt_sharded_step(float* cs, const float* halo_l, const float* halo_r,
+                                       const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                                       const float* bwd_occ, const float* target, void* workspace,
+                                       size_t workspace_bytes, int chunk, int n_loc, int N_total, int C, int h,
+                                       int w, float intra_weight, int it, float lr, float beta1, float beta2,
+                                       float eps, void* stream) {
+    if (!cs || !workspace || chunk <= 0 || n_loc <= 0 || N_total < n_loc || C <= 0 || h <= 1 || w <= 1 || it < 1)
+        return FRESCO_EINVAL;
+    const bool all_t = fwd_flow && bwd_flow && fwd_occ && bwd_occ;
+    const int has_t = all_t ? 1 : 0, has_s = (target && intra_weight > 0.f) ? 1 : 0;
+    if (!has_t && !has_s) return FRESCO_EINVAL;
+    if (has_t && (!halo_l || !halo_r)) return FRESCO_EINVAL;
+    if (workspace_bytes < opt_ws_layout(nullptr, nullptr, chunk, n_loc, C, h, w, has_t, has_s, n_loc + 1))
+        return FRESCO_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    OptWs ws;
+    opt_ws_layout(&ws, static_cast<char*>(workspace), chunk, n_loc, C, h, w, has_t, has_s, n_loc + 1);
+    const TLayout L = {n_loc, n_loc + 1, 0, halo_l, halo_r};
+    opt_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, n_loc, C, h, w, intra_weight, has_t,
+                has_s, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N_total);
     return check_launch();
 }
 

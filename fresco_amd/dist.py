@@ -19,6 +19,12 @@ Payload per rank and layer at 8 x 512^2 on 8 GPUs: K|V 10.5 MB (up_blocks.3) / 5
 xGMI is point-to-point (7 links x ~153 GB/s), so a direct all-gather moves each shard over its own
 link: ~70 us -- comparable to the sharded kernels, hence the overlap.
 
+optimize_feature: Gram loss, normalisation, Adam and AdaIN are per frame (local); the temporal L1 term
+couples frame f with f+-1, so every Adam iteration starts with a halo exchange of the ranks' boundary
+frames (`exchange_halos`: one all-gather of 2 frames per rank, 42 MB at the largest layer) and each
+rank evaluates the n_loc+1 frame pairs touching its frames (`fresco_opt_sharded_step`).  warp_tensor's
+frame chain is a scan over frames and is not sharded (replicas).
+
 The index arithmetic lives in plain functions so that it is testable on CPU (gloo, world_size 2).
 """
 import torch
@@ -71,6 +77,21 @@ class FrameShard:
         out = x.new_empty((self.world * x.shape[0],) + tuple(x.shape[1:]))  # rank-major concatenation
         work = dist.all_gather_into_tensor(out, x, group=self.group, async_op=async_op)
         return out.view((self.world,) + tuple(x.shape)), work
+
+    def pair_index(self):
+        """Global indices of the n_loc+1 frame pairs (f, f+1 mod N) this rank evaluates in the temporal
+        term of optimize_feature: pairs f0-1 .. f0+n_loc-1 (ring order)."""
+        return [(self.f0 - 1 + j) % self.N for j in range(self.n_loc + 1)]
+
+    def exchange_halos(self, cs):
+        """cs: local (chunk*n_loc, C, h, w).  Returns (halo_l, halo_r) = the current frame before / after
+        the owned range, (chunk, C, h, w) each, via one all-gather of every rank's first and last frame."""
+        x = cs.view(self.chunk, self.n_loc, *cs.shape[1:])
+        edges = torch.stack((x[:, 0], x[:, self.n_loc - 1]))  # (2, chunk, C, h, w): first, last
+        allb, _ = self.all_gather(edges)
+        left = (self.rank - 1) % self.world
+        right = (self.rank + 1) % self.world
+        return allb[left, 1], allb[right, 0]
 
     def kv_rows(self, rows, HW, key, device):
         """Remapped int32 key rows (on `device`) + group_rows for the fused K|V gather buffer;

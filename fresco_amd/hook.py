@@ -36,6 +36,7 @@ class _OptState:
         self.intra_weight, self.iters = intra_weight, iters
         self.optimize_temporal = optimize_temporal
         self.saliency = saliency
+        self.shard = None  # fresco_amd.dist.FrameShard: set on unet._fresco_opt_state for frame-parallel runs
         self.active = False
         self.up_samples = ()
         self.handles = []
@@ -59,11 +60,12 @@ def _make_block_hook(state, i):
         state.up_samples += (sample,)
         if not state.active:
             return None
+        extra = {} if state.shard is None else {"shard": state.shard}
         sample = _opt.optimize_feature(sample, state.flows, state.occs, state.correlation_matrix,
                                        state.intra_weight, state.iters,
-                                       optimize_temporal=state.optimize_temporal)
+                                       optimize_temporal=state.optimize_temporal, **extra)
         if state.saliency is not None:
-            sample = _warp.warp_tensor(sample, state.flows, state.occs, state.saliency, 2)
+            sample = _warp.warp_tensor(sample, state.flows, state.occs, state.saliency, 2, **extra)
         if in_kwargs:
             kwargs = dict(kwargs)
             kwargs["hidden_states"] = sample

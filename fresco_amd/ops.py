@@ -284,6 +284,45 @@ def opt_run(cs, prep, target, intra_weight, iters, chunk, lr=0.2, betas=(0.9, 0.
     return cs
 
 
+def opt_run_sharded(cs, prep_pairs, target, intra_weight, iters, chunk, N_total, exchange, lr=0.2,
+                    betas=(0.9, 0.999), eps=1e-8, workspace=None):
+    """Frame-sharded optimize_feature loop (fresco_opt_sharded_begin / _step).
+
+    cs: local (chunk*n_loc, C, h, w) fp32 contiguous, updated in place.
+    prep_pairs = (fwd_flow, bwd_flow, fwd_occ, bwd_occ) for the n_loc+1 local frame pairs, or None.
+    exchange(cs) -> (halo_l, halo_r): current frame before / after the owned range, (chunk, C, h, w) each;
+    called before every step (it is where the inter-GPU traffic happens)."""
+    _need_gpu(cs)
+    assert cs.dtype == torch.float32 and cs.is_contiguous()
+    Bt, C, h, w = cs.shape
+    n_loc = Bt // chunk
+    keep = (None, None, None, None)
+    if prep_pairs is not None:
+        keep = tuple(_f32c(t) for t in prep_pairs)
+        assert keep[0].shape == (n_loc + 1, 2, h, w) and keep[2].numel() == (n_loc + 1) * h * w
+    if target is not None:
+        target = _f32c(target)
+        assert target.shape == (Bt, h * w, h * w)
+    lib = _lib.load()
+    has_t, has_s = int(prep_pairs is not None), int(target is not None and intra_weight > 0)
+    nbytes = lib.fresco_opt_sharded_workspace_bytes(chunk, n_loc, C, h, w, has_t, has_s)
+    ws = (workspace or _default_ws).get(nbytes, cs.device)
+    rc = lib.fresco_opt_sharded_begin(_ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]), ws.data_ptr(),
+                                      ws.numel(), chunk, n_loc, N_total, C, h, w, has_s, _stream())
+    _lib.check(rc, "fresco_opt_sharded_begin")
+    for it in range(1, iters + 1):
+        halo_l = halo_r = None
+        if has_t:
+            halo_l, halo_r = exchange(cs)
+            halo_l, halo_r = _f32c(halo_l), _f32c(halo_r)
+        rc = lib.fresco_opt_sharded_step(cs.data_ptr(), _ptr(halo_l), _ptr(halo_r), _ptr(keep[0]), _ptr(keep[1]),
+                                         _ptr(keep[2]), _ptr(keep[3]), _ptr(target), ws.data_ptr(), ws.numel(),
+                                         chunk, n_loc, N_total, C, h, w, float(intra_weight), it, float(lr),
+                                         float(betas[0]), float(betas[1]), float(eps), _stream())
+        _lib.check(rc, "fresco_opt_sharded_step(it=%d)" % it)
+    return cs
+
+
 def opt_loss_grad(cs, prep, target, intra_weight, chunk, workspace=None):
     """One closure evaluation: returns (loss_temporal, loss_spatial) device tensor (2,) and grad."""
     _need_gpu(cs)

@@ -35,9 +35,19 @@ def _prep_flow_occ(h, flows, occs, with_dilate):
 
 
 @torch.no_grad()
-def warp_tensor(sample, flows, occs, saliency, unet_chunk_size):
+def warp_tensor(sample, flows, occs, saliency, unet_chunk_size, shard=None):
     """flow_utils.py:18-53: warp frame i into frame i+1 along the chain and blend by
-    (1-occ) * saliency * warped saliency; the last step warps frame 0 into frame N-1."""
+    (1-occ) * saliency * warped saliency; the last step warps frame 0 into frame N-1.
+
+    shard (extension): a fresco_amd.dist.FrameShard.  The chain is a scan over frames, so it does not
+    shard: the ranks all-gather their frames, every rank runs the whole chain (cheap, HBM-bound) and
+    keeps its own frames ("replicas only" for this op)."""
+    if shard is not None:
+        allf, _ = shard.all_gather(sample.contiguous())  # (world, chunk*n_loc, C, h, w)
+        full = allf.view(shard.world, shard.chunk, shard.n_loc, *sample.shape[1:]).transpose(0, 1)
+        full = full.reshape(shard.chunk * shard.N, *sample.shape[1:])
+        out = warp_tensor(full, flows, occs, saliency, unet_chunk_size)
+        return out.index_select(0, shard.local_batch_index().to(out.device)).contiguous()
     h = sample.shape[2]
     fwd_flow, bwd_flow, fwd_occ, bwd_occ = _prep_flow_occ(h, flows, occs, with_dilate=True)
     scale2 = h * 1.0 / saliency.shape[2]

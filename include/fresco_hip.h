@@ -207,6 +207,27 @@ int fresco_opt_loss_grad(const float* cs, const float* fwd_flow, const float* bw
                          float* grad, float* loss, void* workspace, size_t workspace_bytes,
                          int chunk, int N, int C, int h, int w, float intra_weight, void* stream);
 
+/* Frame-sharded optimize_feature (multi-GPU): this rank owns n_loc consecutive frames of
+ * both CFG halves out of N_total.  cs, target : local (chunk*n_loc, ...).  The temporal term couples
+ * neighbouring frames, so before EVERY step the host hands over the current values of the frame before
+ * (halo_l) and after (halo_r) the owned range, each (chunk, C, h, w) fp32 (ring order, wrap-around).
+ * fwd_flow, bwd_flow : (n_loc+1, 2, h, w), fwd_occ, bwd_occ : (n_loc+1, h, w) -- entry j belongs to the
+ * frame pair (f0-1+j, f0+j) mod N_total; both loss terms are normalised by the GLOBAL batch 2*N_total.
+ * begin: zero the Adam state, build the warp-adjoint CSRs; step `it` = 1..iters: one Adam iteration.
+ * With n_loc = N_total and halos = own last / first frame this reproduces fresco_opt_run. */
+size_t fresco_opt_sharded_workspace_bytes(int chunk, int n_loc, int C, int h, int w, int has_temporal,
+                                          int has_target);
+int fresco_opt_sharded_begin(const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                             const float* bwd_occ, void* workspace, size_t workspace_bytes,
+                             int chunk, int n_loc, int N_total, int C, int h, int w, int has_target,
+                             void* stream);
+int fresco_opt_sharded_step(float* cs, const float* halo_l, const float* halo_r,
+                            const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                            const float* bwd_occ, const float* target, void* workspace,
+                            size_t workspace_bytes, int chunk, int n_loc, int N_total, int C, int h, int w,
+                            float intra_weight, int it, float lr, float beta1, float beta2, float eps,
+                            void* stream);
+
 /* Gram target of get_intraframe_paras (DH:889-895): T[b] = V V^T, V = rows of x (B,C,h,w)
  * viewed as (B, hw, C) and L2-normalised; fp32 (B,hw,hw).  workspace: B*C*hw + 33*B*hw floats
  * (each block rounded up to 256 bytes). */

@@ -75,3 +75,83 @@ def test_sharded_processor_equals_single_gpu(world, mode):
         d = float((o.float() - ref_out.index_select(0, sel).float()).abs().max())
         # same kernels, same key order: only the projection GEMMs see a different batch size
         assert d < 5e-4, (world, mode, d)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_sharded_optimize_feature_equals_single_gpu(world):
+    """frame-sharded optimize_feature (halo exchange every Adam step) == the single-GPU loop.  Same kernels,
+    same summation orders -> the raw optimised features agree exactly (checked through the public function,
+    i.e. after AdaIN, to a rounding-level tolerance)."""
+    import fresco_amd
+    from fresco_amd.dist import FrameShard
+
+    N, chunk = 4, 2
+    case = synth.make_opt_case(N, 24, 16, 64, seed=11)
+    x = case["x"].to(DEV)
+    flows = [f.to(DEV) for f in case["flows"]]
+    occs = [o.to(DEV) for o in case["occs"]]
+    target = case["target"].to(DEV)
+    ref = fresco_amd.optimize_feature(x, flows, occs, [target], iters=4)
+    torch.cuda.synchronize()
+
+    slots = [None] * world
+    barrier = threading.Barrier(world)
+    outs, errs = [None] * world, []
+
+    def rank_fn(r):
+        try:
+            base = FrameShard(N, chunk, r, world)
+            sh = ThreadShard(base, slots, barrier)
+            sh.exchange_halos = lambda cs: FrameShard.exchange_halos(sh, cs)
+            sh.pair_index = base.pair_index
+            sel = base.local_batch_index().to(DEV)
+            # every emulated rank needs its own scratch (real ranks are separate processes)
+            outs[r] = (sel, fresco_amd.optimize_feature(x.index_select(0, sel).contiguous(), flows, occs,
+                                                        [target.index_select(0, sel).contiguous()], iters=4,
+                                                        shard=sh, _workspace=fresco_amd.ops.Workspace()))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            barrier.abort()
+
+    ts = [threading.Thread(target=rank_fn, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for sel, o in outs:
+        d = float((o - ref.index_select(0, sel)).abs().max())
+        assert d < 1e-5, (world, d)
+
+
+def test_sharded_warp_tensor_replicas():
+    import fresco_amd
+    from fresco_amd.dist import FrameShard
+
+    N, chunk, world = 4, 2, 2
+    case = synth.make_opt_case(N, 12, 16, 64, seed=12)
+    x = case["x"].to(DEV)
+    flows = [f.to(DEV) for f in case["flows"]]
+    occs = [o.to(DEV) for o in case["occs"]]
+    sal = case["sal"].to(DEV)
+    ref = fresco_amd.warp_tensor(x, flows, occs, sal, chunk)
+    slots, barrier = [None] * world, threading.Barrier(world)
+    outs, errs = [None] * world, []
+
+    def rank_fn(r):
+        try:
+            base = FrameShard(N, chunk, r, world)
+            sh = ThreadShard(base, slots, barrier)
+            sh.local_batch_index = base.local_batch_index
+            sel = base.local_batch_index().to(DEV)
+            outs[r] = (sel, fresco_amd.warp_tensor(x.index_select(0, sel).contiguous(), flows, occs, sal, chunk,
+                                                   shard=sh))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            barrier.abort()
+
+    ts = [threading.Thread(target=rank_fn, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for sel, o in outs:
+        assert torch.equal(o, ref.index_select(0, sel))
