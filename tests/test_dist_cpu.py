@@ -58,6 +58,16 @@ def _worker(rank, world, port, N, chunk, HW, C, ret):
                 vb = gathered_batch(gf, c, sh.n_loc, B_loc)
                 ok &= torch.equal(kv.view(-1, HW, C)[kb], K[c * N + gf])
                 ok &= torch.equal(hs_all.view(-1, HW, C)[vb], V[c * N + gf])
+        # (3) optimize_feature halos: frame before / after the owned range (ring), and the pair list
+        X = torch.randn(chunk * N, 3, 4, 5, generator=g)
+        hl, hr = sh.exchange_halos(X[sel].contiguous())
+        Xg = X.view(chunk, N, 3, 4, 5)
+        ok &= torch.equal(hl, Xg[:, (sh.f0 - 1) % N]) and torch.equal(hr, Xg[:, (sh.f0 + sh.n_loc) % N])
+        ok &= sh.pair_index() == [(sh.f0 - 1 + j) % N for j in range(sh.n_loc + 1)]
+        # (4) warp_tensor's re-assembly of the global (c, f) batch order from the rank-major gather
+        allf, _ = sh.all_gather(X[sel].contiguous())
+        full = allf.view(world, chunk, sh.n_loc, 3, 4, 5).transpose(0, 1).reshape(chunk * N, 3, 4, 5)
+        ok &= torch.equal(full, X)
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
