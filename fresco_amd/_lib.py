@@ -51,6 +51,8 @@ SIGNATURES = {
     "fresco_opt_sharded_workspace_bytes": (_sz, [_i] * 7),
     "fresco_opt_sharded_begin": (_i, [_vp] * 5 + [_sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fresco_opt_sharded_step": (_i, [_vp] * 9 + [_sz, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _vp]),
+    "fresco_mapping_workspace_bytes": (_sz, [_i, _i, _i]),
+    "fresco_mapping_ind": (_i, [_vp] * 7 + [_sz, _i, _i, _i, _f, _vp]),
     "fresco_gram_target": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
 }
 

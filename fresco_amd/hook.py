@@ -133,5 +133,13 @@ def patch_reference(dh=None, pf=None, fu=None):
     if pf is not None:
         pf.warp_tensor = _warp.warp_tensor
     if fu is not None:
+        from . import mapping
+
         fu.warp_tensor = _warp.warp_tensor
         fu.flow_warp = _warp.flow_warp
+        fu.get_mapping_ind = mapping.get_mapping_ind
+        fu.get_single_mapping_ind = mapping.get_single_mapping_ind
+    if dh is not None:
+        from . import mapping
+
+        dh.get_mapping_ind = mapping.get_mapping_ind  # looked up by get_flow_and_interframe_paras (:943)

@@ -64,7 +64,27 @@ class Workspace:
         return self.buf
 
 
-_default_ws = Workspace()
+class _PerStreamWorkspace:
+    """Default scratch when the caller passes none: one grow-only buffer per (thread, device, stream), so
+    that concurrent callers on different streams or threads never share scratch memory."""
+
+    def __init__(self):
+        import threading
+
+        self._tls = threading.local()
+
+    def get(self, nbytes, device):
+        table = getattr(self._tls, "table", None)
+        if table is None:
+            table = self._tls.table = {}
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = table.get(key)
+        if ws is None:
+            ws = table[key] = Workspace()
+        return ws.get(nbytes, device)
+
+
+_default_ws = _PerStreamWorkspace()
 
 
 # ---------------------------------------------------------------------------------------------

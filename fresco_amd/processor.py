@@ -12,6 +12,7 @@ the controller interaction are the reference's; the data 
   * the linear projections stay `attn.to_q/to_k/to_v/to_out` (torch GEMMs owned by diffusers).
 """
 import math
+import weakref
 
 import torch
 
@@ -32,12 +33,13 @@ class FRESCOAttnProcessor2_0:
     def _kv_rows(self, mask):
         key = (mask.data_ptr(), tuple(mask.shape), mask._version)
         hit = self._rows_cache.get(key)
-        if hit is None:
+        if hit is None or hit[0]() is not mask:  # the weakref guards against a recycled address
             if len(self._rows_cache) > 16:
                 self._rows_cache.clear()
-            hit = torch.nonzero(mask.reshape(-1), as_tuple=False).squeeze(1).to(torch.int32).contiguous()
+            rows = torch.nonzero(mask.reshape(-1), as_tuple=False).squeeze(1).to(torch.int32).contiguous()
+            hit = (weakref.ref(mask), rows)
             self._rows_cache[key] = hit
-        return hit
+        return hit[1]
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
         residual = hidden_states

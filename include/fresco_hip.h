@@ -234,6 +234,22 @@ int fresco_opt_sharded_step(float* cs, const float* halo_l, const float* halo_r,
 int fresco_gram_target(const float* x, float* target, void* workspace, size_t workspace_bytes,
                        int B, int C, int hw, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (f1)  FLATTEN pixel correspondences -- get_mapping_ind / get_single_mapping_ind (FU:56-138) without
+ * the per-pixel Python loop.  Inputs are the reference's intermediates at the reduced resolution
+ * (produced with fresco_resize_bilinear, scale_factor = 1/scale):
+ *   flow   : (N-1, 2, H, W) resized bwd flow, channel 0 = x, 1 = y, NOT yet divided by scale
+ *   occ    : (N-1, H, W)    resized bwd occlusion (> 0.5 = occluded)
+ *   frames : (N, 3, H*W)    resized images
+ * Outputs: fwd_map, bwd_map (N, H*W) int64, mask (H*W, N, N) uint8 {0,1}.  Integers are bit-exact with
+ * the reference's CPU run (ties: the earliest source wins, unlinked targets get the unused sources in
+ * ascending order).
+ * ------------------------------------------------------------------------------------------ */
+size_t fresco_mapping_workspace_bytes(int N, int H, int W);
+int fresco_mapping_ind(const float* flow, const float* occ, const float* frames, int64_t* fwd_map,
+                       int64_t* bwd_map, uint8_t* mask, void* workspace, size_t workspace_bytes,
+                       int N, int H, int W, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
