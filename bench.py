@@ -175,6 +175,42 @@ def pmc_traffic_bytes(kernel_substr):
                 note="(2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch; separate --pmc passes")
 
 
+def torch_gpu_baseline(layers, params, N, device):
+    """The reference algorithm as plain PyTorch ops on the SAME GPU (oracle.fresco_attention on fp16 cuda
+    tensors, dense passes through torch's SDPA like the reference): the "reference PyTorch path" the
+    north-star speed-up target is stated against.  One call per (layer kind, mode), schedule-weighted."""
+    from oracle import fresco_oracle as O
+
+    O.USE_TORCH_SDPA = True
+    t_mode = {}
+    for mode in ("full", "cf_temporal", "cf"):
+        tot = 0.0
+        for l in (layers[0], layers[3]):
+            a = l["attn"]
+            W = [a.to_q.weight, a.to_k.weight, a.to_v.weight, a.to_out[0].weight]
+            fwd, _, tm, cfm = params[l["down"]]
+            kw = dict(use_cf=True, cf_mask=cfm.to(device))
+            if mode in ("full", "cf_temporal"):
+                kw.update(fwd_map=fwd[:, 0].to(device), tmask=tm[:, 0].to(device))
+            if mode == "full":
+                kw.update(ref=l["ref"])
+            with torch.no_grad():
+                for rep in range(3):  # 2 warm-up runs, the third is timed
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    O.fresco_attention(l["hidden"], W[0], W[1], W[2], W[3], a.to_out[0].bias, 8, **kw)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+            tot += 3 * dt
+        t_mode[mode] = tot
+    O.USE_TORCH_SDPA = False
+    step_s = sum(t_mode[m] for m in SCHEDULE) / len(SCHEDULE)
+    return dict(value=round(1.0 / step_s, 3), unit="denoising-steps/sec", kind="port",
+                sample="oracle.fresco_attention on fp16 cuda tensors (torch SDPA + gather/rearrange ops), one call per "
+                       "(layer kind, mode), x3 layers, schedule-weighted: " +
+                       ", ".join("%s %.1f ms" % (m, 1e3 * t) for m, t in t_mode.items()))
+
+
 def read_prof(lib, cap):
     tags = (ctypes.c_int * cap)()
     dims = (ctypes.c_int * (4 * cap))()
@@ -308,6 +344,8 @@ def main():
             "kernel_avg_us": kernels_us,
         }
         if not args.no_cpu_baseline and world == 1:
+            res["torch_gpu_baseline"] = torch_gpu_baseline(layers, params, N, device)
+            res["speedup_vs_torch_gpu"] = round(res["value"] / res["torch_gpu_baseline"]["value"], 2)
             res["cpu_baseline"] = cpu_baseline(layers, params, N)
         elif world == 1:
             res["cpu_baseline"] = None
