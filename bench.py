@@ -16,7 +16,8 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, attn_flas
 up_blocks.3 cross-frame pass: algorithmic flop 4*B*HW*M*C per launch / mean HIP-event duration of those
 launches, measured in a second, instrumented replay of the same K steps (so `value` is not perturbed).
 `cpu_baseline` times the oracle (a CPU port of the reference algorithm) on rank 0's host cores on one
-call per (layer, mode) and weights them by the schedule.
+call per (layer, mode) and weights them by the schedule; `torch_gpu_baseline` times the same port as plain
+PyTorch ops on the same GPU (the "reference PyTorch path" of the north star).
 """
 import argparse
 import ctypes
@@ -236,13 +237,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
                              % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # FRESCO_BENCH_BACKEND=gloo + FRESCO_BENCH_ONE_GPU=1: functional test of the multi-process path on a
+    # single-GPU box (all ranks on device 0, collectives staged through the host) -- not a measurement
+    one_gpu = os.environ.get("FRESCO_BENCH_ONE_GPU") == "1"
+    backend = os.environ.get("FRESCO_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import fresco_amd
     from fresco_amd import _lib
@@ -274,6 +283,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     def run(k0, k):
         with torch.no_grad():
             for s in range(k0, k0 + k):
@@ -284,11 +300,7 @@ def main():
     t0 = time.perf_counter()
     run(0, args.steps)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     # instrumented replay of the same K steps: per-launch HIP-event durations of the dominant kernel
     cap = args.steps * 64 + 64

@@ -74,6 +74,13 @@ class FrameShard:
     def all_gather(self, x, async_op=False):
         """x (any shape, contiguous) -> (world, *x.shape); returns (buffer, work-or-None)."""
         x = x.contiguous()
+        if x.is_cuda and dist.get_backend(self.group) == "gloo":
+            # functional testing of the multi-process path without RCCL (e.g. several ranks on one GPU):
+            # stage through host memory
+            xc = x.cpu()
+            outc = xc.new_empty((self.world * xc.shape[0],) + tuple(xc.shape[1:]))
+            dist.all_gather_into_tensor(outc, xc, group=self.group)
+            return outc.to(x.device).view((self.world,) + tuple(x.shape)), None
         out = x.new_empty((self.world * x.shape[0],) + tuple(x.shape[1:]))  # rank-major concatenation
         work = dist.all_gather_into_tensor(out, x, group=self.group, async_op=async_op)
         return out.view((self.world,) + tuple(x.shape)), work
