@@ -223,3 +223,41 @@ def test_full_size_properties_cfg2():
                        group_rows=N * HW)
     assert float((op.float() - out.float()).abs().max()) < 2e-3
     assert torch.isfinite(out.float()).all()
+
+
+def test_processor_4d_input_residual_rescale_groupnorm():
+    """the generic AttnProcessor branches SD-1.5's attn1 does not take: 4-D (B,C,h,w) hidden states,
+    group_norm, residual connection and output rescale (diffusion_hacked.py:183-199, 379-385)"""
+    import fresco_amd
+    g = synth.gen(21)
+    B, C, h, w, heads = 4, 64, 6, 5, 8
+    attn = synth.FakeAttn(C, heads)
+    attn.group_norm = torch.nn.GroupNorm(8, C)
+    attn.residual_connection = True
+    attn.rescale_output_factor = 2.0
+    with torch.no_grad():
+        for p in attn.parameters():
+            p.copy_(p.half().float())
+    x = torch.randn(B, C, h, w, generator=g).half()
+    proc = fresco_amd.FRESCOAttnProcessor2_0(2, fresco_amd.AttentionControl())
+    with torch.no_grad():
+        out = proc(copy.deepcopy(attn).to(DEV).half(), x.to(DEV))
+        xs = x.float().view(B, C, h * w).transpose(1, 2)
+        xn = attn.group_norm(xs.transpose(1, 2)).transpose(1, 2)
+        W = [p.detach().float() for p in attn.weights()]
+        core = O.fresco_attention(xn, W[0], W[1], W[2], W[3], attn.to_out[0].bias.detach().float(), heads,
+                                  round_dtype=torch.float16)
+        ref = (core.transpose(-1, -2).reshape(B, C, h, w) + x.float()) / 2.0
+    assert out.shape == (B, C, h, w) and out.dtype == torch.float16
+    _check(out, ref, atol=3e-3, rtol=3e-3, what="4-D / residual / rescale")
+
+
+def test_processor_rejects_unsupported_inputs():
+    import fresco_amd
+    attn = synth.FakeAttn(64, 8).to(DEV)
+    proc = fresco_amd.FRESCOAttnProcessor2_0(2, fresco_amd.AttentionControl())
+    x32 = torch.zeros(2, 16, 64, device=DEV)
+    with pytest.raises(TypeError):          # fp32 hidden states: the kernels are fp16 (no silent down-cast)
+        proc(attn, x32)
+    with pytest.raises(NotImplementedError):
+        proc(attn.half(), x32.half(), attention_mask=torch.zeros(2, 1, 16, device=DEV))
