@@ -12,10 +12,12 @@ from .opt import optimize_feature
 from .warp import Dilate, adaptive_instance_normalization, flow_warp, warp_tensor
 from .hook import apply_FRESCO_opt, disable_FRESCO_opt, patch_reference
 from .mapping import cross_frame_masks, get_mapping_ind, get_single_mapping_ind
+from .step import predict_x0, step
 
 __all__ = [
     "AttentionControl", "FRESCOAttnProcessor2_0", "apply_FRESCO_attn", "optimize_feature",
     "warp_tensor", "flow_warp", "adaptive_instance_normalization", "Dilate", "apply_FRESCO_opt",
     "disable_FRESCO_opt", "patch_reference", "get_mapping_ind", "get_single_mapping_ind", "cross_frame_masks",
+    "step", "predict_x0",
     "FrescoHipError", "LIB_PATH",
 ]

@@ -53,6 +53,8 @@ SIGNATURES = {
     "fresco_opt_sharded_step": (_i, [_vp] * 9 + [_sz, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _vp]),
     "fresco_mapping_workspace_bytes": (_sz, [_i, _i, _i]),
     "fresco_mapping_ind": (_i, [_vp] * 7 + [_sz, _i, _i, _i, _f, _vp]),
+    "fresco_ddpm_x0": (_i, [_vp] * 5 + [_i64, _f, _f, _f, _i, _vp]),
+    "fresco_ddpm_prev": (_i, [_vp] * 4 + [_i64, _i64, _f, _f, _f, _i, _vp]),
     "fresco_gram_target": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
 }
 

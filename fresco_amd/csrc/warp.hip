@@ -273,3 +273,70 @@ extern "C" int fresco_adain(const void* content, const void* style, void* out, i
         return FRESCO_EUNSUPPORTED;
     return check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// (f2) DDPM step pieces of src/pipe_FRESCO.py:14-77, 212-214 as fused elementwise kernels (fp32 math,
+// fp16 / fp32 storage).  x0 = (x_t - sqrt(1-abar_t) * eps) / sqrt(abar_t), with eps optionally formed in
+// flight by classifier-free guidance  eps = e_u + s (e_c - e_u);  x_{t-1} = c0 x0 + c1 x_t + sigma z.
+// ------------------------------------------------------------------------------------------------
+namespace fresco {
+template <typename T>
+__global__ __launch_bounds__(256) void ddpm_x0_kernel(const T* __restrict__ xt, const T* __restrict__ eps_u,
+                                                       const T* __restrict__ eps_c, T* __restrict__ x0,
+                                                       T* __restrict__ eps_out, int64_t n, float guidance,
+                                                       float sqrt_beta, float sqrt_alpha) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float e = (float)eps_u[i];
+    if (eps_c) e = e + guidance * ((float)eps_c[i] - e);
+    if (eps_out) eps_out[i] = (T)e;
+    x0[i] = (T)(((float)xt[i] - sqrt_beta * e) / sqrt_alpha);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ddpm_prev_kernel(const T* __restrict__ x0, const T* __restrict__ xt,
+                                                         const T* __restrict__ noise, T* __restrict__ out,
+                                                         int64_t n, int64_t noise_period, float c_x0, float c_xt,
+                                                         float sigma) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float mean = c_x0 * (float)x0[i] + c_xt * (float)xt[i];
+    out[i] = (T)(mean + sigma * (float)noise[i % noise_period]);
+}
+}  // namespace fresco
+
+extern "C" int fresco_ddpm_x0(const void* xt, const void* eps_uncond, const void* eps_text, void* x0,
+                              void* eps_out, int64_t n, float guidance, float sqrt_beta_prod,
+                              float sqrt_alpha_prod, int dtype, void* stream) {
+    if (!xt || !eps_uncond || !x0 || n <= 0 || !(sqrt_alpha_prod > 0.f)) return FRESCO_EINVAL;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t st = as_stream(stream);
+    if (dtype == FRESCO_F16)
+        hipLaunchKernelGGL((ddpm_x0_kernel<half_t>), grid, dim3(256), 0, st, (const half_t*)xt,
+                           (const half_t*)eps_uncond, (const half_t*)eps_text, (half_t*)x0, (half_t*)eps_out, n,
+                           guidance, sqrt_beta_prod, sqrt_alpha_prod);
+    else if (dtype == FRESCO_F32)
+        hipLaunchKernelGGL((ddpm_x0_kernel<float>), grid, dim3(256), 0, st, (const float*)xt,
+                           (const float*)eps_uncond, (const float*)eps_text, (float*)x0, (float*)eps_out, n, guidance,
+                           sqrt_beta_prod, sqrt_alpha_prod);
+    else
+        return FRESCO_EUNSUPPORTED;
+    return check_launch();
+}
+
+extern "C" int fresco_ddpm_prev(const void* x0, const void* xt, const void* noise, void* out, int64_t n,
+                                int64_t noise_period, float c_x0, float c_xt, float sigma, int dtype,
+                                void* stream) {
+    if (!x0 || !xt || !noise || !out || n <= 0 || noise_period <= 0) return FRESCO_EINVAL;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t st = as_stream(stream);
+    if (dtype == FRESCO_F16)
+        hipLaunchKernelGGL((ddpm_prev_kernel<half_t>), grid, dim3(256), 0, st, (const half_t*)x0, (const half_t*)xt,
+                           (const half_t*)noise, (half_t*)out, n, noise_period, c_x0, c_xt, sigma);
+    else if (dtype == FRESCO_F32)
+        hipLaunchKernelGGL((ddpm_prev_kernel<float>), grid, dim3(256), 0, st, (const float*)x0, (const float*)xt,
+                           (const float*)noise, (float*)out, n, noise_period, c_x0, c_xt, sigma);
+    else
+        return FRESCO_EUNSUPPORTED;
+    return check_launch();
+}

@@ -131,7 +131,10 @@ def patch_reference(dh=None, pf=None, fu=None):
         dh.flow_warp = _warp.flow_warp
         dh.adaptive_instance_normalization = _warp.adaptive_instance_normalization
     if pf is not None:
+        from . import step as _step
+
         pf.warp_tensor = _warp.warp_tensor
+        pf.step = _step.step  # inference() looks `step` up in its module globals (pipe_FRESCO.py:222-228)
     if fu is not None:
         from . import mapping
 

@@ -250,6 +250,22 @@ int fresco_mapping_ind(const float* flow, const float* occ, const float* frames,
                        int64_t* bwd_map, uint8_t* mask, void* workspace, size_t workspace_bytes,
                        int N, int H, int W, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (f2)  DDPM step of src/pipe_FRESCO.py:14-77 (+ classifier-free guidance, 212-214), elementwise over n
+ * values, dtype FRESCO_F16 / FRESCO_F32 (fp32 arithmetic inside):
+ *   fresco_ddpm_x0  : eps = eps_text ? eps_uncond + guidance*(eps_text - eps_uncond) : eps_uncond
+ *                     (written to eps_out if non-NULL);  x0 = (xt - sqrt_beta_prod*eps) / sqrt_alpha_prod
+ *   fresco_ddpm_prev: out = c_x0*x0 + c_xt*xt + sigma*noise[i % noise_period]
+ *                     (noise_period = n, or one frame's element count for repeat_noise)
+ * The background-smoothing hack between the two (VAE decode -> warp_tensor -> VAE encode of x0) stays
+ * with the caller.
+ * ------------------------------------------------------------------------------------------ */
+int fresco_ddpm_x0(const void* xt, const void* eps_uncond, const void* eps_text, void* x0, void* eps_out,
+                   int64_t n, float guidance, float sqrt_beta_prod, float sqrt_alpha_prod, int dtype,
+                   void* stream);
+int fresco_ddpm_prev(const void* x0, const void* xt, const void* noise, void* out, int64_t n,
+                     int64_t noise_period, float c_x0, float c_xt, float sigma, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
