@@ -26,6 +26,8 @@
 
 namespace fresco {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------------------------------------
 // shared bilinear tap helper (same arithmetic as warp.hip: geometry.py:50-55,65-72)
 // ------------------------------------------------------------------------------------------------
@@ -401,13 +403,42 @@ __device__ __forceinline__ void store_rowmajor_tile(float (*S)[GT], int tid, con
         *reinterpret_cast<floatx4*>(&S[(tid >> 5) + 8 * i][(tid & 31) * 4]) = src[i];
 }
 
+// This lane's 64 target values in accumulator order, fetched during the K loop so that the strided
+// target read (128-byte segments, one tile row apart) overlaps the MFMAs instead of stalling the epilogue
+// (measured: 0.4 of 1.2 ms at hw=4096 when read in place).  Half MI=0 is issued at the top of the
+// kernel, half MI=1 before the last K chunk, where it reuses the staging registers: 64 more live
+// registers would drop the kernel to one block per CU.
+struct TilePre {
+    float v[2][2][16];
+};
+
+template <int MI>
+__device__ __forceinline__ void tile_prefetch(TilePre& t, const float* __restrict__ target, int b, int ti, int tj,
+                                              int hw, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    constexpr int mi = MI;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        {
+            const int col = tj * GT + wn * 64 + ni * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = ti * GT + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                t.v[mi][ni][r] = (row < hw && col < hw) ? target[((int64_t)b * hw + row) * hw + col] : 0.f;
+            }
+        }
+    }
+}
+
 // Epilogue shared by the fp32 and the fp16-split Gram kernels: MODE 0 writes sign(G - T) (and, for an
 // off-diagonal tile, the transposed tile to the mirror position, staged through `tr` = >= 18 KB of LDS
 // that is free once the main loop is done); MODE 1 writes G.
-template <int MODE>
+template <int MODE, bool PRE>
 __device__ __forceinline__ void gram_epilogue(const GemmAcc& acc, int8_t* tr, const float* __restrict__ target,
                                               int8_t* __restrict__ sgn_out, float* __restrict__ g_out,
-                                              float* __restrict__ loss, int b, int ti, int tj, int hw, int tid) {
+                                              float* __restrict__ loss, int b, int ti, int tj, int hw, int tid, const TilePre& pre) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int p0 = ti * GT, q0 = tj * GT;
@@ -415,6 +446,7 @@ __device__ __forceinline__ void gram_epilogue(const GemmAcc& acc, int8_t* tr, co
     const bool mirror = (MODE == 0) && (ti != tj);
     constexpr int TRS = GT + 16;
     float lsum = 0.f;
+    int8_t sg[2][2][16];  // this lane's 64 signs (kept for the mirrored tile)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -425,37 +457,56 @@ __device__ __forceinline__ void gram_epilogue(const GemmAcc& acc, int8_t* tr, co
             for (int r = 0; r < 16; ++r) {
                 const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int row = p0 + rl;
+                int8_t v8 = 0;
                 if (row < hw && col < hw) {
                     const int64_t o = ((int64_t)b * hw + row) * hw + col;
                     const float gval = acc.a[mi][ni][r];
                     if (MODE == 0) {
-                        const float d = gval - target[o];
-                        const int8_t sg = (int8_t)sgn(d);
-                        sgn_out[o] = sg;
-                        if (mirror) tr[cl * TRS + rl] = sg;
+                        const float d = gval - (PRE ? pre.v[mi][ni][r] : target[o]);
+                        v8 = (int8_t)sgn(d);
                         lsum += fabsf(d);
                     } else {
                         g_out[o] = gval;
                     }
                 }
+                sg[mi][ni][r] = v8;
+                if (MODE == 0) tr[rl * TRS + cl] = v8;  // sign tile staged in LDS: rows leave as 16-byte stores
             }
         }
-    if (mirror) {
-        __syncthreads();
-        // rows of the mirror tile = columns of this one; 128 bytes per row, 16 bytes per thread and step
-        const bool v16 = (hw % 16 == 0);
-        for (int i = tid; i < GT * (GT / 16); i += 256) {
-            const int cl = i / (GT / 16), ch = i % (GT / 16);
-            const int grow = q0 + cl, gcol = p0 + ch * 16;
-            if (grow >= hw) continue;
-            int8_t* dst = sgn_out + ((int64_t)b * hw + grow) * hw + gcol;
-            const int8_t* src = tr + cl * TRS + ch * 16;
-            if (v16 && gcol + 15 < hw) {
-                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
-            } else {
-                for (int e = 0; e < 16; ++e)
-                    if (gcol + e < hw) dst[e] = src[e];
+    if (MODE == 0) {
+        // write one orientation of the staged tile: LDS row i -> global row (r0 + i), columns c0 ..
+        auto flush = [&](int r0, int c0) {
+            __syncthreads();
+            const bool v16 = (hw % 16 == 0);
+            for (int i = tid; i < GT * (GT / 16); i += 256) {
+                const int rl = i / (GT / 16), ch = i % (GT / 16);
+                const int grow = r0 + rl, gcol = c0 + ch * 16;
+                if (grow >= hw) continue;
+                int8_t* dst = sgn_out + ((int64_t)b * hw + grow) * hw + gcol;
+                const int8_t* src = tr + rl * TRS + ch * 16;
+                if (v16 && gcol + 15 < hw) {
+                    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+                } else {
+                    for (int e = 0; e < 16; ++e)
+                        if (gcol + e < hw) dst[e] = src[e];
+                }
             }
+        };
+        flush(p0, q0);
+        if (mirror) {
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int cl = wn * 64 + ni * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        tr[cl * TRS + rl] = sg[mi][ni][r];
+                    }
+                }
+            flush(q0, p0);
         }
     }
     if (MODE == 0 && loss) {
@@ -523,8 +574,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ vt,
         __syncthreads();
     }
 
-    gram_epilogue<MODE>(acc, reinterpret_cast<int8_t*>(&As[0][0][0]), target, sgn_out, g_out, loss, b, ti, tj, hw,
-                        tid);
+    TilePre none;
+    gram_epilogue<MODE, false>(acc, reinterpret_cast<int8_t*>(&As[0][0][0]), target, sgn_out, g_out, loss, b, ti, tj,
+                               hw, tid, none);
 }
 
 // dV^T[c][p] = alpha * sum_q V^T[c][q] * S[q][p]   (S symmetric sign matrix, int8)
@@ -625,6 +677,132 @@ __global__ __launch_bounds__(256) void sv_kernel(const float* __restrict__ vt,
                 if (row < C && col < hw) dvt[((int64_t)b * C + row) * hw + col] = acc.a[mi][ni][r] * alpha;
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16-split Gram step:  G = Vh Vh^T + Vh Vl^T + Vl Vh^T  (the Vl Vl^T term is < 2^-22) on
+// v_mfma_f32_32x32x16_f16 -- 3/16 of the matrix-pipe time of gram_kernel at fp32-class accuracy (every
+// product is exact in the fp32 accumulator; |V| <= 1, so Vh + Vl carries V to an absolute 2^-25).
+// Both MFMA operands need a pixel's 8 consecutive channels, i.e. V pixel-major: vsplit_t_kernel writes
+// Vp = Vph + Vpl as (B, hw, C) halfs (64 x 64 tiles transposed through LDS), gram16_kernel stages 128-pixel x
+// 32-channel tiles of the four operands in ONE LDS stage (40 KB -> 4 workgroups per CU; the next chunk
+// waits in registers), rows of 64 B + 16 B pad (conflict-free ds_read_b128).
+// Upper-triangular tiles + mirrored sign tile (gram_epilogue<0>).  Requires C % 8 == 0.
+// ------------------------------------------------------------------------------------------------
+// grid (ceil(hw/64), ceil(C/64), B), 256 threads
+__global__ __launch_bounds__(256) void vsplit_t_kernel(const float* __restrict__ vt, half_t* __restrict__ vph,
+                                                        half_t* __restrict__ vpl, int C, int hw) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const float* src = vt + (int64_t)b * C * hw;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        tile[c][p] = (c0 + c < C && p0 + p < hw) ? src[(int64_t)(c0 + c) * hw + p0 + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int p = i >> 6, c = i & 63;
+        if (p0 + p < hw && c0 + c < C) {
+            const float val = tile[c][p];
+            const half_t hi16 = (half_t)val;
+            const int64_t o = ((int64_t)b * hw + p0 + p) * C + c0 + c;
+            vph[o] = hi16;
+            vpl[o] = (half_t)(val - (float)hi16);
+        }
+    }
+}
+
+constexpr int GK16 = 32;              // K chunk (channels): 64-byte row segments
+constexpr int GROW = GK16 * 2 + 16;   // LDS bytes per tile row (80: odd multiple of 16)
+
+// grid (nt*(nt+1)/2, 1, B)
+__global__ __launch_bounds__(256) void gram16_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
+                                                      const float* __restrict__ target,
+                                                      int8_t* __restrict__ sgn_out, float* __restrict__ loss,
+                                                      int C, int hw) {
+    __shared__ __attribute__((aligned(16))) char lds[4][GT * GROW];  // [Ah, Al, Bh, Bl][pixel row]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z;
+    int ti, tj;
+    tri_tile(blockIdx.x, (hw + GT - 1) / GT, ti, tj);
+    const int p0 = ti * GT, q0 = tj * GT;
+    const half_t* hb = vph + (int64_t)b * hw * C;
+    const half_t* lb = vpl + (int64_t)b * hw * C;
+    TilePre pre;
+    tile_prefetch<0>(pre, target, b, ti, tj, hw, tid);
+
+    // staging: 4 arrays x 128 rows x 4 chunks of 8 halfs = 2 chunks per thread and array (native vector
+    // type: arrays of HIP's uint4 struct are not promoted to registers).  A second register set (two K
+    // chunks in flight) was measured: no gain.
+    u32x4 rgA[2][4];
+    auto load = [&](int k0, u32x4 (&rg)[2][4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + i * 256;
+            const int srow = ch >> 2, skc = ch & 3;
+            const int k = k0 + skc * 8;
+            const int pa = p0 + srow, pb = q0 + srow;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            const bool ka = k < C;
+            rg[i][0] = (ka && pa < hw) ? *reinterpret_cast<const u32x4*>(hb + (int64_t)pa * C + k) : z;
+            rg[i][1] = (ka && pa < hw) ? *reinterpret_cast<const u32x4*>(lb + (int64_t)pa * C + k) : z;
+            rg[i][2] = (ka && pb < hw) ? *reinterpret_cast<const u32x4*>(hb + (int64_t)pb * C + k) : z;
+            rg[i][3] = (ka && pb < hw) ? *reinterpret_cast<const u32x4*>(lb + (int64_t)pb * C + k) : z;
+        }
+    };
+    auto store = [&](const u32x4 (&rg)[2][4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + i * 256;
+            const int srow = ch >> 2, skc = ch & 3;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) *reinterpret_cast<u32x4*>(&lds[a][srow * GROW + skc * 16]) = rg[i][a];
+        }
+    };
+
+    GemmAcc acc;
+    gemm_zero(acc);
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < GK16 / 16; ++ks) {
+            half8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oa = (wm * 64 + i * 32 + l31) * GROW + ks * 32 + hi * 16;
+                const int ob = (wn * 64 + i * 32 + l31) * GROW + ks * 32 + hi * 16;
+                ah[i] = *reinterpret_cast<const half8_t*>(&lds[0][oa]);
+                al[i] = *reinterpret_cast<const half8_t*>(&lds[1][oa]);
+                bh[i] = *reinterpret_cast<const half8_t*>(&lds[2][ob]);
+                bl[i] = *reinterpret_cast<const half8_t*>(&lds[3][ob]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc.a[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc.a[i][j], 0, 0, 0);
+                    acc.a[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc.a[i][j], 0, 0, 0);
+                    acc.a[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc.a[i][j], 0, 0, 0);
+                }
+        }
+    };
+    const int nk = (C + GK16 - 1) / GK16;
+    load(0, rgA);
+    for (int kc = 0; kc + 1 < nk; ++kc) {
+        store(rgA);  // the previous chunk's LDS reads are behind the barrier that ended the last iteration
+        __syncthreads();
+        load((kc + 1) * GK16, rgA);
+        compute();
+        __syncthreads();
+    }
+    store(rgA);
+    __syncthreads();
+    tile_prefetch<1>(pre, target, b, ti, tj, hw, tid);
+    compute();
+    __syncthreads();
+    gram_epilogue<0, true>(acc, reinterpret_cast<int8_t*>(&lds[0][0]), target, sgn_out, (float*)nullptr, loss, b, ti,
+                           tj, hw, tid, pre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -794,7 +972,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
 // ------------------------------------------------------------------------------------------------
 struct OptWs {
     float *grad, *m, *v, *vt, *dvt, *nrm, *wgt, *part;
-    half_t *vh, *vl;
+    half_t *vh, *vl, *vph, *vpl;
     int8_t *sgn1, *sgn2, *ssign;
     int *rowptr, *cursor, *src;
 };
@@ -823,6 +1001,8 @@ static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int 
     tmp.part = has_s ? carve<float>(p, B * 32 * hw) : nullptr;
     tmp.vh = has_s ? carve<half_t>(p, E) : nullptr;
     tmp.vl = has_s ? carve<half_t>(p, E) : nullptr;
+    tmp.vph = has_s ? carve<half_t>(p, E) : nullptr;
+    tmp.vpl = has_s ? carve<half_t>(p, E) : nullptr;
     tmp.ssign = has_s ? carve<int8_t>(p, B * hw * hw) : nullptr;
     if (w) *w = tmp;
     return (size_t)(p - basep);
@@ -875,10 +1055,14 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         const int nt = (hw + GT - 1) / GT;
         {
             ProfScope ps(FRESCO_PROF_OPT_GRAM, B, C, hw, 0, st);
-            // (an fp16-split form of this step, Vph Vph^T + Vph Vpl^T + Vpl Vph^T on pixel-major copies, was
-            // built and measured in round 1: 3.1 ms vs 1.74 ms here -- latency-bound at one block per CU)
-            hipLaunchKernelGGL((gram_kernel<0>), dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vt, target,
-                               w.ssign, (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
+            if (f16_sv && C % 8 == 0) {
+                hipLaunchKernelGGL(vsplit_t_kernel, dim3((hw + 63) / 64, (C + 63) / 64, B), dim3(256), 0, st, w.vt,
+                                   w.vph, w.vpl, C, hw);
+                hipLaunchKernelGGL(gram16_kernel, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vph, w.vpl, target,
+                                   w.ssign, loss ? loss + 1 : nullptr, C, hw);
+            } else
+                hipLaunchKernelGGL((gram_kernel<0>), dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vt, target,
+                                   w.ssign, (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
         }
         const float coef = intra_weight / ((float)Bg * (float)hw * (float)hw);
         {
