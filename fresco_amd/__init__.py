@@ -13,11 +13,14 @@ from .warp import Dilate, adaptive_instance_normalization, flow_warp, warp_tenso
 from .hook import apply_FRESCO_opt, disable_FRESCO_opt, patch_reference
 from .mapping import cross_frame_masks, get_mapping_ind, get_single_mapping_ind
 from .step import predict_x0, step
+from .paras import (correlation_matrices, forward_backward_consistency_check, get_flow_and_interframe_paras,
+                    get_intraframe_paras, interframe_paras_from_flows)
 
 __all__ = [
     "AttentionControl", "FRESCOAttnProcessor2_0", "apply_FRESCO_attn", "optimize_feature",
     "warp_tensor", "flow_warp", "adaptive_instance_normalization", "Dilate", "apply_FRESCO_opt",
     "disable_FRESCO_opt", "patch_reference", "get_mapping_ind", "get_single_mapping_ind", "cross_frame_masks",
-    "step", "predict_x0",
+    "step", "predict_x0", "get_flow_and_interframe_paras", "get_intraframe_paras", "interframe_paras_from_flows",
+    "forward_backward_consistency_check", "correlation_matrices",
     "FrescoHipError", "LIB_PATH",
 ]

@@ -188,6 +188,49 @@ __global__ __launch_bounds__(256) void adain_kernel(const T* __restrict__ conten
         op[i] = (T)((((float)cp[i] - mean_c) / std_c) * std_s + mean_s);
 }
 
+// forward_backward_consistency_check (geometry.py:75-96) + the colour-difference refinement of
+// get_flow_and_interframe_paras (diffusion_hacked.py:919-926), one thread per (pair, pixel):
+//   occ_f = |fwd + warp(bwd, fwd)| > alpha (|fwd| + |bwd|) + beta   [OR  mean_c |img_n - warp(img_n+1, fwd)| > thr]
+//   occ_b = |bwd + warp(fwd, bwd)| > ...                            [OR  mean_c |img_n+1 - warp(img_n, bwd)| > thr]
+// Pair n couples frame n with frame (n+1) mod N.  The two tap sets are shared by the flow and the colour
+// samples.  grid (ceil(hw/256), N)
+__global__ __launch_bounds__(256) void flow_occlusion_kernel(const float* __restrict__ images,
+                                                             const float* __restrict__ fwd,
+                                                             const float* __restrict__ bwd,
+                                                             float* __restrict__ fwd_occ, float* __restrict__ bwd_occ,
+                                                             int N, int C, int h, int w, float alpha, float beta,
+                                                             float color_thr) {
+    const int hw = h * w;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (p >= hw) return;
+    const int y = p / w, x = p - y * w;
+    const float* f = fwd + (int64_t)n * 2 * hw;
+    const float* b = bwd + (int64_t)n * 2 * hw;
+    const float fx = f[p], fy = f[hw + p], bx = b[p], by = b[hw + p];
+    const float mag = sqrtf(fx * fx + fy * fy) + sqrtf(bx * bx + by * by);
+    const float thr = alpha * mag + beta;
+    const Taps tf = make_taps(fx, fy, x, y, h, w);
+    const Taps tb = make_taps(bx, by, x, y, h, w);
+    const float dfx = fx + sample(b, tf), dfy = fy + sample(b + hw, tf);
+    const float dbx = bx + sample(f, tb), dby = by + sample(f + hw, tb);
+    bool of = sqrtf(dfx * dfx + dfy * dfy) > thr;
+    bool ob = sqrtf(dbx * dbx + dby * dby) > thr;
+    if (images) {
+        const float* cur = images + (int64_t)n * C * hw;
+        const float* nxt = images + (int64_t)((n + 1) % N) * C * hw;
+        float sf = 0.f, sb = 0.f;
+        for (int c = 0; c < C; ++c) {
+            sb += fabsf(nxt[(int64_t)c * hw + p] - sample(cur + (int64_t)c * hw, tb));
+            sf += fabsf(cur[(int64_t)c * hw + p] - sample(nxt + (int64_t)c * hw, tf));
+        }
+        of = of || (sf / (float)C > color_thr);
+        ob = ob || (sb / (float)C > color_thr);
+    }
+    fwd_occ[(int64_t)n * hw + p] = of ? 1.f : 0.f;
+    bwd_occ[(int64_t)n * hw + p] = ob ? 1.f : 0.f;
+}
+
 }  // namespace fresco
 
 using namespace fresco;
@@ -338,5 +381,17 @@ extern "C" int fresco_ddpm_prev(const void* x0, const void* xt, const void* nois
                            (const float*)noise, (float*)out, n, noise_period, c_x0, c_xt, sigma);
     else
         return FRESCO_EUNSUPPORTED;
+    return check_launch();
+}
+
+extern "C" int fresco_flow_occlusion(const float* images, const float* fwd_flow, const float* bwd_flow,
+                                     float* fwd_occ, float* bwd_occ, int N, int C, int H, int W, float alpha,
+                                     float beta, float color_thr, void* stream) {
+    if (!fwd_flow || !bwd_flow || !fwd_occ || !bwd_occ || N <= 0 || H <= 0 || W <= 0) return FRESCO_EINVAL;
+    if (images && C <= 0) return FRESCO_EINVAL;
+    if ((int64_t)H * W > (1 << 30) || N > 65535) return FRESCO_EUNSUPPORTED;
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(flow_occlusion_kernel, grid, dim3(256), 0, as_stream(stream), images, fwd_flow, bwd_flow,
+                       fwd_occ, bwd_occ, N, C, H, W, alpha, beta, color_thr);
     return check_launch();
 }

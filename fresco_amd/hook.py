@@ -145,4 +145,12 @@ def patch_reference(dh=None, pf=None, fu=None):
     if dh is not None:
         from . import mapping
 
+        from . import paras
+
         dh.get_mapping_ind = mapping.get_mapping_ind  # looked up by get_flow_and_interframe_paras (:943)
+        dh.forward_backward_consistency_check = paras.forward_backward_consistency_check  # (:917)
+        # run_fresco.py:20 binds these two by `from ... import` before anyone can patch, so a caller that
+        # wants them replaced imports them from fresco_amd; rebinding covers webUI-style
+        # late lookups through the module
+        dh.get_flow_and_interframe_paras = paras.get_flow_and_interframe_paras
+        dh.get_intraframe_paras = paras.get_intraframe_paras

@@ -237,6 +237,28 @@ def dilate(x, k):
     return out
 
 
+def flow_occlusion(fwd_flow, bwd_flow, images=None, alpha=0.01, beta=0.5, color_thr=255 * 0.25):
+    """(fwd_occ, bwd_occ) fp32 (N,H,W) for the frame pairs (n, n+1 mod N); images (N,C,H,W) in 0..255 adds
+    the colour-difference test, None = forward_backward_consistency_check alone."""
+    _need_gpu(fwd_flow)
+    fwd_flow, bwd_flow = _f32c(fwd_flow), _f32c(bwd_flow)
+    N, two, H, W = fwd_flow.shape
+    if two != 2 or bwd_flow.shape != fwd_flow.shape:
+        raise ValueError("flows must be (N,2,H,W) and of equal shape")
+    C, ip = 0, None
+    if images is not None:
+        images = _f32c(images)
+        if images.shape[0] != N or tuple(images.shape[2:]) != (H, W):
+            raise ValueError("images must be (N,C,H,W) matching the flows")
+        C, ip = images.shape[1], images.data_ptr()
+    fo = torch.empty(N, H, W, dtype=torch.float32, device=fwd_flow.device)
+    bo = torch.empty_like(fo)
+    rc = _lib.load().fresco_flow_occlusion(ip, fwd_flow.data_ptr(), bwd_flow.data_ptr(), fo.data_ptr(), bo.data_ptr(),
+                                           N, C, H, W, alpha, beta, color_thr, _stream())
+    _lib.check(rc, "fresco_flow_occlusion")
+    return fo, bo
+
+
 def warp_fuse_chain(lat, bwd_flow, fwd_flow, bwd_occ, fwd_occ, sal, warp_sal, warp_sal_last, chunk):
     """In-place frame chain of warp_tensor on lat (chunk*N, C, h, w) fp32 contiguous."""
     _need_gpu(lat)

@@ -151,6 +151,17 @@ int fresco_resize_bilinear(const float* x, float* out, int BC, int H, int W, int
 /* F.max_pool2d(x, kernel_size=k) (stride k, floor) on (BC,H,W) fp32 -> (BC,H/k,W/k)  (FU:27,31; DH:440,442) */
 int fresco_max_pool(const float* x, float* out, int BC, int H, int W, int k, void* stream);
 
+/* forward_backward_consistency_check (gmflow/geometry.py:75-96) fused with the colour-difference
+ * occlusion refinement of get_flow_and_interframe_paras (DH:919-926).  Pair n couples frame n with frame
+ * (n+1) mod N: fwd_flow[n] maps frame n onto n+1, bwd_flow[n] the reverse; all fp32.
+ *   fwd_occ[n] = |fwd + warp(bwd, fwd)| > alpha*(|fwd|+|bwd|) + beta  OR  mean_c |img[n]   - warp(img[n+1], fwd)| > color_thr
+ *   bwd_occ[n] = |bwd + warp(fwd, bwd)| > alpha*(|fwd|+|bwd|) + beta  OR  mean_c |img[n+1] - warp(img[n],   bwd)| > color_thr
+ *   images (N,C,H,W) in 0..255 or NULL (consistency check only); flows (N,2,H,W); occs (N,H,W) in {0,1}.
+ *   Reference constants: alpha 0.01, beta 0.5, color_thr 255*0.25. */
+int fresco_flow_occlusion(const float* images, const float* fwd_flow, const float* bwd_flow, float* fwd_occ,
+                          float* bwd_occ, int N, int C, int H, int W, float alpha, float beta, float color_thr,
+                          void* stream);
+
 /* Dilate (UT:81-93): replicate pad (k-1)/2, k x k box sum, clamp [0,1]; (BC,H,W) fp32, k odd */
 int fresco_dilate(const float* x, float* out, int BC, int H, int W, int k, void* stream);
 

@@ -547,3 +547,49 @@ def mapping_ind(bwd_flows, bwd_occs, imgs, scale=1.0):
         fwd.append(m[fwd[-1]])
         bwd.append(torch.sort(fwd[-1])[1])
     return torch.stack(fwd, 0).unsqueeze(1), torch.stack(bwd, 0).unsqueeze(1), tmask.unsqueeze(1)
+
+
+# --------------------------------------------------------------------------------------------
+# flows -> occlusions -> attention parameters (the part of get_flow_and_interframe_paras after the
+# flow network; diffusion_hacked.py:914-957, gmflow/geometry.py:75-96)
+# --------------------------------------------------------------------------------------------
+
+
+def fb_consistency_check(fwd_flow, bwd_flow, alpha=0.01, beta=0.5):
+    """geometry.py:75-96: a pixel is occluded when the round trip fwd + bwd(warped) does not close to
+    within alpha*(|fwd| + |bwd|) + beta.  Returns (fwd_occ, bwd_occ), float {0,1}, (B,H,W)."""
+    mag = fwd_flow.square().sum(1).sqrt() + bwd_flow.square().sum(1).sqrt()
+    diff_f = (fwd_flow + flow_warp(bwd_flow, fwd_flow)).square().sum(1).sqrt()
+    diff_b = (bwd_flow + flow_warp(fwd_flow, bwd_flow)).square().sum(1).sqrt()
+    thr = alpha * mag + beta
+    return (diff_f > thr).to(fwd_flow.dtype), (diff_b > thr).to(fwd_flow.dtype)
+
+
+def flow_occlusions(images, fwd_flows, bwd_flows, color_thr=255 * 0.25):
+    """diffusion_hacked.py:919-926.  images (N,3,H,W) in 0..255; flows of the pairs (i, i+1 mod N).
+    fb-consistency occlusion OR mean absolute colour difference between a frame and its neighbour
+    warped onto it above `color_thr`."""
+    N = images.shape[0]
+    nxt = list(range(1, N)) + [0]
+    fwd_occ, bwd_occ = fb_consistency_check(fwd_flows, bwd_flows)
+    w1 = flow_warp(images, bwd_flows)
+    bwd_occ = torch.clamp(bwd_occ + ((images[nxt] - w1).abs().mean(1) > color_thr).to(bwd_occ.dtype), 0, 1)
+    w2 = flow_warp(images[nxt], fwd_flows)
+    fwd_occ = torch.clamp(fwd_occ + ((images - w2).abs().mean(1) > color_thr).to(fwd_occ.dtype), 0, 1)
+    return fwd_occ, bwd_occ
+
+
+def interframe_paras(images, fwd_flows, bwd_flows):
+    """Everything get_flow_and_interframe_paras derives from the predicted flows (914-953).
+    images (N,3,H,W) float in 0..255.  Returns ([fwd,bwd] flows, [fwd,bwd] occs, attn_mask (3 scales),
+    dict(fwd_mappings, bwd_mappings, interattn_masks) at scales 8 and 16)."""
+    fwd_occ, bwd_occ = flow_occlusions(images, fwd_flows, bwd_flows)
+    imgs_torch = images / 255.0 * 2.0 - 1.0  # utils.py:9
+    masks = cross_frame_masks(bwd_occ)
+    paras = dict(fwd_mappings=[], bwd_mappings=[], interattn_masks=[])
+    for scale in (8.0, 16.0):
+        f, b, m = mapping_ind(bwd_flows, bwd_occ, imgs_torch, scale)
+        paras["fwd_mappings"].append(f)
+        paras["bwd_mappings"].append(b)
+        paras["interattn_masks"].append(m)
+    return [fwd_flows, bwd_flows], [fwd_occ, bwd_occ], masks, paras

@@ -18,3 +18,9 @@ def golden():
     import numpy as np
     path = os.path.join(ROOT, "tests", "golden", "reference_outputs.npz")
     return dict(np.load(path))
+
+
+@pytest.fixture(scope="session")
+def paras_golden():
+    import numpy as np
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "paras_golden.npz")))

@@ -65,3 +65,12 @@ def attn_hidden(B, HW, C, phase=0.0):
 def checksum(t):
     t = t.double()
     return float(t.sum()), float(t.abs().sum())
+
+
+def video_case(N, H, W):
+    """uint8 HxWx3 frames (as cv2 hands them to get_flow_and_interframe_paras) + closed-form flows for
+    the pairs (i -> i+1 mod N).  Returns (list of numpy frames, fwd flows, bwd flows)."""
+    img = feat(N, 3, H, W, 0.5).double()
+    u8 = torch.round((img * 0.5 + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
+    frames = [u8[i].permute(1, 2, 0).contiguous().numpy() for i in range(N)]
+    return frames, flow(N, H, W, +1.0), flow(N, H, W, -1.0)
