@@ -37,10 +37,15 @@ struct AttnCfg {
     static constexpr int VTILE = (DPV * VROW + 1023) / 1024 * 1024;  // rounded up: whole 1 KiB DMA pieces
     static constexpr int KDMA = KTILE / 1024;                        // wave-level DMA instructions per tile
     static constexpr int VDMA = VTILE / 1024;
-    static constexpr int LDS_BYTES = 2 * (KTILE + VTILE);
+    static constexpr int NP = KDMA + VDMA;      // 1 KiB DMA pieces per tile
+    static constexpr int PW = (NP + 3) / 4;     // pieces per wave and tile (the last ones may be pad pieces)
+    static constexpr int BUFB = PW * 4 * 1024;  // LDS bytes per buffer: K tile, V^T tile, pad pieces
+    static constexpr int LDS_BYTES = 2 * BUFB;
     static constexpr int KCH = 64 * NKC;  // 16-byte chunks in a K tile
     static constexpr int VCH = DPV * 8;   // 16-byte chunks in a V^T tile
     static constexpr bool ONES = DPV > D;  // spare V^T row D holds ones: the PV MFMA also yields the row sum
+    static constexpr bool MCOL = DPK > D;  // spare K column D holds ones: Q column D carries -m_run, so the
+                                           // QK MFMA subtracts the running max (no C operand to keep around)
     static constexpr int KPT = (KCH + 255) / 256;
     static constexpr int VPT = (VCH + 255) / 256;
 };
@@ -58,6 +63,8 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 // online softmax: skip the O rescale while the tile max grows by less than this (log2 units);
 // P then reaches at most 2^8 = 256, far inside fp16 range, and stays exactly normalised by the row sum
 #define RESCALE_THR 8.0f
+// no running max at all when |c q| max|k| - m_run stays below this (P <= 2^14 = 16384 < 65504)
+#define NOMAX_THR 14.0f
 
 static inline int mpad_of(int M) { return (M + 63) / 64 * 64; }
 
@@ -69,8 +76,8 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
                                                        const half_t* __restrict__ v,
                                                        const int32_t* __restrict__ kv_rows,
                                                        half_t* __restrict__ kp, half_t* __restrict__ vt,
-                                                       int H, int M, int Mpad, int64_t group_rows,
-                                                       int64_t kv_ld) {
+                                                       float* __restrict__ ktmax, int H, int M, int Mpad,
+                                                       int64_t group_rows, int64_t kv_ld) {
     using Cfg = AttnCfg<D>;
     const int tile = blockIdx.x, h = blockIdx.y, g = blockIdx.z;
     __shared__ int32_t rows[64];
@@ -93,7 +100,35 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
         const int32_t r = rows[row];
         if (r >= 0 && dc * 8 < D)
             val = *reinterpret_cast<const uint4*>(k + ((int64_t)g * group_rows + r) * kv_ld + h * D + dc * 8);
+        else if (Cfg::MCOL && r >= 0 && dc * 8 == D)
+            val.x = 0x3C00u;  // K[key][D] = 1.0: with Q[query][D] = -m the QK MFMA delivers  q.k - m
         *reinterpret_cast<uint4*>(kdst + (int64_t)c * 8) = val;
+    }
+    // largest squared key norm of the tile (one thread per key, fixed summation order): the flash kernel
+    // bounds every logit of a query by |q| max|k| (Cauchy-Schwarz) and drops the running-max search when
+    // that bound cannot leave fp16 range
+    {
+        // four threads per key, each a fixed subset of the 16-byte chunks; combined in a fixed order
+        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+        const int32_t r = rows[row];
+        float n2 = 0.f;
+        if (r >= 0) {
+            const half_t* kr = k + ((int64_t)g * group_rows + r) * kv_ld + h * D;
+            for (int dc = part; dc < D / 8; dc += 4) {
+                const half8_t kk = *reinterpret_cast<const half8_t*>(kr + dc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) n2 = fmaf((float)kk[e], (float)kk[e], n2);
+            }
+        }
+        n2 += __shfl_xor(n2, 1, 64);
+        n2 += __shfl_xor(n2, 2, 64);
+#pragma unroll
+        for (int off = 32; off >= 4; off >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, off, 64));
+        __shared__ float wmax[4];
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = n2;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            ktmax[(int64_t)(g * H + h) * (Mpad / 64) + tile] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     }
     // V: stage the 64 x D slab, then write it transposed
     for (int c = threadIdx.x; c < 64 * (D / 8); c += 256) {
@@ -133,6 +168,7 @@ template <int D, int QB, int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __restrict__ q,
                                                           const half_t* __restrict__ kp,
                                                           const half_t* __restrict__ vt,
+                                                          const float* __restrict__ ktmax,
                                                           half_t* __restrict__ out, int B, int H, int Lq,
                                                           int M, int Mpad, int batch_per_group,
                                                           float scale_log2, float diag_bias_log2, int64_t q_ld) {
@@ -174,48 +210,73 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
         }
     }
 
+    // Cauchy-Schwarz bound on this lane's query: every exponent argument c*q.k is <= |c q| max|k|
+    float qbound[QB];
+    {
+        const int nTk = Mpad / 64;
+        const float* km = ktmax + (int64_t)(g * H + h) * nTk;
+        float k2 = 0.f;
+        for (int i = lane; i < nTk; i += 64) k2 = fmaxf(k2, km[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, off, 64));
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            float q2 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < Cfg::NKS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q2 = fmaf((float)qf[j][ks][e], (float)qf[j][ks][e], q2);
+            q2 += __shfl_xor(q2, 32, 64);
+            qbound[j] = sqrtf(q2 * k2) * 1.001f + 1e-3f;
+        }
+    }
+
     const char* kg = reinterpret_cast<const char*>(kp + (int64_t)(g * H + h) * Mpad * Cfg::DPK);
     const char* vg = reinterpret_cast<const char*>(vt + (int64_t)(g * H + h) * Cfg::DPV * Mpad);
     const int nT = Mpad / 64;
 
     // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4), no register round trip ---------
     // One wave-level instruction fills 1 KiB of LDS: destination = wave-uniform base + lane * 16, the
-    // source address is per lane.  The padded row layout is kept by pointing the pad chunk's lane at a
-    // dummy (valid) source.  Piece i of a tile is issued by wave i % 4.
-    auto stage_tile = [&](int t, int buf) {
-        char* kb = smem + buf * (Cfg::KTILE + Cfg::VTILE);
-        char* vb = kb + Cfg::KTILE;
-        const char* ksrc = kg + (int64_t)t * Cfg::KCH * 16;
+    // source address is per lane.  The K tile and the V^T tile are contiguous in LDS and both whole
+    // KiB, so a tile is NP pieces (rounded up to 4 per round); piece p = i*4 + wave is issued by wave p % 4.  Everything that does
+    // not change from tile to tile is computed once: a per-lane byte offset inside the packed image
+    // (the pad chunks of the LDS row layout point at a valid dummy source) and a wave-uniform running
+    // base that advances by one tile per issue -- the loop body carries scalar adds and the DMA
+    // instructions only (no per-tile address VALU, no exec-mask branches).
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    uint64_t dma_addr[Cfg::PW];  // this lane's source address of piece i*4 + wave in the next tile to stage
+    int dma_step[Cfg::PW];       // bytes per tile (wave-uniform): K rows are tile-contiguous, V^T advances 64 keys
 #pragma unroll
-        for (int i = 0; i < (Cfg::KDMA + 3) / 4; ++i) {
-            const int piece = i * 4 + wave;
-            if (piece < Cfg::KDMA) {
-                const int c = piece * 64 + lane;  // linear 16-byte chunk of the LDS tile
-                const int row = c / Cfg::KCR, dc = c % Cfg::KCR;
-                const char* src = ksrc + (dc < Cfg::NKC ? (row * Cfg::NKC + dc) * 16 : 0);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src),
-                    (__attribute__((address_space(3))) void*)(kb + piece * 1024), 16, 0, 0);
-            }
-        }
+    for (int i = 0; i < Cfg::PW; ++i) {
+        const int p = i * 4 + wave_s;
+        const bool isk = p < Cfg::KDMA;
+        const int ck = p * 64 + lane;  // linear 16-byte chunk of the LDS K tile
+        const int krw = ck / Cfg::KCR, kdc = ck % Cfg::KCR;
+        const uint32_t koff = kdc < Cfg::NKC ? (uint32_t)(krw * Cfg::NKC + kdc) * 16u : 0u;
+        const int cv = (p - Cfg::KDMA) * 64 + lane;
+        const int vd = cv / Cfg::VCR, vkc = cv % Cfg::VCR;
+        // pieces past the tile (p >= NP, when NP is not a multiple of 4) re-read chunk 0 into the pad KiBs
+        const uint32_t voff = (vd < Cfg::DPV && vkc < 8) ? (uint32_t)(vd * Mpad + vkc * 8) * 2u : 0u;
+        dma_addr[i] = reinterpret_cast<uint64_t>(isk ? kg : vg) + (isk ? koff : voff);
+        dma_step[i] = isk ? Cfg::KCH * 16 : 128;
+    }
+    auto stage_next = [&](int buf) {  // issues the next not-yet-staged tile into LDS buffer `buf`
+        char* dst = smem + buf * Cfg::BUFB + wave_s * 1024;
 #pragma unroll
-        for (int i = 0; i < (Cfg::VDMA + 3) / 4; ++i) {
-            const int piece = i * 4 + wave;
-            if (piece < Cfg::VDMA) {
-                const int c = piece * 64 + lane;
-                const int d = c / Cfg::VCR, kc = c % Cfg::VCR;
-                const bool real = d < Cfg::DPV && kc < 8;
-                const char* src = vg + (real ? ((int64_t)d * Mpad + t * 64 + kc * 8) * 2 : 0);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src),
-                    (__attribute__((address_space(3))) void*)(vb + piece * 1024), 16, 0, 0);
-            }
+        for (int i = 0; i < Cfg::PW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_addr[i]),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+            dma_addr[i] += dma_step[i];
         }
     };
 
     floatx16 o[QB][Cfg::NDB];
-    floatx16 negm[QB];  // -m_run in all 16 registers: the C operand of the first QK MFMA, so that the
-                        // accumulators come out as  c*s - m_run  (no per-score subtraction)
+    // The accumulators must come out as  c*s - m_run  (no per-score subtraction).  MCOL: -m_run rides in Q's
+    // spare column D against the ones column of the packed K (m_run is kept on the fp16 grid so that the
+    // value the MFMA subtracts is exactly the one the rescale factors are computed from).  Otherwise
+    // -m_run sits in all 16 registers of `negm`, the C operand of the first QK MFMA.
+    constexpr int MKS = Cfg::MCOL ? D / 16 : 0, MHI = (D % 16) / 8, ME = D % 8;
+    floatx16 negm[QB];
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
@@ -229,27 +290,35 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
             for (int r = 0; r < 16; ++r) o[j][db][r] = 0.f;
     }
 
-    stage_tile(0, 0);
+    stage_next(0);
     __syncthreads();
 
     const bool need_diag = diag_bias_log2 != 0.f;
 
     // One 64-key tile.  FIX = true adds the per-element fix-ups (padded keys of the last tile,
     // diagonal bias); it is a separate instantiation so that the common path carries none of it.
-    auto tile = [&](int t, auto fix_c) {
+    // NOMAX = true (only after tile 0 has anchored m_run, and only when `qbound` proves that no exponent
+    // argument can exceed NOMAX_THR): the running-max search and the rescale test are dropped -- P is then
+    // at most 2^NOMAX_THR, inside fp16 range, and the row sum normalises it exactly as before.
+    auto tile = [&](int t, auto fix_c, auto nomax_c) {
         constexpr bool FIX = decltype(fix_c)::value;
+        constexpr bool NOMAX = decltype(nomax_c)::value;
         const int buf = (FRESCO_ABL == 5) ? 0 : (t & 1);
-        // every wave has left tile t-1 (barrier below), so its buffer can be refilled while tile t runs
-        if (FRESCO_ABL != 5 && t + 1 < nT) stage_tile(t + 1, buf ^ 1);
-        const char* kb = smem + buf * (Cfg::KTILE + Cfg::VTILE);
+        const char* kb = smem + buf * Cfg::BUFB;
         const char* vb = kb + Cfg::KTILE;
+#ifdef FRESCO_IGLP
+        __builtin_amdgcn_iglp_opt(FRESCO_IGLP);  // scheduling experiments (tools/ablate_attn.hip)
+#endif
 
         // ---- S^T = K Q^T : per query block two independent 32-key accumulators ------------------
         floatx16 s[QB][2];
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
-            s[j][0] = negm[j];
-            s[j][1] = negm[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[j][0][r] = Cfg::MCOL ? 0.f : negm[j][r];
+                s[j][1][r] = Cfg::MCOL ? 0.f : negm[j][r];
+            }
         }
         const char* kr = kb + krow * Cfg::KROW + hi * 16;
 #pragma unroll
@@ -273,6 +342,10 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
                 }
             }
         }
+
+        // every wave has left tile t-1 (barrier below), so its buffer can be refilled while tile t runs;
+        // issued here, the scalar adds + DMA instructions sit in the shadow of the QK MFMAs
+        if (FRESCO_ABL != 5 && t + 1 < nT) stage_next(buf ^ 1);
 
         half8_t pf[QB][4];
 #pragma unroll
@@ -300,18 +373,29 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
             // ---- online softmax, one query per lane.  s = exponent argument relative to m_run; the
             // reference point moves (and O, l are rescaled) only when the tile max exceeds it by more than
             // RESCALE_THR -- or on tile 0, which anchors it at the row's first-tile max.
-            float mt = fmaxf(s[j][0][0], s[j][1][0]);
+            float mt = 0.f;
+            if (!NOMAX) {
+                mt = fmaxf(s[j][0][0], s[j][1][0]);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[j][0][r]), s[j][1][r]);  // v_max3_f32
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            if (t == 0 || __any(mt > RESCALE_THR)) {
-                const float delta = (t == 0) ? mt : fmaxf(mt, 0.f);
+                for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[j][0][r]), s[j][1][r]);  // v_max3_f32
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            }
+            if (!NOMAX && (t == 0 || __any(mt > RESCALE_THR))) {
+                float delta = (t == 0) ? mt : fmaxf(mt, 0.f);
+                if (Cfg::MCOL) {
+                    const float m_new = (float)(half_t)(m_run[j] + delta);  // stays fp16-representable
+                    delta = m_new - m_run[j];
+                    m_run[j] = m_new;
+                    const half_t nm = (half_t)(-m_new);
+                    qf[j][MKS][ME] = (hi == MHI) ? nm : qf[j][MKS][ME];
+                } else {
+                    m_run[j] += delta;
+                }
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
-                m_run[j] += delta;
                 l_run[j] *= alpha;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    negm[j][r] = -m_run[j];
+                    if (!Cfg::MCOL) negm[j][r] = -m_run[j];
                     s[j][0][r] -= delta;
                     s[j][1][r] -= delta;
                 }
@@ -354,16 +438,33 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
         if (FRESCO_ABL != 5) __syncthreads();  // also drains this wave's DMA pieces (vmcnt) before release
     };
 
-    const std::integral_constant<bool, true> fix_on;
-    const std::integral_constant<bool, false> fix_off;
+    const std::integral_constant<bool, true> yes;
+    const std::integral_constant<bool, false> no;
     if (need_diag) {
-        for (int t = 0; t < nT; ++t) tile(t, fix_on);
-    } else {
-        for (int t = 0; t < nT - 1; ++t) tile(t, fix_off);
+        for (int t = 0; t < nT; ++t) tile(t, yes, no);
+    } else if (nT == 1) {
         if (Mpad != M)
-            tile(nT - 1, fix_on);
+            tile(0, yes, no);
         else
-            tile(nT - 1, fix_off);
+            tile(0, no, no);
+    } else {
+        tile(0, no, no);
+        bool safe = true;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) safe = safe && (qbound[j] - m_run[j] <= NOMAX_THR);
+        if (__all(safe)) {
+            for (int t = 1; t < nT - 1; ++t) tile(t, no, yes);
+            if (Mpad != M)
+                tile(nT - 1, yes, yes);
+            else
+                tile(nT - 1, no, yes);
+        } else {
+            for (int t = 1; t < nT - 1; ++t) tile(t, no, no);
+            if (Mpad != M)
+                tile(nT - 1, yes, no);
+            else
+                tile(nT - 1, no, no);
+        }
     }
 
     // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
@@ -414,7 +515,7 @@ static int attn_qb_choice(int D, int Lq) {
 template <int D, int QB, int MINW>
 static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, half_t* out, int B, int H,
                          int Lq, int M, int Mpad, int n_groups, float scale, float diag_bias, int64_t q_ld,
-                         hipStream_t st) {
+                         const float* ktmax, hipStream_t st) {
     using Cfg = AttnCfg<D>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -426,7 +527,7 @@ static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, ha
     const float log2e = 1.4426950408889634f;
     ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
     hipLaunchKernelGGL((attn_flash_kernel<D, QB, MINW>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
-                       kp, vt, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
+                       kp, vt, ktmax, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
 }
 
 // FRESCO_ATTN_OCC=lo|hi in the environment picks the launch-bounds variant (tuning only)
@@ -448,28 +549,30 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
     const int Mpad = mpad_of(M);
     half_t* kp = reinterpret_cast<half_t*>(ws);
     half_t* vt = kp + (size_t)n_groups * H * Mpad * Cfg::DPK;
+    float* ktmax = reinterpret_cast<float*>(vt + (size_t)n_groups * H * Mpad * Cfg::DPV);
     dim3 pg(Mpad / 64, H, n_groups);
     {
         ProfScope ps(FRESCO_PROF_KV_PACK, n_groups, H, M, D, st);
-        hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, H, M, Mpad,
+        hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, ktmax, H, M, Mpad,
                            group_rows, kv_ld);
     }
     // waves per SIMD the register allocator is asked to make room for (lo / hi variants)
     constexpr int LO = D <= 40 ? 3 : (D <= 80 ? 2 : 1);
     constexpr int HI = D <= 40 ? 4 : (D <= 80 ? 3 : 1);
     if (D <= 96 && attn_qb_choice(D, Lq) == 2)
-        launch_flash<D, (D <= 96 ? 2 : 1), 1>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, st);
+        launch_flash<D, (D <= 96 ? 2 : 1), 1>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, ktmax, st);
     else if (attn_occ_choice() == 2)
-        launch_flash<D, 1, HI>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, st);
+        launch_flash<D, 1, HI>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, ktmax, st);
     else
-        launch_flash<D, 1, LO>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, st);
+        launch_flash<D, 1, LO>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, ktmax, st);
     return check_launch();
 }
 
 static size_t attn_ws_bytes(int n_groups, int H, int M, int D) {
     const size_t Mpad = mpad_of(M);
     const size_t dpk = (D + 15) / 16 * 16, dpv = (D + 31) / 32 * 32;
-    return align_up((size_t)n_groups * H * Mpad * (dpk + dpv) * sizeof(half_t), 256);
+    return align_up((size_t)n_groups * H * Mpad * (dpk + dpv) * sizeof(half_t) +
+                        (size_t)n_groups * H * (Mpad / 64) * sizeof(float), 256);
 }
 
 }  // namespace fresco
