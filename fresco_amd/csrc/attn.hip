@@ -65,6 +65,8 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 #define RESCALE_THR 8.0f
 // no running max at all when |c q| max|k| - m_run stays below this (P <= 2^14 = 16384 < 65504)
 #define NOMAX_THR 14.0f
+// largest |exponent| (log2 units) for which the scale is folded into the fp16 Q
+#define FOLD_MAX 16.0f
 
 static inline int mpad_of(int M) { return (M + 63) / 64 * 64; }
 
@@ -193,25 +195,33 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
 
     // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
     half8_t qf[QB][Cfg::NKS];
+    float q2[QB];  // |q|^2 of this lane's query
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         const int qr = qrow0 + 32 * j;
         const half_t* qp = q + ((int64_t)b * Lq + (qr < Lq ? qr : Lq - 1)) * q_ld + h * D;
+        q2[j] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < Cfg::NKS; ++ks) {
             const int d0 = ks * 16 + hi * 8;
             half8_t t = {0, 0, 0, 0, 0, 0, 0, 0};
             if (d0 < D) t = *reinterpret_cast<const half8_t*>(qp + d0);
-            // the logit scale (softmax scale * log2 e) is folded into Q once per wave (one fp16 rounding of
-            // q*c, the same order as the fp16 rounding of P): the MFMA then delivers exponent arguments
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = (half_t)((float)t[e] * scale_log2);
+            for (int e = 0; e < 8; ++e) q2[j] = fmaf((float)t[e], (float)t[e], q2[j]);
             qf[j][ks] = t;
         }
+        q2[j] += __shfl_xor(q2[j], 32, 64);
     }
 
-    // Cauchy-Schwarz bound on this lane's query: every exponent argument c*q.k is <= |c q| max|k|
-    float qbound[QB];
+    // Cauchy-Schwarz: every logit of this lane's query is bounded by |q| max|k| (max|k|^2 per key tile comes
+    // from kv_pack).  Two per-wave decisions hang on it:
+    //  * FOLDED scale: the exponent scale c = softmax scale * log2 e is multiplied into Q once (one fp16
+    //    rounding of c*q) and the MFMA delivers exponent arguments directly.  That rounding perturbs an
+    //    exponent by at most 2^-12 * c|q||k|, so it is taken only while c|q||k| <= FOLD_MAX (error of the
+    //    order of P's own fp16 rounding); otherwise Q stays exact and every score is multiplied by c in fp32.
+    //  * no running-max search (NOMAX, below) when the bound cannot leave fp16 range.
+    // Accumulator units u: exponent argument = cmul * u, with (qs, cmul) = (c, 1) folded or (1, c) exact.
+    float kmax;
     {
         const int nTk = Mpad / 64;
         const float* km = ktmax + (int64_t)(g * H + h) * nTk;
@@ -219,17 +229,28 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
         for (int i = lane; i < nTk; i += 64) k2 = fmaxf(k2, km[i]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, off, 64));
+        kmax = sqrtf(k2);
+    }
+    bool fold_ok = true;
 #pragma unroll
-        for (int j = 0; j < QB; ++j) {
-            float q2 = 0.f;
+    for (int j = 0; j < QB; ++j) fold_ok = fold_ok && (scale_log2 * sqrtf(q2[j]) * kmax <= FOLD_MAX);
+    // (readfirstlane: tells the compiler the vote is wave-uniform, so the paths below are scalar branches)
+    const bool folded = __builtin_amdgcn_readfirstlane((int)__all(fold_ok)) != 0;
+    const float qs = folded ? scale_log2 : 1.f;
+    const float cmul = folded ? 1.f : scale_log2;
+    float qbound[QB];  // bound on the accumulators (units u), with a margin for the roundings above
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        qbound[j] = qs * sqrtf(q2[j]) * kmax * 1.001f + 1e-3f;
+        if (folded) {
 #pragma unroll
             for (int ks = 0; ks < Cfg::NKS; ++ks)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) q2 = fmaf((float)qf[j][ks][e], (float)qf[j][ks][e], q2);
-            q2 += __shfl_xor(q2, 32, 64);
-            qbound[j] = sqrtf(q2 * k2) * 1.001f + 1e-3f;
+                for (int e = 0; e < 8; ++e) qf[j][ks][e] = (half_t)((float)qf[j][ks][e] * scale_log2);
         }
     }
+    const float resc_thr = RESCALE_THR / cmul;  // thresholds and the diagonal bias in accumulator units
+    const float diag_u = diag_bias_log2 / cmul;
 
     const char* kg = reinterpret_cast<const char*>(kp + (int64_t)(g * H + h) * Mpad * Cfg::DPK);
     const char* vg = reinterpret_cast<const char*>(vt + (int64_t)(g * H + h) * Cfg::DPV * Mpad);
@@ -260,7 +281,7 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
         dma_addr[i] = reinterpret_cast<uint64_t>(isk ? kg : vg) + (isk ? koff : voff);
         dma_step[i] = isk ? Cfg::KCH * 16 : 128;
     }
-    auto stage_next = [&](int buf) {  // issues the next not-yet-staged tile into LDS buffer `buf`
+    auto stage_next = [&](int buf) __attribute__((always_inline)) {  // issues the next not-yet-staged tile into LDS buffer `buf`
         char* dst = smem + buf * Cfg::BUFB + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < Cfg::PW; ++i) {
@@ -300,9 +321,12 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     // NOMAX = true (only after tile 0 has anchored m_run, and only when `qbound` proves that no exponent
     // argument can exceed NOMAX_THR): the running-max search and the rescale test are dropped -- P is then
     // at most 2^NOMAX_THR, inside fp16 range, and the row sum normalises it exactly as before.
-    auto tile = [&](int t, auto fix_c, auto nomax_c) {
+    // EXACT = the wave keeps Q unscaled: scores are multiplied by c in fp32 before the exponential.
+    auto tile = [&](int t, auto fix_c, auto nomax_c, auto exact_c) __attribute__((always_inline)) {
         constexpr bool FIX = decltype(fix_c)::value;
         constexpr bool NOMAX = decltype(nomax_c)::value;
+        constexpr bool EXACT = decltype(exact_c)::value;
+        const float cm = EXACT ? cmul : 1.f;
         const int buf = (FRESCO_ABL == 5) ? 0 : (t & 1);
         const char* kb = smem + buf * Cfg::BUFB;
         const char* vb = kb + Cfg::KTILE;
@@ -345,7 +369,8 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
 
         // every wave has left tile t-1 (barrier below), so its buffer can be refilled while tile t runs;
         // issued here, the scalar adds + DMA instructions sit in the shadow of the QK MFMAs
-        if (FRESCO_ABL != 5 && t + 1 < nT) stage_next(buf ^ 1);
+        // (the sites without fix-ups only run tiles t < nT - 1: there is always a next tile)
+        if (FRESCO_ABL != 5 && (!FIX || t + 1 < nT)) stage_next(buf ^ 1);
 
         half8_t pf[QB][4];
 #pragma unroll
@@ -364,8 +389,8 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key0 = t * 64 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (need_diag && key0 == qr) s[j][0][r] += diag_bias_log2;
-                    if (need_diag && key0 + 32 == qr) s[j][1][r] += diag_bias_log2;
+                    if (need_diag && key0 == qr) s[j][0][r] += diag_u;
+                    if (need_diag && key0 + 32 == qr) s[j][1][r] += diag_u;
                     if (key0 >= M) s[j][0][r] = -1e30f;
                     if (key0 + 32 >= M) s[j][1][r] = -1e30f;
                 }
@@ -380,10 +405,11 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
                 for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[j][0][r]), s[j][1][r]);  // v_max3_f32
                 mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             }
-            if (!NOMAX && (t == 0 || __any(mt > RESCALE_THR))) {
+            if (!NOMAX && (t == 0 || __builtin_amdgcn_readfirstlane((int)__any(mt > resc_thr)) != 0)) {
                 float delta = (t == 0) ? mt : fmaxf(mt, 0.f);
                 if (Cfg::MCOL) {
-                    const float m_new = (float)(half_t)(m_run[j] + delta);  // stays fp16-representable
+                    // stays fp16-representable (and finite: logits beyond +-6e4 log2 units saturate)
+                    const float m_new = (float)(half_t)fminf(fmaxf(m_run[j] + delta, -6.0e4f), 6.0e4f);
                     delta = m_new - m_run[j];
                     m_run[j] = m_new;
                     const half_t nm = (half_t)(-m_new);
@@ -391,7 +417,7 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
                 } else {
                     m_run[j] += delta;
                 }
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                const float alpha = __builtin_amdgcn_exp2f(-delta * cm);
                 l_run[j] *= alpha;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -409,7 +435,8 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
             for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float x0 = s[j][kbk][r], x1 = s[j][kbk][r + 1];
+                    const float x0 = EXACT ? s[j][kbk][r] * cm : s[j][kbk][r];
+                    const float x1 = EXACT ? s[j][kbk][r + 1] * cm : s[j][kbk][r + 1];
                     const float p0 = (FRESCO_ABL == 1) ? x0 : __builtin_amdgcn_exp2f(x0);
                     const float p1 = (FRESCO_ABL == 1) ? x1 : __builtin_amdgcn_exp2f(x1);
                     if (!Cfg::ONES) psum += p0 + p1;
@@ -440,32 +467,30 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
 
     const std::integral_constant<bool, true> yes;
     const std::integral_constant<bool, false> no;
-    if (need_diag) {
-        for (int t = 0; t < nT; ++t) tile(t, yes, no);
-    } else if (nT == 1) {
-        if (Mpad != M)
-            tile(0, yes, no);
-        else
-            tile(0, no, no);
-    } else {
-        tile(0, no, no);
-        bool safe = true;
+    // Three call sites per precision variant: search + deferred rescale from tile 0 on; without the search
+    // once `qbound` allows it; the fix-up form for the last tile (padded keys) or, with a diagonal bias, for
+    // every tile.
+    auto run = [&](auto exact_c) __attribute__((always_inline)) {
+        int t = 0;
+        if (!need_diag) {
+            bool nomax = false;
+            for (; t < nT - 1 && !nomax; ++t) {
+                tile(t, no, no, exact_c);
+                if (t == 0) {
+                    bool safe = true;
 #pragma unroll
-        for (int j = 0; j < QB; ++j) safe = safe && (qbound[j] - m_run[j] <= NOMAX_THR);
-        if (__all(safe)) {
-            for (int t = 1; t < nT - 1; ++t) tile(t, no, yes);
-            if (Mpad != M)
-                tile(nT - 1, yes, yes);
-            else
-                tile(nT - 1, no, yes);
-        } else {
-            for (int t = 1; t < nT - 1; ++t) tile(t, no, no);
-            if (Mpad != M)
-                tile(nT - 1, yes, no);
-            else
-                tile(nT - 1, no, no);
+                    for (int j = 0; j < QB; ++j) safe = safe && (cmul * (qbound[j] - m_run[j]) <= NOMAX_THR);
+                    nomax = __builtin_amdgcn_readfirstlane((int)__all(safe)) != 0;
+                }
+            }
+            for (; t < nT - 1; ++t) tile(t, no, yes, exact_c);
         }
-    }
+        for (; t < nT; ++t) tile(t, yes, no, exact_c);
+    };
+    if (folded)
+        run(no);
+    else
+        run(yes);
 
     // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
 #pragma unroll

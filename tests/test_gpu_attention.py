@@ -100,6 +100,27 @@ def test_attention_forced_rescale():
     _check(out, _dense_ref(q.float(), k.float(), v.float(), H, scale, [0]), what="rescale")
 
 
+@pytest.mark.parametrize("D", [40, 80])
+@pytest.mark.parametrize("qgain", [1.0, 2.2, 6.0, 30.0])
+def test_attention_logit_ranges(D, qgain):
+    """The flash kernel picks, per wave, between the path without a running-max search (when |c q| max|k|
+    proves every exponent fits fp16) and the search + deferred-rescale path.  qgain moves the logits from
+    'always provably safe' over 'mixed per wave' to 'never safe, near one-hot softmax'; a slow ramp along the
+    keys makes the running max creep upwards tile after tile."""
+    import fresco_amd.ops as ops
+    g = synth.gen(int(D * 10 + qgain))
+    B, H, Lq, M = 2, 8, 256, 700
+    C = H * D
+    q = (torch.randn(B, Lq, C, generator=g) * qgain * torch.linspace(0.3, 1.5, Lq).view(1, Lq, 1)).half()
+    k = (torch.randn(B, M, C, generator=g) * torch.linspace(0.5, 1.6, M).view(1, M, 1)).half()
+    v = torch.randn(B, M, C, generator=g).half()
+    scale = 1.0 / math.sqrt(D)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, scale)
+    ref = _dense_ref(q.float(), k.float(), v.float(), H, scale, list(range(B)))
+    assert bool(torch.isfinite(out).all())
+    _check(out, ref, atol=3e-3, rtol=3e-3, what="qgain %g D=%d" % (qgain, D))
+
+
 @pytest.mark.parametrize("D,H,N", [(8, 8, 4), (40, 8, 8), (80, 8, 5), (40, 8, 16)])
 def test_temporal_attention(D, H, N):
     import fresco_amd.ops as ops
