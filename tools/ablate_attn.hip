@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
         unsigned s = 12345u;
         for (size_t i = 0; i < n; ++i) {
             s = s * 1664525u + 1013904223u;
-            h[i] = (_Float16)(((int)(s >> 16) % 2001 - 1000) / 500.0f);
+            h[i] = (_Float16)(((int)(s >> 16) % 2001 - 1000) / 1000.0f);
         }
         _Float16 *q, *k, *v, *o;
         void* ws;
