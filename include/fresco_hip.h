@@ -84,6 +84,11 @@ int fresco_prof_read(int max_records, int* tags, int* dims, float* ms);
  *                         q = to_q(ref), k = to_k(ref), v = current query, scale = 0.2/sqrt(D).
  *   out : (B, Lq, H*D) half.
  *   D must be a multiple of 8, 8 <= D <= 128.  Softmax in fp32, P and V in half, accumulation fp32.
+ *   Numerics: the exponent scale  scale*log2(e)  is folded into the fp16 query (one rounding) only for
+ *   queries whose logits are provably small (scale*log2e*|q|*max|k| <= 16, a per-wavefront decision from
+ *   the key norms the pack pass records); otherwise scores are scaled in fp32.  Logits are assumed to stay
+ *   below 6e4 in log2 units.
+ *   Workspace: packed K / V^T images of every key group and head plus one float per 64-key tile.
  * ------------------------------------------------------------------------------------------ */
 size_t fresco_attn_workspace_bytes(int n_groups, int H, int M, int D);
 
