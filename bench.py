@@ -160,7 +160,13 @@ def pmc_traffic_bytes(kernel_substr):
     import csv
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_attn_*.csv")))
+    import re
+
+    def order(path):  # rNN_pmc_attn_vMM.csv -> (NN, MM): the latest round / kernel version wins
+        m = re.search(r"r(\d+)_pmc_attn_v(\d+)\.csv$", path)
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_attn_*.csv")), key=order)
     if not files:
         return None
     fetch = write = None
