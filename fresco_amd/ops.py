@@ -88,6 +88,46 @@ _default_ws = _PerStreamWorkspace()
 
 
 # ---------------------------------------------------------------------------------------------
+# fused linear projections
+# ---------------------------------------------------------------------------------------------
+def linear_supported(K, N, dtype):
+    """shapes / dtype fresco_linear takes (SD-1.5 up_blocks.2/3 attention widths); others keep torch's GEMM"""
+    return dtype == torch.float16 and K in (320, 640) and N % 32 == 0
+
+
+def linear(x, W, bias=None, nw=1, outs=None):
+    """out_j = x W_j^T (+ b_j): x (..., K) fp16 read once, W (nw*N, K) fp16 = the stacked nn.Linear weights,
+    bias (nw*N,) fp16 or None.  Returns nw tensors shaped x.shape[:-1] + (N,); `outs` may supply them (dense in
+    the last dim, uniformly strided rows -- e.g. the two halves of a fused K|V buffer)."""
+    _need_gpu(x, W, bias)
+    K = x.shape[-1]
+    if W.dtype != torch.float16 or x.dtype != torch.float16 or W.shape[1] != K or W.shape[0] % nw != 0:
+        raise ValueError("linear: x (...,K) and W (nw*N,K) must be fp16 with matching K")
+    if not W.is_contiguous():
+        W = W.contiguous()
+    N = W.shape[0] // nw
+    x2, x_ld, M = _rows(x)
+    if outs is None:
+        outs = [torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device) for _ in range(nw)]
+    ptrs, lds = [], []
+    for t in outs:
+        t2, ld, rows = _rows(t)
+        if t2 is not t or rows != M or t.shape[-1] != N or t.dtype != torch.float16:
+            raise ValueError("linear: every output must be a (M,N) fp16 tensor with uniformly strided rows")
+        ptrs.append(t.data_ptr())
+        lds.append(ld)
+    while len(ptrs) < 3:
+        ptrs.append(None)
+        lds.append(0)
+    if bias is not None:
+        bias = bias.to(torch.float16).contiguous()
+    rc = _lib.load().fresco_linear(x2.data_ptr(), x_ld, W.data_ptr(), _ptr(bias), ptrs[0], ptrs[1], ptrs[2], lds[0],
+                                   lds[1], lds[2], nw, M, N, K, _stream())
+    _lib.check(rc, "fresco_linear(M=%d,N=%d,K=%d,nw=%d)" % (M, N, K, nw))
+    return outs
+
+
+# ---------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------
 def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, group_rows=None,

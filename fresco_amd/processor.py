@@ -20,6 +20,12 @@ from . import _lib, ops
 from .control import AttentionControl
 
 
+def _plain_linear(m, with_bias):
+    """an unwrapped nn.Linear whose forward is exactly x W^T (+ b): safe to run through fresco_linear"""
+    return (type(m) is torch.nn.Linear and (m.bias is not None) == with_bias and m.weight.is_cuda
+            and ops.linear_supported(m.in_features, m.out_features, m.weight.dtype))
+
+
 class FRESCOAttnProcessor2_0:
     def __init__(self, unet_chunk_size=2, controller=None):
         _lib.load()  # fail here, loudly, when the HIP library is absent
@@ -27,7 +33,43 @@ class FRESCOAttnProcessor2_0:
         self.controller = controller
         self._ws = ops.Workspace()
         self._rows_cache = {}
+        self._wcat_cache = {}
         self.shard = None  # fresco_amd.dist.FrameShard for frame-parallel multi-GPU runs
+        self.fuse_projections = True  # q/k/v (and to_out at C = 320) through fresco_linear when they are plain Linears
+
+    # ---- fused projections ---------------------------------------------------------------------------
+    def _project(self, attn, x, names, outs=None):
+        """[attn.<name>(x) for name in names] in ONE launch that reads x once (fresco_linear), when every module
+        is a plain bias-free fp16 nn.Linear of a supported width; otherwise the modules are called as the
+        reference calls them (wrapped / LoRA / quantised layers keep their own forward)."""
+        mods = [getattr(attn, n) for n in names]
+        if (self.fuse_projections and x.dtype == torch.float16 and x.is_cuda
+                and all(_plain_linear(m, False) for m in mods)
+                and len({(m.in_features, m.out_features) for m in mods}) == 1):
+            key = (id(attn), names)
+            sig = tuple((m.weight.data_ptr(), m.weight._version) for m in mods)
+            hit = self._wcat_cache.get(key)
+            if hit is None or hit[0] != sig:
+                if len(self._wcat_cache) > 64:
+                    self._wcat_cache.clear()
+                w = mods[0].weight.detach() if len(mods) == 1 else torch.cat([m.weight.detach() for m in mods], 0)
+                hit = (sig, w.contiguous())
+                self._wcat_cache[key] = hit
+            return ops.linear(x, hit[1], None, len(mods), outs)
+        res = [m(x) for m in mods]
+        if outs is not None:
+            for o, r in zip(outs, res):
+                o.copy_(r)
+            return outs
+        return res
+
+    def _project_out(self, attn, hs):
+        lin = attn.to_out[0]
+        # a single C = 640 projection is faster in the library GEMM (csrc/proj.hip header): fuse only C = 320
+        if (self.fuse_projections and hs.dtype == torch.float16 and hs.is_cuda and _plain_linear(lin, True)
+                and lin.in_features == 320):
+            return ops.linear(hs, lin.weight.detach(), lin.bias.detach(), 1)[0]
+        return lin(hs)
 
     # flat int32 indices of the True entries of a (N, HW) mask, cached per mask tensor
     def _kv_rows(self, mask):
@@ -57,19 +99,20 @@ class FRESCOAttnProcessor2_0:
             hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
 
         ctrl = self.controller
-        query = attn.to_q(hidden_states)
         crossattn = encoder_hidden_states is not None
         if not crossattn:
             encoder_hidden_states = hidden_states
             if ctrl and ctrl.store:
                 ctrl(hidden_states.detach().clone())
-        elif attn.norm_cross:
-            encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
-        key = attn.to_k(encoder_hidden_states)
-        value = attn.to_v(encoder_hidden_states)
-        if self.shard is not None and ctrl and not crossattn and (ctrl.use_cfattn or ctrl.use_interattn):
-            return self._sharded_self_attention(attn, hidden_states, query, key, value, residual,
-                                                input_ndim)
+            if self.shard is not None and ctrl and (ctrl.use_cfattn or ctrl.use_interattn):
+                return self._sharded_self_attention(attn, hidden_states, residual, input_ndim)
+            query, key, value = self._project(attn, hidden_states, ("to_q", "to_k", "to_v"))
+        else:
+            query = attn.to_q(hidden_states)
+            if attn.norm_cross:
+                encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
+            key = attn.to_k(encoder_hidden_states)
+            value = attn.to_v(encoder_hidden_states)
 
         heads = attn.heads
         head_dim = key.shape[-1] // heads
@@ -83,8 +126,7 @@ class FRESCOAttnProcessor2_0:
         if fresco and ctrl.use_intraattn:
             ref = ctrl(None)
             assert ref.shape == encoder_hidden_states.shape
-            q_ref = attn.to_q(ref)
-            k_ref = attn.to_k(ref)
+            q_ref, k_ref = self._project(attn, ref, ("to_q", "to_k"))
             q_att = ops.attention(q_ref, k_ref, query, heads, ctrl.intraattn_scale_factor * sm_scale,
                                   diag_bias=float(ctrl.intraattn_bias), workspace=self._ws)
 
@@ -118,7 +160,7 @@ class FRESCOAttnProcessor2_0:
                                         ctrl.interattn_scale_factor * sm_scale, chunk)
 
         hs = hs.to(query.dtype)
-        hs = attn.to_out[0](hs)
+        hs = self._project_out(attn, hs)
         hs = attn.to_out[1](hs)
         if input_ndim == 4:
             hs = hs.transpose(-1, -2).reshape(batch_size, channel, height, width)
@@ -129,7 +171,7 @@ class FRESCOAttnProcessor2_0:
         return hs
 
 
-def _sharded_self_attention(self, attn, hidden_states, query, key, value, residual, input_ndim):
+def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
     """Frame-parallel form of the FRESCO self-attention branch (fresco_amd/dist.py): this rank holds
     `shard.n_loc` frames of both CFG halves; K|V (and the cross-frame output, for the temporal pass)
     are all-gathered over RCCL, everything else is local."""
@@ -138,17 +180,24 @@ def _sharded_self_attention(self, attn, hidden_states, query, key, value, residu
     ctrl, sh = self.controller, self.shard
     chunk = self.unet_chunk_size
     heads = attn.heads
-    B_loc, hw, C = key.shape
+    B_loc, hw, _ = hidden_states.shape
+    C = attn.to_k.out_features
     head_dim = C // heads
     sm_scale = 1.0 / math.sqrt(head_dim)
     assert B_loc == sh.B_loc and chunk == sh.chunk
+    # q, k, v in one pass over the hidden states; K and V land directly in the fused exchange buffer
+    query = torch.empty(B_loc, hw, C, dtype=hidden_states.dtype, device=hidden_states.device)
+    kv_loc = torch.empty(2, B_loc, hw, C, dtype=hidden_states.dtype, device=hidden_states.device)
+    self._project(attn, hidden_states, ("to_q", "to_k", "to_v"), outs=[query, kv_loc[0], kv_loc[1]])
+    key = kv_loc[0]
     # exchange 1: fused K|V, launched before the local work it overlaps with
-    kv, work = sh.all_gather(torch.stack((key, value)), async_op=True)
+    kv, work = sh.all_gather(kv_loc, async_op=True)
     q_att = query
     if ctrl.use_intraattn:
         ref = ctrl(None)
         assert ref.shape == hidden_states.shape
-        q_att = ops.attention(attn.to_q(ref), attn.to_k(ref), query, heads,
+        q_ref, k_ref = self._project(attn, ref, ("to_q", "to_k"))
+        q_att = ops.attention(q_ref, k_ref, query, heads,
                               ctrl.intraattn_scale_factor * sm_scale, diag_bias=float(ctrl.intraattn_bias),
                               workspace=self._ws)
     if work is not None:
@@ -168,7 +217,7 @@ def _sharded_self_attention(self, attn, hidden_states, query, key, value, residu
         hs = ops.attention(q_att, kv_flat, kv_flat[B_loc * hw:], heads, sm_scale, kv_rows=rows,
                            n_groups=chunk, M=rows.numel(), group_rows=group_rows, workspace=self._ws)
     else:
-        hs = ops.attention(q_att, key, value, heads, sm_scale, workspace=self._ws)
+        hs = ops.attention(q_att, key, kv_loc[1], heads, sm_scale, workspace=self._ws)
     if ctrl.use_interattn:
         fwd_mapping = interattn_mask = None
         paras = ctrl.interattn_paras
@@ -181,7 +230,7 @@ def _sharded_self_attention(self, attn, hidden_states, query, key, value, residu
         hs = ops.temporal_attention(query, kv_flat, hs_all.view(-1, C), fwd_mapping, interattn_mask, heads,
                                     ctrl.interattn_scale_factor * sm_scale, chunk,
                                     shard=(sh.N, sh.n_loc, sh.f0, 2 * B_loc, B_loc))
-    hs = attn.to_out[0](hs.to(query.dtype))
+    hs = self._project_out(attn, hs.to(query.dtype))
     hs = attn.to_out[1](hs)
     if attn.residual_connection:
         hs = hs + residual

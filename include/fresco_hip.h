@@ -61,6 +61,7 @@ const char* fresco_last_error(void);
 #define FRESCO_PROF_OPT_GRAM 7
 #define FRESCO_PROF_OPT_SV 8
 #define FRESCO_PROF_OPT_ADAM 9
+#define FRESCO_PROF_LINEAR 10 /* dims = {M, N, K, nw} */
 int fresco_prof_enable(int capacity);
 int fresco_prof_disable(void);
 int fresco_prof_read(int max_records, int* tags, int* dims, float* ms);
@@ -91,6 +92,21 @@ int fresco_prof_read(int max_records, int* tags, int* dims, float* ms);
  *   Workspace: packed K / V^T images of every key group and head plus one float per 64-key tile.
  * ------------------------------------------------------------------------------------------ */
 size_t fresco_attn_workspace_bytes(int n_groups, int H, int M, int D);
+
+/* ------------------------------------------------------------------------------------------
+ * (a1)  Fused linear projections  attn.to_q / to_k / to_v (DH:201, 214-215, 260-261) and to_out[0] (DH:375):
+ *           out_j = x W_j^T (+ b_j),   j = 0 .. nw-1,  nw <= 3
+ *   x    : (M, K) half, row stride x_ld (elements);  read once for all nw outputs
+ *   W    : (nw*N, K) half row-major = the nn.Linear weights of the nw projections stacked along dim 0
+ *   bias : (nw*N) half or NULL
+ *   out_j: (M, N) half, row stride ld_j (elements); unused outputs NULL
+ *   fp32 accumulation, one rounding to half at the end (what the library GEMM behind nn.Linear does).
+ *   Supported: K in {320, 640} (SD-1.5 up_blocks.3 / up_blocks.2), N % 32 == 0; anything else returns
+ *   FRESCO_EUNSUPPORTED and the caller keeps its own GEMM.
+ * ------------------------------------------------------------------------------------------ */
+int fresco_linear(const void* x, int64_t x_ld, const void* W, const void* bias, void* out0, void* out1, void* out2,
+                  int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N, int K, void* stream);
+
 
 int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* kv_rows,
                     void* out, void* workspace, size_t workspace_bytes,
