@@ -9,7 +9,8 @@ the controller interaction are the reference's; the data 
     shared by all frames;
   * spatial-guided pass (257-288): no HW x HW eye mask is materialised; `key * 0.2` is a logit scale;
   * temporal pass (309-367): one fused gather / N x N masked softmax / scatter kernel;
-  * the linear projections stay `attn.to_q/to_k/to_v/to_out` (torch GEMMs owned by diffusers).
+  * `attn.to_q/to_k/to_v` run as one fresco_linear launch that reads the hidden states once (and
+    `to_out[0]` at C = 320) when they are plain nn.Linear modules; wrapped modules keep their forward.
 """
 import math
 import weakref
