@@ -163,8 +163,7 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
 // flash attention: grid (H * nQblk * B), 256 threads = 4 waves x QB blocks of 32 query rows
 // blockIdx.x = (b * nQblk + qblk) * H + h   -> head h lands on XCD (h % 8): each XCD's L2 holds
 // only its own heads' packed K / V^T.
-// QB = 2: every K / V^T fragment read from LDS feeds two MFMAs and the two query blocks give the
-// scheduler independent MFMA (block j) and VALU softmax (block 1-j) streams to overlap in one wave.
+// QB query blocks per wave (the product instantiates QB = 1, see launch_attn).
 // ---------------------------------------------------------------------------------------------
 template <int D, int QB, int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __restrict__ q,
@@ -523,20 +522,6 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     }
 }
 
-// Query blocks per wave.  2 wherever the accumulators still fit (D <= 96); FRESCO_ATTN_QB=1|2 in the
-// environment overrides it (tuning / A-B measurements only).
-static int attn_qb_choice(int D, int Lq) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("FRESCO_ATTN_QB");
-        forced = e ? atoi(e) : 0;
-    }
-    if (forced == 1 || forced == 2) return forced;
-    // measured on MI355X (cfg2 shapes, round 1): QB = 1 at 3 (D <= 40) / 2 waves per SIMD beats QB = 2 at
-    // 1 wave per SIMD by ~15 %: hipcc does not interleave the two query blocks' MFMA and VALU streams
-    return 1;
-}
-
 template <int D, int QB, int MINW>
 static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, half_t* out, int B, int H,
                          int Lq, int M, int Mpad, int n_groups, float scale, float diag_bias, int64_t q_ld,
@@ -555,16 +540,6 @@ static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, ha
                        kp, vt, ktmax, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
 }
 
-// FRESCO_ATTN_OCC=lo|hi in the environment picks the launch-bounds variant (tuning only)
-static int attn_occ_choice() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FRESCO_ATTN_OCC");
-        v = (e && e[0] == 'h') ? 2 : (e && e[0] == 'l') ? 1 : 0;
-    }
-    return v;
-}
-
 template <int D>
 static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const int32_t* kv_rows,
                        half_t* out, char* ws, int B, int H, int Lq, int n_groups, int M,
@@ -581,15 +556,11 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
         hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, ktmax, H, M, Mpad,
                            group_rows, kv_ld);
     }
-    // waves per SIMD the register allocator is asked to make room for (lo / hi variants)
-    constexpr int LO = D <= 40 ? 3 : (D <= 80 ? 2 : 1);
-    constexpr int HI = D <= 40 ? 4 : (D <= 80 ? 3 : 1);
-    if (D <= 96 && attn_qb_choice(D, Lq) == 2)
-        launch_flash<D, (D <= 96 ? 2 : 1), 1>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, ktmax, st);
-    else if (attn_occ_choice() == 2)
-        launch_flash<D, 1, HI>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, ktmax, st);
-    else
-        launch_flash<D, 1, LO>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, ktmax, st);
+    // One query block per wave; waves per SIMD the register allocator is asked to make room for.  Measured on
+    // MI355X (round 1): two query blocks per wave (QB = 2, halves the LDS reads per MFMA) 15-25 % slower at the
+    // one or two waves per SIMD they leave; one more wave per SIMD forced by launch bounds (spills) 5 % slower.
+    constexpr int MINW = D <= 40 ? 3 : (D <= 80 ? 2 : 1);
+    launch_flash<D, 1, MINW>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, ktmax, st);
     return check_launch();
 }
 

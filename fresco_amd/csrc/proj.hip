@@ -16,7 +16,6 @@
 // 40 us.  K = 640, M = 16384: 57 vs 77 us fused, but 30 vs 25 us for a single projection (the caller keeps the
 // library GEMM there).
 #include "common.h"
-#include <stdlib.h>
 
 namespace fresco {
 
@@ -191,15 +190,7 @@ extern "C" int fresco_linear(const void* x, int64_t x_ld, const void* W, const v
     half_t* o0 = static_cast<half_t*>(out0);
     half_t* o1 = static_cast<half_t*>(out1);
     half_t* o2 = static_cast<half_t*>(out2);
-    static int nwv = 0;  // FRESCO_LINEAR_WAVES=8: 256-row workgroups (tuning only)
-    if (nwv == 0) {
-        const char* e = getenv("FRESCO_LINEAR_WAVES");
-        nwv = (e && atoi(e) == 8) ? 8 : 4;  // measured: 4 waves (128 rows, 3 workgroups per CU) beat 8
-    }
-    if (nwv == 4) {
-        if (K == 320) return launch_linear<320, 4>(xh, x_ld, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
-        return launch_linear<640, 4>(xh, x_ld, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
-    }
-    if (K == 320) return launch_linear<320, 8>(xh, x_ld, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
-    return launch_linear<640, 8>(xh, x_ld, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
+    // 4 waves = 128 rows per workgroup (3 workgroups per CU); 256-row workgroups measured 20 % slower
+    if (K == 320) return launch_linear<320, 4>(xh, x_ld, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
+    return launch_linear<640, 4>(xh, x_ld, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
 }

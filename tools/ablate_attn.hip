@@ -27,12 +27,6 @@ int main(int argc, char** argv) {
         hipMemcpy(v, h.data(), n * 2, hipMemcpyHostToDevice);
         const size_t wsb = fresco_attn_workspace_bytes(G, H, M, D);
         hipMalloc(&ws, wsb);
-        for (int qb = 1; qb <= 2; ++qb) {
-            char env[8];
-            snprintf(env, sizeof env, "%d", qb);
-            // attn_qb_choice caches the env on first use, so qb is fixed per process: pass it as argv[1]
-            (void)env;
-        }
         fresco_prof_enable(256);
         for (int r = 0; r < reps + 3; ++r)
             fresco_attn_fwd(q, k, v, nullptr, o, ws, wsb, B, H, HW, D, G, M, 8 * HW, 0.158f, 0.f, nullptr);
@@ -42,8 +36,7 @@ int main(int argc, char** argv) {
         double tot = 0; int cnt = 0;
         for (int i = 6; i < nrec; ++i)
             if (tags[i] == FRESCO_PROF_ATTN_FLASH) { tot += ms[i]; ++cnt; }
-        printf("ABL=%d QB=%s HW=%d D=%d M=%d: flash %.1f us\n", FRESCO_ABL, getenv("FRESCO_ATTN_QB") ? getenv("FRESCO_ATTN_QB") : "default",
-               HW, D, M, 1e3 * tot / cnt);
+        printf("ABL=%d HW=%d D=%d M=%d: flash %.1f us\n", FRESCO_ABL, HW, D, M, 1e3 * tot / cnt);
         hipFree(q); hipFree(k); hipFree(v); hipFree(o); hipFree(ws);
     }
     return 0;
