@@ -17,7 +17,6 @@
 // MFMA 32x32x16 f16 operand layout used below (gfx950): lane l supplies 8 consecutive k for
 // row/col (l & 31), k-chunk (l >> 5); C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
 #include "common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace fresco {
