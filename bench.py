@@ -355,7 +355,7 @@ def main():
                         avg_launch_us=round(mean_s * 1e6, 2), algorithmic_flop_per_launch=flop)
     by_tag = {}
     for tag, d, ms in recs:
-        key = {1: "attn_flash", 2: "kv_pack", 3: "temporal"}.get(tag, str(tag)) + str(list(d))
+        key = {1: "attn_flash", 2: "kv_pack", 3: "temporal", 10: "linear"}.get(tag, str(tag)) + str(list(d))
         by_tag.setdefault(key, []).append(ms)
     kernels_us = {k: round(1e3 * sum(v) / len(v), 2) for k, v in sorted(by_tag.items())}
 
