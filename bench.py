@@ -395,6 +395,11 @@ def main():
             res["speedup_vs_torch_gpu_lean_port"] = round(
                 res["value"] / res["torch_gpu_baseline"]["lean_port"]["value"], 2)
             res["cpu_baseline"] = cpu_baseline(layers, params, N)
+            # auxiliary, NOT part of `value`: what BASELINE.json's third config adds to every denoising step
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_opt
+
+            res["cfg3"] = bench_opt.measure(N=N, R=R, dev=device)
         elif world == 1:
             res["cpu_baseline"] = None
         print(json.dumps(res))
