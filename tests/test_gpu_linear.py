@@ -64,3 +64,64 @@ def test_linear_rejects_unsupported():
         ops.linear(x, W)
     with pytest.raises(ValueError):
         ops.linear(x.float(), W)
+
+
+class _Scaled(torch.nn.Linear):
+    """a wrapped projection (what a LoRA / quantisation layer looks like to the processor): NOT a plain Linear"""
+
+    def forward(self, x):
+        return super().forward(x) * 0.5
+
+
+@torch.no_grad()
+def test_processor_fuses_only_plain_linears_and_tracks_weight_updates():
+    import copy
+    import fresco_amd
+    from oracle import fresco_oracle as O
+    g = synth.gen(21)
+    C, H, B, HW = 320, 8, 4, 64
+    attn = synth.FakeAttn(C, H).half().to(DEV)
+    x = torch.randn(B, HW, C, generator=g).half().to(DEV)
+    proc = fresco_amd.FRESCOAttnProcessor2_0(2, fresco_amd.AttentionControl())
+    seen = []
+    real = fresco_amd.ops.linear
+
+    def spy(*a, **k):
+        seen.append(a[3] if len(a) > 3 else k.get("nw", 1))
+        return real(*a, **k)
+
+    fresco_amd.ops.linear = spy
+    try:
+        y = proc(attn, x)
+        assert seen == [3, 1]  # q,k,v in one launch, to_out (C = 320) in another
+        W = [w.detach().float().cpu() for w in attn.weights()]
+        ref = O.fresco_attention(x.float().cpu(), W[0], W[1], W[2], W[3], attn.to_out[0].bias.detach().float().cpu(), H,
+                                 round_dtype=torch.float16)
+        assert float((y.float().cpu() - ref).abs().max()) < 3e-3
+        # in-place weight update: the stacked copy must follow
+        with torch.no_grad():
+            attn.to_k.weight.mul_(-1.0)
+        y2 = proc(attn, x)
+        W[1] = -W[1]
+        ref2 = O.fresco_attention(x.float().cpu(), W[0], W[1], W[2], W[3], attn.to_out[0].bias.detach().float().cpu(), H,
+                                  round_dtype=torch.float16)
+        assert float((y2.float().cpu() - ref2).abs().max()) < 3e-3
+        # a wrapped module keeps its own forward: no fused q,k,v launch, and its scaling is honoured
+        seen.clear()
+        attn2 = copy.deepcopy(attn)
+        wrapped = _Scaled(C, C, bias=False).half().to(DEV)
+        with torch.no_grad():
+            wrapped.weight.copy_(attn2.to_q.weight)
+        attn2.to_q = wrapped
+        y3 = proc(attn2, x)
+        assert 3 not in seen
+        ref3 = O.fresco_attention(x.float().cpu(), 0.5 * W[0], W[1], W[2], W[3],
+                                  attn.to_out[0].bias.detach().float().cpu(), H, round_dtype=torch.float16)
+        assert float((y3.float().cpu() - ref3).abs().max()) < 3e-3
+        # switch off: module calls only
+        seen.clear()
+        proc.fuse_projections = False
+        y4 = proc(attn, x)
+        assert seen == [] and float((y4.float() - y2.float()).abs().max()) < 2e-3
+    finally:
+        fresco_amd.ops.linear = real
