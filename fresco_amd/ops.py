@@ -12,7 +12,15 @@ from . import _lib
 from ._lib import FrescoHipError
 
 
+try:  # raw handle of the current HIP stream without building a torch.cuda.Stream object (~10x cheaper per call)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    _raw_stream = None
+
+
 def _stream():
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -36,6 +44,8 @@ def _rows(t):
     (dense, or a column slice of a dense (..., k*C) tensor such as a fused projection output);
     anything else is made dense first."""
     C = t.shape[-1]
+    if t.is_contiguous() and C % 8 == 0 and t.dim() >= 2 and t.data_ptr() % 16 == 0:  # the common case
+        return t, C, t.numel() // C
     ok = t.stride(-1) == 1 and t.dim() >= 2
     if ok:
         ld = t.stride(-2)
@@ -77,7 +87,7 @@ class _PerStreamWorkspace:
         table = getattr(self._tls, "table", None)
         if table is None:
             table = self._tls.table = {}
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, _stream())
         ws = table.get(key)
         if ws is None:
             ws = table[key] = Workspace()

@@ -44,19 +44,24 @@ class FRESCOAttnProcessor2_0:
         is a plain bias-free fp16 nn.Linear of a supported width; otherwise the modules are called as the
         reference calls them (wrapped / LoRA / quantised layers keep their own forward)."""
         mods = [getattr(attn, n) for n in names]
-        if (self.fuse_projections and x.dtype == torch.float16 and x.is_cuda
-                and all(_plain_linear(m, False) for m in mods)
-                and len({(m.in_features, m.out_features) for m in mods}) == 1):
+        if self.fuse_projections and x.dtype == torch.float16 and x.is_cuda:
+            # the decision and the stacked weight are cached per (module, projection set) and re-validated by
+            # the identity of the modules and the (address, version) of their weights
             key = (id(attn), names)
-            sig = tuple((m.weight.data_ptr(), m.weight._version) for m in mods)
+            sig = tuple((id(m), m.weight.data_ptr(), m.weight._version) for m in mods)
             hit = self._wcat_cache.get(key)
             if hit is None or hit[0] != sig:
                 if len(self._wcat_cache) > 64:
                     self._wcat_cache.clear()
-                w = mods[0].weight.detach() if len(mods) == 1 else torch.cat([m.weight.detach() for m in mods], 0)
-                hit = (sig, w.contiguous())
+                w = None
+                if (all(_plain_linear(m, False) for m in mods)
+                        and len({(m.in_features, m.out_features) for m in mods}) == 1):
+                    w = mods[0].weight.detach() if len(mods) == 1 else torch.cat([m.weight.detach() for m in mods], 0)
+                    w = w.contiguous()
+                hit = (sig, w)
                 self._wcat_cache[key] = hit
-            return ops.linear(x, hit[1], None, len(mods), outs)
+            if hit[1] is not None:
+                return ops.linear(x, hit[1], None, len(mods), outs)
         res = [m(x) for m in mods]
         if outs is not None:
             for o, r in zip(outs, res):
