@@ -8,11 +8,16 @@
 //                     rows = head dim padded to a multiple of 32, keys contiguous).  HBM-bound.
 //   attn_flash_kernel: flash-style attention on v_mfma_f32_32x32x16_f16.  One wave owns 32 query
 //                     rows; S^T = K Q^T is computed "swapped" so that every lane holds the scores
-//                     of ONE query (its column of the 32x32 MFMA C tile): row max / row sum are
-//                     in-lane plus one cross-lane exchange with lane^32, and the exponentiated
-//                     scores are already laid out as the B operand of  O^T = V^T P^T.
-//                     K / V^T tiles of 64 keys are staged through double-buffered LDS whose row
-//                     strides are odd multiples of 16 B (conflict-free ds_read_b128).
+//                     of ONE query (its column of the 32x32 MFMA C tile): the exponentiated scores
+//                     are already laid out as the B operand of  O^T = V^T P^T.
+//                     K / V^T tiles of 64 keys are DMA'd into double-buffered LDS whose row strides
+//                     are odd multiples of 16 B (conflict-free ds_read_b128).
+//                     The softmax bookkeeping rides in the MFMAs wherever the head dim leaves room:
+//                     a ones ROW in V^T makes the PV product deliver the row sum, a ones COLUMN in K
+//                     against -m in Q's spare column makes the QK product subtract the running max.
+//                     Per wave, from the key norms kv_pack records (Cauchy-Schwarz bound on the logits):
+//                     the max search is dropped when no exponent can leave fp16 range, and the exponent
+//                     scale is folded into the fp16 Q only while that costs no more than P's own rounding.
 //
 // MFMA 32x32x16 f16 operand layout used below (gfx950): lane l supplies 8 consecutive k for
 // row/col (l & 31), k-chunk (l >> 5); C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
@@ -328,9 +333,6 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
         const int buf = (FRESCO_ABL == 5) ? 0 : (t & 1);
         const char* kb = smem + buf * Cfg::BUFB;
         const char* vb = kb + Cfg::KTILE;
-#ifdef FRESCO_IGLP
-        __builtin_amdgcn_iglp_opt(FRESCO_IGLP);  // scheduling experiments (tools/ablate_attn.hip)
-#endif
 
         // ---- S^T = K Q^T : per query block two independent 32-key accumulators ------------------
         floatx16 s[QB][2];
