@@ -187,7 +187,7 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
     chunk = self.unet_chunk_size
     heads = attn.heads
     B_loc, hw, _ = hidden_states.shape
-    C = attn.to_k.out_features
+    C = getattr(attn.to_k, "out_features", hidden_states.shape[-1])  # inner dim (= hidden width in SD-1.5 attn1)
     head_dim = C // heads
     sm_scale = 1.0 / math.sqrt(head_dim)
     assert B_loc == sh.B_loc and chunk == sh.chunk
