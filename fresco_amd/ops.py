@@ -186,6 +186,22 @@ def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, gro
     return out
 
 
+def attention_f32(q, k, v, scale):
+    """softmax(scale * q k^T) v in fp32 (fresco_attn_f32): q (B,Lq,D), k (B,Lk,D), v (B,Lk,Dv) -> (B,Lq,Dv).
+    One head; batch entries are independent problems (windows)."""
+    _need_gpu(q, k, v)
+    q, k, v = _f32c(q), _f32c(k), _f32c(v)
+    B, Lq, D = q.shape
+    Lk, Dv = k.shape[1], v.shape[2]
+    if k.shape != (B, Lk, D) or v.shape[:2] != (B, Lk):
+        raise ValueError("attention_f32: q (B,Lq,D), k (B,Lk,D), v (B,Lk,Dv) expected")
+    out = torch.empty(B, Lq, Dv, dtype=torch.float32, device=q.device)
+    rc = _lib.load().fresco_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, Lk, D, Dv,
+                                     float(scale), _stream())
+    _lib.check(rc, "fresco_attn_f32(B=%d,Lq=%d,Lk=%d,D=%d,Dv=%d)" % (B, Lq, Lk, D, Dv))
+    return out
+
+
 def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk, shard=None):
     """fresco_temporal_attn: q, k, v (chunk*N, HW, C) fp16; fwd_map (N,HW) int64; mask (HW,N,N) bool.
 

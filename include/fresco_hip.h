@@ -62,6 +62,7 @@ const char* fresco_last_error(void);
 #define FRESCO_PROF_OPT_SV 8
 #define FRESCO_PROF_OPT_ADAM 9
 #define FRESCO_PROF_LINEAR 10 /* dims = {M, N, K, nw} */
+#define FRESCO_PROF_ATTN_F32 11 /* dims = {B, Lq, Lk, D} */
 int fresco_prof_enable(int capacity);
 int fresco_prof_disable(void);
 int fresco_prof_read(int max_records, int* tags, int* dims, float* ms);
@@ -171,6 +172,15 @@ int fresco_resize_bilinear(const float* x, float* out, int BC, int H, int W, int
 
 /* F.max_pool2d(x, kernel_size=k) (stride k, floor) on (BC,H,W) fp32 -> (BC,H/k,W/k)  (FU:27,31; DH:440,442) */
 int fresco_max_pool(const float* x, float* out, int BC, int H, int W, int k, void* stream);
+
+/* fp32 attention for the flow network (f3): out = softmax(scale * q k^T) v, one head.
+ *   GMFlow's full / window attention (gmflow/transformer.py:8-17, 92-95; windows = batch entries), global
+ *   correlation softmax (gmflow/matching.py:7-36: v = pixel grid, Dv = 2) and flow propagation
+ *   (gmflow/transformer.py:356-372: v = flow, Dv = 2).
+ *   q (B,Lq,D), k (B,Lk,D), v (B,Lk,Dv), out (B,Lq,Dv): fp32 row-major, dense.  D in {32, 64, 128}, Dv <= 128.
+ *   fp32 MFMA for both contractions, fp32 softmax (the flows feed integer decisions downstream). */
+int fresco_attn_f32(const float* q, const float* k, const float* v, float* out, int B, int Lq, int Lk, int D, int Dv,
+                    float scale, void* stream);
 
 /* forward_backward_consistency_check (gmflow/geometry.py:75-96) fused with the colour-difference
  * occlusion refinement of get_flow_and_interframe_paras (DH:919-926).  Pair n couples frame n with frame

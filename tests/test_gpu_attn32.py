@@ -1,0 +1,48 @@
+"""GPU parity of the fp32 attention kernel (fresco_attn_f32) against an fp64 softmax(q k^T) v."""
+import math
+
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref(q, k, v, scale):
+    s = (q.double() @ k.double().transpose(1, 2)) * scale
+    return torch.softmax(s, -1) @ v.double()
+
+
+@pytest.mark.parametrize("D,Dv,B,Lq,Lk", [(128, 128, 3, 200, 333), (128, 2, 2, 130, 257), (64, 64, 2, 64, 64),
+                                           (32, 5, 1, 33, 31), (128, 128, 8, 1024, 1024), (128, 2, 2, 4096, 4096)])
+def test_attention_f32(D, Dv, B, Lq, Lk):
+    import fresco_amd.ops as ops
+    g = synth.gen(D + Dv + Lq)
+    q = torch.randn(B, Lq, D, generator=g) * 1.5
+    k = torch.randn(B, Lk, D, generator=g) * 1.5
+    v = torch.randn(B, Lk, Dv, generator=g)
+    if Dv == 2:  # a pixel grid, as in the global matching step
+        v = torch.stack((torch.arange(Lk) % 64, torch.arange(Lk) // 64), -1).float().expand(B, Lk, 2).contiguous()
+    scale = 1.0 / math.sqrt(D)
+    out = ops.attention_f32(q.to(DEV), k.to(DEV), v.to(DEV), scale)
+    ref = _ref(q, k, v, scale)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (B, Lq, Dv)
+    err = (out.cpu().double() - ref).abs().max()
+    assert float(err) < 2e-5 * max(1.0, float(ref.abs().max())), float(err)
+
+
+def test_attention_f32_peaked_logits_and_validation():
+    import fresco_amd
+    import fresco_amd.ops as ops
+    g = synth.gen(9)
+    q = torch.randn(1, 96, 128, generator=g) * 6.0   # logits of several tens: near one-hot rows
+    k = torch.randn(1, 500, 128, generator=g) * 6.0
+    v = torch.randn(1, 500, 128, generator=g)
+    out = ops.attention_f32(q.to(DEV), k.to(DEV), v.to(DEV), 1.0 / math.sqrt(128))
+    assert float((out.cpu().double() - _ref(q, k, v, 1.0 / math.sqrt(128))).abs().max()) < 5e-5
+    with pytest.raises(fresco_amd.FrescoHipError):
+        ops.attention_f32(q.to(DEV)[..., :48], k.to(DEV)[..., :48], v.to(DEV), 1.0)   # D = 48 unsupported
+    with pytest.raises(ValueError):
+        ops.attention_f32(q.to(DEV), k.to(DEV)[:, :10], v.to(DEV), 1.0)
