@@ -1,0 +1,274 @@
+"""GMFlow inference for FRESCO's flow / occlusion producer, in the one configuration the
+reference instantiates (run_fresco.py:38-45: feature_channels 128, one scale, upsample 8, one head, swin
+attention with 2 x 2 splits, 6 transformer blocks, global matching, global propagation, bidirectional).
+
+Reference: src/ebsynth/deps/gmflow/gmflow/{gmflow,backbone,transformer,matching,position,utils}.py.  The module
+tree carries the reference's parameter names, so `load_state_dict` takes the published checkpoint
+(gmflow_sintel-0c07dcb3.pth, `checkpoint['model']`) unchanged; everything else is written for this package:
+
+  * every attention -- window self / cross attention, shifted windows, the global correlation softmax, the
+    flow propagation -- is `fresco_attn_f32` (fp32 MFMA, csrc/attn32.hip): the flows feed integer decisions,
+    fp16 attention operands move them by 0.1 - 2 px;
+  * shifted-window attention needs no mask: the reference's additive -100 mask only separates the (at most
+    four) regions a rolled window is stitched from, so tokens are grouped by (window, region) once per
+    resolution and every group is an ordinary attention problem; equally sized groups share a launch;
+  * no roll / split / merge copies, no L x L score or mask tensors;
+  * convolutions, instance / layer norms and the linear layers are PyTorch's (MIOpen / rocBLAS), fp32.
+
+`GMFlow.forward(img0, img1, attn_splits_list=[2], corr_radius_list=[-1], prop_radius_list=[-1],
+pred_bidir_flow=True)` returns {'flow_preds': [flow]} like the reference, flow (2B, 2, H, W) in pixels.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------
+# backbone (gmflow/backbone.py): 1/8-resolution features
+# ------------------------------------------------------------------------------------------------
+class ResidualBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1, bias=False)
+        self.norm1 = nn.InstanceNorm2d(cout)
+        self.norm2 = nn.InstanceNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.norm3 = nn.InstanceNorm2d(cout)
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = F.relu(self.norm1(self.conv1(x)))
+        y = F.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return F.relu(x + y)
+
+
+class CNNEncoder(nn.Module):
+    def __init__(self, output_dim=128):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.norm1 = nn.InstanceNorm2d(64)
+        self.layer1 = nn.Sequential(ResidualBlock(64, 64, 1), ResidualBlock(64, 64, 1))
+        self.layer2 = nn.Sequential(ResidualBlock(64, 96, 2), ResidualBlock(96, 96, 1))
+        self.layer3 = nn.Sequential(ResidualBlock(96, 128, 2), ResidualBlock(128, 128, 1))
+        self.conv2 = nn.Conv2d(128, output_dim, 1)
+
+    def forward(self, x):
+        x = F.relu(self.norm1(self.conv1(x)))
+        return self.conv2(self.layer3(self.layer2(self.layer1(x))))
+
+
+# ------------------------------------------------------------------------------------------------
+# token groups of the (shifted) window attention
+# ------------------------------------------------------------------------------------------------
+def window_groups(h, w, splits, shifted, device):
+    """Partition of the h*w tokens into the sets that attend to each other (transformer.py:20-44, 48-108).
+    Plain windows: splits^2 windows.  Shifted windows: the feature map is rolled by half a window and the
+    reference's mask confines attention to tokens of the same pre-roll region, i.e. to the groups
+    (window, region) computed here in UN-rolled coordinates.  Returns a list of (idx (G, n) int64) tensors, one
+    per group size."""
+    wh, ww = h // splits, w // splits
+    sh, sw = (wh // 2, ww // 2) if shifted else (0, 0)
+    y = torch.arange(h).view(h, 1).expand(h, w)
+    x = torch.arange(w).view(1, w).expand(h, w)
+    yr, xr = (y - sh) % h, (x - sw) % w  # position after torch.roll(shifts=(-sh, -sw))
+
+    def slice_id(c, size, win, shift):  # the reference's three slices: [0, size-win), [size-win, size-shift), rest
+        if shift == 0:
+            return torch.zeros_like(c)
+        return (c >= size - win).long() + (c >= size - shift).long()
+
+    gid = (((yr // wh) * splits + (xr // ww)) * 3 + slice_id(yr, h, wh, sh)) * 3 + slice_id(xr, w, ww, sw)
+    gid = gid.reshape(-1)
+    by_size = {}
+    for g in torch.unique(gid).tolist():
+        idx = (gid == g).nonzero().squeeze(1)
+        by_size.setdefault(idx.numel(), []).append(idx)
+    return [torch.stack(v, 0).to(device) for _, v in sorted(by_size.items())]
+
+
+def grouped_attention(q, k, v, groups, scale):
+    """q, k, v (B, L, C) fp32; attention inside every token group; groups from window_groups()."""
+    B, L, C = q.shape
+    out = torch.empty_like(q)
+    for idx in groups:  # (G, n): G groups of n tokens -> one launch over B*G problems
+        G, n = idx.shape
+        flat = idx.reshape(-1)
+        qs = q[:, flat].reshape(B * G, n, C)
+        ks = k[:, flat].reshape(B * G, n, C)
+        vs = v[:, flat].reshape(B * G, n, C)
+        out[:, flat] = ops.attention_f32(qs, ks, vs, scale).reshape(B, G * n, C)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer (gmflow/transformer.py:111-293)
+# ------------------------------------------------------------------------------------------------
+class TransformerLayer(nn.Module):
+    def __init__(self, d_model, no_ffn, ffn_dim_expansion=4):
+        super().__init__()
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.no_ffn = no_ffn
+        if not no_ffn:
+            self.mlp = nn.Sequential(nn.Linear(2 * d_model, 2 * d_model * ffn_dim_expansion, bias=False), nn.GELU(),
+                                     nn.Linear(2 * d_model * ffn_dim_expansion, d_model, bias=False))
+            self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, source, target, groups):
+        C = source.shape[-1]
+        msg = grouped_attention(self.q_proj(source), self.k_proj(target), self.v_proj(target), groups,
+                                1.0 / math.sqrt(C))
+        msg = self.norm1(self.merge(msg))
+        if not self.no_ffn:
+            msg = self.norm2(self.mlp(torch.cat((source, msg), -1)))
+        return source + msg
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, d_model, ffn_dim_expansion=4):
+        super().__init__()
+        self.self_attn = TransformerLayer(d_model, True, ffn_dim_expansion)
+        self.cross_attn_ffn = TransformerLayer(d_model, False, ffn_dim_expansion)
+
+    def forward(self, source, target, groups):
+        source = self.self_attn(source, source, groups)
+        return self.cross_attn_ffn(source, target, groups)
+
+
+class FeatureTransformer(nn.Module):
+    def __init__(self, num_layers=6, d_model=128, ffn_dim_expansion=4):
+        super().__init__()
+        self.layers = nn.ModuleList([TransformerBlock(d_model, ffn_dim_expansion) for _ in range(num_layers)])
+        self._groups = {}
+
+    def _get_groups(self, h, w, splits, shifted, device):
+        key = (h, w, splits, shifted, str(device))
+        if key not in self._groups:
+            self._groups[key] = window_groups(h, w, splits, shifted, device)
+        return self._groups[key]
+
+    def forward(self, feature0, feature1, attn_num_splits):
+        b, c, h, w = feature0.shape
+        f0 = feature0.flatten(2).transpose(1, 2)
+        f1 = feature1.flatten(2).transpose(1, 2)
+        # both directions in one batch: (f0 | f1) attends to (f1 | f0)
+        x = torch.cat((f0, f1), 0)
+        for i, layer in enumerate(self.layers):
+            shifted = attn_num_splits > 1 and i % 2 == 1
+            groups = self._get_groups(h, w, attn_num_splits, shifted, x.device)
+            y = torch.cat((x[b:], x[:b]), 0)
+            x = layer(x, y, groups)
+        f0, f1 = x[:b], x[b:]
+        return (f0.transpose(1, 2).reshape(b, c, h, w).contiguous(),
+                f1.transpose(1, 2).reshape(b, c, h, w).contiguous())
+
+
+class FeatureFlowAttention(nn.Module):
+    """flow propagation: softmax(q k^T / sqrt(C)) flow, with the reference's quirk k = k_proj(q_proj(x))
+    (transformer.py:345-357) kept -- the checkpoint was trained with it"""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.q_proj = nn.Linear(in_channels, in_channels)
+        self.k_proj = nn.Linear(in_channels, in_channels)
+
+    def forward(self, feature0, flow):
+        b, c, h, w = feature0.shape
+        query = self.q_proj(feature0.flatten(2).transpose(1, 2))
+        key = self.k_proj(query)
+        value = flow.flatten(2).transpose(1, 2)
+        out = ops.attention_f32(query, key, value, 1.0 / math.sqrt(c))
+        return out.transpose(1, 2).reshape(b, flow.shape[1], h, w)
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def sine_position(c, h, w, device, temperature=10000.0):
+    """DETR-style normalised sine embedding (gmflow/position.py), (1, c, h, w)"""
+    npf = c // 2
+    ys = (torch.arange(1, h + 1, dtype=torch.float32, device=device) / (h + 1e-6) * (2 * math.pi)).view(h, 1, 1)
+    xs = (torch.arange(1, w + 1, dtype=torch.float32, device=device) / (w + 1e-6) * (2 * math.pi)).view(1, w, 1)
+    i = torch.arange(npf, dtype=torch.float32, device=device)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / npf)
+    py = (ys / dim_t).expand(h, w, npf)
+    px = (xs / dim_t).expand(h, w, npf)
+
+    def interleave(p):
+        return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), -1).flatten(-2)
+
+    return torch.cat((interleave(py), interleave(px)), -1).permute(2, 0, 1).unsqueeze(0)
+
+
+def pixel_grid(h, w, device):
+    y, x = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+    return torch.stack((x, y), 0).float()  # (2, h, w): channel 0 = x
+
+
+class GMFlow(nn.Module):
+    def __init__(self, num_scales=1, upsample_factor=8, feature_channels=128, attention_type="swin",
+                 num_transformer_layers=6, ffn_dim_expansion=4, num_head=1, **kwargs):
+        super().__init__()
+        if num_scales != 1 or attention_type != "swin" or num_head != 1:
+            raise NotImplementedError("fresco_amd.gmflow covers FRESCO's GMFlow configuration: one scale, swin "
+                                      "attention, one head (run_fresco.py:38-45)")
+        self.feature_channels = feature_channels
+        self.upsample_factor = upsample_factor
+        self.backbone = CNNEncoder(feature_channels)
+        self.transformer = FeatureTransformer(num_transformer_layers, feature_channels, ffn_dim_expansion)
+        self.feature_flow_attn = FeatureFlowAttention(feature_channels)
+        self.upsampler = nn.Sequential(nn.Conv2d(2 + feature_channels, 256, 3, 1, 1), nn.ReLU(inplace=True),
+                                       nn.Conv2d(256, upsample_factor ** 2 * 9, 1, 1, 0))
+
+    def upsample_flow(self, flow, feature):
+        """convex upsampling (gmflow.py:75-90): every fine pixel is a softmax-weighted mix of its coarse 3x3"""
+        K = self.upsample_factor
+        b, _, h, w = flow.shape
+        mask = self.upsampler(torch.cat((flow, feature), 1)).view(b, 1, 9, K, K, h, w).softmax(2)
+        nb = F.unfold(K * flow, (3, 3), padding=1).view(b, 2, 9, 1, 1, h, w)
+        up = (mask * nb).sum(2)  # (b, 2, K, K, h, w)
+        return up.permute(0, 1, 4, 2, 5, 3).reshape(b, 2, K * h, K * w)
+
+    @torch.no_grad()
+    def forward(self, img0, img1, attn_splits_list=None, corr_radius_list=None, prop_radius_list=None,
+                pred_bidir_flow=False, **kwargs):
+        if list(attn_splits_list) != [attn_splits_list[0]] or corr_radius_list[0] != -1 or prop_radius_list[0] != -1:
+            raise NotImplementedError("global matching / global propagation at one scale only")
+        splits = attn_splits_list[0]
+        dev = img0.device
+        mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+        x = torch.cat((img0, img1), 0).float()
+        feats = self.backbone((x / 255.0 - mean) / std)
+        f0, f1 = feats.chunk(2, 0)
+        b, c, h, w = f0.shape
+        if h % splits or w % splits:
+            raise ValueError("feature map %dx%d is not divisible into %d x %d windows" % (h, w, splits, splits))
+        # position added per window (utils.py:69-86): the same embedding tiled over the windows
+        pos = sine_position(c, h // splits, w // splits, dev).repeat(1, 1, splits, splits)
+        f0, f1 = self.transformer(f0 + pos, f1 + pos, splits)
+        # global matching (matching.py:7-36): expected coordinate under softmax(f0 f1^T / sqrt(c)) minus own
+        grid = pixel_grid(h, w, dev)
+        gtok = grid.flatten(1).t().unsqueeze(0)  # (1, hw, 2)
+        t0 = f0.flatten(2).transpose(1, 2)
+        t1 = f1.flatten(2).transpose(1, 2)
+        if pred_bidir_flow:
+            qs, ks = torch.cat((t0, t1), 0), torch.cat((t1, t0), 0)
+        else:
+            qs, ks = t0, t1
+        corr = ops.attention_f32(qs, ks, gtok.expand(qs.shape[0], -1, -1).contiguous(), 1.0 / math.sqrt(c))
+        flow = corr.transpose(1, 2).reshape(-1, 2, h, w) - grid.unsqueeze(0)
+        feature0 = torch.cat((f0, f1), 0) if pred_bidir_flow else f0
+        flow = self.feature_flow_attn(feature0, flow)
+        return {"flow_preds": [self.upsample_flow(flow, feature0)]}

@@ -74,3 +74,36 @@ def video_case(N, H, W):
     u8 = torch.round((img * 0.5 + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
     frames = [u8[i].permute(1, 2, 0).contiguous().numpy() for i in range(N)]
     return frames, flow(N, H, W, +1.0), flow(N, H, W, -1.0)
+
+
+def gmflow_param(name, shape):
+    """Closed-form stand-in weights for the flow network (the published checkpoint is not available):
+    a deterministic function of the parameter's NAME and SHAPE only, so that the reference model (fixture
+    generation) and fresco_amd.gmflow (GPU test) are filled identically without shipping a state dict.
+    Matrices / kernels ~ unit-variance / sqrt(fan_in); LayerNorm scales ~ 1; biases small."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    seed = sum((i + 1) * ord(ch) for i, ch in enumerate(name)) % 9973
+    i = torch.arange(n, dtype=torch.float64)
+    base = torch.sin(i * 0.7548776662466927 + 0.001 * seed) * torch.cos(i * 0.5698402909980532 + 0.013 * seed)
+    if len(shape) > 1:
+        fan_in = n // int(shape[0])
+        val = base * (2.0 / math.sqrt(fan_in))
+    elif name.endswith("norm1.weight") or name.endswith("norm2.weight"):
+        val = 1.0 + 0.1 * base
+    else:
+        val = 0.05 * base
+    return val.reshape(shape).float()
+
+
+def gmflow_frames(N, H, W):
+    """N float frames (N,3,H,W) in 0..255: one smooth texture translated by (2, -3) px per frame"""
+    out = []
+    for n in range(N):
+        _, c, i, j = _grid(1, 3, H, W)
+        ii, jj = i + 2.0 * n, j - 3.0 * n
+        v = (torch.sin(0.21 * ii + 0.4 * c) * torch.cos(0.17 * jj - 0.3 * c) + 0.5 * torch.sin(0.05 * ii * (c + 1) + 0.09 * jj)
+             + 0.3 * torch.sin(0.9 * ii) * torch.sin(0.8 * jj))
+        out.append((v * 70.0 + 128.0).clamp(0, 255)[0])
+    return torch.stack(out, 0).float()
