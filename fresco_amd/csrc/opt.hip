@@ -683,21 +683,46 @@ __global__ __launch_bounds__(256) void sv_kernel(const float* __restrict__ vt,
 // fp16-split Gram step:  G = Vh Vh^T + Vh Vl^T + Vl Vh^T  (the Vl Vl^T term is < 2^-22) on
 // v_mfma_f32_32x32x16_f16 -- 3/16 of the matrix-pipe time of gram_kernel at fp32-class accuracy (every
 // product is exact in the fp32 accumulator; |V| <= 1, so Vh + Vl carries V to an absolute 2^-25).
-// Both MFMA operands need a pixel's 8 consecutive channels, i.e. V pixel-major: vsplit_t_kernel writes
+// Both MFMA operands need a pixel's 8 consecutive channels, i.e. V pixel-major: normalize_split_kernel writes
 // Vp = Vph + Vpl as (B, hw, C) halfs (64 x 64 tiles transposed through LDS), gram16_kernel stages 128-pixel x
 // 32-channel tiles of the four operands in ONE LDS stage (40 KB -> 4 workgroups per CU; the next chunk
 // waits in registers), rows of 64 B + 16 B pad (conflict-free ds_read_b128).
 // Upper-triangular tiles + mirrored sign tile (gram_epilogue<0>).  Requires C % 8 == 0.
 // ------------------------------------------------------------------------------------------------
+// Normalisation for the fp16-split GEMMs, one pass over x (same arithmetic and summation order as normalize_kernel): the 64 x 64
+// tile of normalised values is written channel-major (vt fp32, vh / vl halfs: operands of S V) straight from the
+// registers and pixel-major (vph / vpl: operands of the Gram product) through the LDS transpose.
 // grid (ceil(hw/64), ceil(C/64), B), 256 threads
-__global__ __launch_bounds__(256) void vsplit_t_kernel(const float* __restrict__ vt, half_t* __restrict__ vph,
-                                                        half_t* __restrict__ vpl, int C, int hw) {
+__global__ __launch_bounds__(256) void normalize_split_kernel(const float* __restrict__ cs,
+                                                               const float* __restrict__ part, float* __restrict__ vt,
+                                                               float* __restrict__ nrm, half_t* __restrict__ vh,
+                                                               half_t* __restrict__ vl, half_t* __restrict__ vph,
+                                                               half_t* __restrict__ vpl, int C, int hw, int S) {
     __shared__ float tile[64][65];
+    __shared__ float nn[64];
     const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const float* src = vt + (int64_t)b * C * hw;
+    if (threadIdx.x < 64) {
+        const int p = p0 + threadIdx.x;
+        float ss = 0.f;
+        if (p < hw)
+            for (int s = 0; s < S; ++s) ss += part[((int64_t)b * S + s) * hw + p];
+        const float n = sqrtf(ss);
+        nn[threadIdx.x] = n;
+        if (blockIdx.y == 0 && p < hw) nrm[(int64_t)b * hw + p] = n;
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int c = i >> 6, p = i & 63;
-        tile[c][p] = (c0 + c < C && p0 + p < hw) ? src[(int64_t)(c0 + c) * hw + p0 + p] : 0.f;
+        float val = 0.f;
+        if (c0 + c < C && p0 + p < hw) {
+            const int64_t o = ((int64_t)b * C + c0 + c) * hw + p0 + p;
+            val = cs[o] / nn[p];
+            vt[o] = val;
+            const half_t hi16 = (half_t)val;
+            vh[o] = hi16;
+            vl[o] = (half_t)(val - (float)hi16);
+        }
+        tile[c][p] = val;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
@@ -1049,15 +1074,17 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
             ProfScope ps(FRESCO_PROF_OPT_COLNORM, B, C, hw, 0, st);
             hipLaunchKernelGGL((chan_partial_kernel<0>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, cs,
                                (const float*)nullptr, w.part, C, hw, S);
-            hipLaunchKernelGGL(normalize_kernel, egrid, dim3(256), 0, st, cs, w.part, w.vt, w.nrm,
-                               f16_sv ? w.vh : (half_t*)nullptr, f16_sv ? w.vl : (half_t*)nullptr, C, hw, S);
+            if (f16_sv && C % 8 == 0)
+                hipLaunchKernelGGL(normalize_split_kernel, dim3((hw + 63) / 64, (C + 63) / 64, B), dim3(256), 0, st, cs,
+                                   w.part, w.vt, w.nrm, w.vh, w.vl, w.vph, w.vpl, C, hw, S);
+            else
+                hipLaunchKernelGGL(normalize_kernel, egrid, dim3(256), 0, st, cs, w.part, w.vt, w.nrm,
+                                   f16_sv ? w.vh : (half_t*)nullptr, f16_sv ? w.vl : (half_t*)nullptr, C, hw, S);
         }
         const int nt = (hw + GT - 1) / GT;
         {
             ProfScope ps(FRESCO_PROF_OPT_GRAM, B, C, hw, 0, st);
             if (f16_sv && C % 8 == 0) {
-                hipLaunchKernelGGL(vsplit_t_kernel, dim3((hw + 63) / 64, (C + 63) / 64, B), dim3(256), 0, st, w.vt,
-                                   w.vph, w.vpl, C, hw);
                 hipLaunchKernelGGL(gram16_kernel, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vph, w.vpl, target,
                                    w.ssign, loss ? loss + 1 : nullptr, C, hw);
             } else
