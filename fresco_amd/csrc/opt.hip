@@ -278,12 +278,14 @@ __global__ __launch_bounds__(256) void temporal_grad_kernel(
 // Per-pixel reductions over channels, in two deterministic steps so that small planes (8x8 .. 32x32)
 // still fill the chip: (1) partial sums over one of S channel slices: block = 64 pixels x 4
 // sub-slices, grid (ceil(hw/64), S, B), written to part[b][s][p]; (2) an elementwise kernel adds the S
-// partials in a fixed order.  MODE 0: sum x^2 (column norms), MODE 1: sum x*y (<V, dV>).
+// partials in a fixed order.  MODE 0: sum x^2 (column norms), MODE 1: sum x*y (<V, dV>), MODE 2: sum (x/n[p])*y
+// (<V, dV> with V = X/|X| rebuilt from X: the same quotient normalize wrote, so V need not be stored).
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ y,
-                                                            float* __restrict__ part, int C, int hw, int S) {
+                                                            float* __restrict__ part, int C, int hw, int S,
+                                                            const float* __restrict__ nrm = nullptr) {
     __shared__ float red[4][64];
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + px;
@@ -292,11 +294,13 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restri
     const int cbeg = s * cper, cend = min(cbeg + cper, C);
     const int64_t base = (int64_t)b * C * hw;
     float acc = 0.f;
-    if (p < hw)
+    if (p < hw) {
+        const float n = (MODE == 2) ? nrm[(int64_t)b * hw + p] : 1.f;
         for (int c = cbeg + sl; c < cend; c += 4) {
             const int64_t o = base + (int64_t)c * hw + p;
-            acc = (MODE == 0) ? fmaf(x[o], x[o], acc) : fmaf(x[o], y[o], acc);
+            acc = (MODE == 0) ? fmaf(x[o], x[o], acc) : (MODE == 1 ? fmaf(x[o], y[o], acc) : fmaf(x[o] / n, y[o], acc));
         }
+    }
     red[sl][px] = acc;
     __syncthreads();
     if (sl == 0 && p < hw) part[((int64_t)b * S + s) * hw + p] = red[0][px] + red[1][px] + red[2][px] + red[3][px];
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
         if (c0 + c < C && p0 + p < hw) {
             const int64_t o = ((int64_t)b * C + c0 + c) * hw + p0 + p;
             val = cs[o] / nn[p];
-            vt[o] = val;
+            if (vt) vt[o] = val;
             const half_t hi16 = (half_t)val;
             vh[o] = hi16;
             vl[o] = (half_t)(val - (float)hi16);
@@ -970,15 +974,17 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= hw) return;
     const int b = blockIdx.z, c0 = blockIdx.y * ECPT, cend = min(c0 + ECPT, C);
-    float dot = 0.f, inv_n = 0.f;
+    float dot = 0.f, inv_n = 0.f, n = 1.f;
     if (has_s) {
         for (int s = 0; s < S; ++s) dot += part[((int64_t)b * S + s) * hw + p];
-        inv_n = 1.f / nrm[(int64_t)b * hw + p];
+        n = nrm[(int64_t)b * hw + p];
+        inv_n = 1.f / n;
     }
     for (int c = c0; c < cend; ++c) {
         const int64_t o = ((int64_t)b * C + c) * hw + p;
         float g = has_t ? grad_t[o] : 0.f;
-        if (has_s) g += (dvt[o] - vt[o] * dot) * inv_n;
+        const float x = cs[o];
+        if (has_s) g += (dvt[o] - (vt ? vt[o] : x / n) * dot) * inv_n;  // vt == nullptr: V = X/|X| rebuilt (same quotient)
         if (mode == 1) {
             gout[o] = g;
         } else {
@@ -987,7 +993,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
             m[o] = mm;
             v2[o] = vv;
             const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
-            cs[o] = cs[o] - a.step_size * (mm / denom);
+            cs[o] = x - a.step_size * (mm / denom);
         }
     }
 }
@@ -1074,9 +1080,9 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
             ProfScope ps(FRESCO_PROF_OPT_COLNORM, B, C, hw, 0, st);
             hipLaunchKernelGGL((chan_partial_kernel<0>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, cs,
                                (const float*)nullptr, w.part, C, hw, S);
-            if (f16_sv && C % 8 == 0)
+            if (f16_sv && C % 8 == 0)  // both GEMMs read the fp16 split: the fp32 V is not stored at all
                 hipLaunchKernelGGL(normalize_split_kernel, dim3((hw + 63) / 64, (C + 63) / 64, B), dim3(256), 0, st, cs,
-                                   w.part, w.vt, w.nrm, w.vh, w.vl, w.vph, w.vpl, C, hw, S);
+                                   w.part, (float*)nullptr, w.nrm, w.vh, w.vl, w.vph, w.vpl, C, hw, S);
             else
                 hipLaunchKernelGGL(normalize_kernel, egrid, dim3(256), 0, st, cs, w.part, w.vt, w.nrm,
                                    f16_sv ? w.vh : (half_t*)nullptr, f16_sv ? w.vl : (half_t*)nullptr, C, hw, S);
@@ -1103,11 +1109,18 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         }
     }
     ProfScope ps(FRESCO_PROF_OPT_ADAM, B, C, hw, 0, st);
-    if (has_s)
-        hipLaunchKernelGGL((chan_partial_kernel<1>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, w.vt, w.dvt,
-                           w.part, C, hw, S);
-    hipLaunchKernelGGL(adam_update_kernel, egrid, dim3(256), 0, st, cs, w.m, w.v, w.grad, w.vt, w.dvt, w.nrm,
-                       w.part, gout, C, hw, S, has_t, has_s, mode, a);
+    const bool v_stored = !(has_s && (hw % 16 == 0) && sv_mode == 0 && C % 8 == 0);
+    if (has_s) {
+        if (v_stored)
+            hipLaunchKernelGGL((chan_partial_kernel<1>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, w.vt, w.dvt,
+                               w.part, C, hw, S, (const float*)nullptr);
+        else
+            hipLaunchKernelGGL((chan_partial_kernel<2>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, cs, w.dvt,
+                               w.part, C, hw, S, w.nrm);
+    }
+    hipLaunchKernelGGL(adam_update_kernel, egrid, dim3(256), 0, st, cs, w.m, w.v, w.grad,
+                       v_stored ? w.vt : (const float*)nullptr, w.dvt, w.nrm, w.part, gout, C, hw, S, has_t, has_s, mode,
+                       a);
 }
 
 // loss[0], loss[1] hold raw sums after opt_closure; scale them to the reference's means
