@@ -352,6 +352,8 @@ def main():
                         frac=round(ach / PEAK_F16_DENSE, 4), traffic=pmc_traffic_bytes("attn_flash_kernelILi40"),
                         algorithmic_bytes_per_launch=int(2 * B_loc * HW3 * 320 * 2 + 2 * 2 * M3 * 320 * 2),
                         launches=len(dom),
+                        note="peak = spec figure; a pure-MFMA micro-kernel sustains 1.6-1.85 PFLOP/s on these boxes "
+                             "(profiles/r01_mfma_peak_ubench.txt)",
                         avg_launch_us=round(mean_s * 1e6, 2), algorithmic_flop_per_launch=flop)
     by_tag = {}
     for tag, d, ms in recs:
