@@ -48,7 +48,9 @@ class FRESCOAttnProcessor2_0:
             # the decision and the stacked weight are cached per (module, projection set) and re-validated by
             # the identity of the modules and the (address, version) of their weights
             key = (id(attn), names)
-            sig = tuple((id(m), m.weight.data_ptr(), m.weight._version) for m in mods)
+            ws = [getattr(m, "weight", None) for m in mods]  # exotic wrappers may not expose one: never fused
+            sig = tuple((id(m), 0, 0) if not torch.is_tensor(w) else (id(m), w.data_ptr(), w._version)
+                        for m, w in zip(mods, ws))
             hit = self._wcat_cache.get(key)
             if hit is None or hit[0] != sig:
                 if len(self._wcat_cache) > 64:
