@@ -16,7 +16,8 @@
 // 40 us.  K = 640, M = 16384: 57 vs 77 us fused, but 30 vs 25 us for a single projection (the caller keeps the
 // library GEMM there).  Where the 57 us go: 13 us output stores (kernel without them: 45 us), the rest the
 // DMA -> 20 MFMA -> barrier steps at ~36 % of the MFMA rate; a 3-deep LDS ring with counted vmcnt (slab two steps
-// ahead in flight) and 256-row workgroups (half the weight traffic) were measured: equal / 20 % slower.
+// ahead in flight), 256-row workgroups (half the weight traffic) and pairing two tiles' stores into whole 128-byte
+// lines were measured: equal / 20 % slower / 12 % slower.
 #include "common.h"
 
 namespace fresco {
