@@ -33,6 +33,11 @@ def _epe(a, b):
     return (a - b).pow(2).sum(1).sqrt()
 
 
+def _att64(q, k, v, scale):
+    s = (q.double() @ k.double().transpose(1, 2)) * scale
+    return (torch.softmax(s, -1) @ v.double()).float()
+
+
 def test_parameter_names_are_the_checkpoints(gm_golden):
     """`load_state_dict` of the published checkpoint needs exactly the reference's names"""
     _, names = _model("cpu")
@@ -49,6 +54,25 @@ def test_window_groups_partition_tokens():
         assert sizes == ([24] * 4 if not shifted else [6] * 4 + [12] * 4 + [24])
 
 
+@pytest.mark.parametrize("h,w,splits", [(8, 12, 2), (16, 16, 2), (12, 8, 4), (6, 10, 1)])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_grouped_attention_equals_the_masked_window_form(h, w, splits, shifted, monkeypatch):
+    """token groups (no roll, no mask) == the reference's roll + split + additive -100 mask + merge + roll back"""
+    import fresco_amd.gmflow as G
+    import fresco_amd.ops as ops
+    from oracle import gmflow_oracle as GO
+    if splits == 1 and shifted:
+        pytest.skip("no shifted form without windows")
+    monkeypatch.setattr(ops, "attention_f32", _att64)
+    g = torch.Generator().manual_seed(h * 100 + w + splits)
+    q, k, v = (torch.randn(3, h * w, 16, generator=g) for _ in range(3))
+    groups = G.window_groups(h, w, splits, shifted, "cpu")
+    ours = G.grouped_attention(q, k, v, groups, 1.0 / 16 ** 0.5)
+    ref = GO.swin_attention(q.double(), k.double(), v.double(), h, w, splits, shifted)
+    # exp(-100) of leakage across regions is all that separates the two
+    assert float((ours.double() - ref).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("tag", ["b"])
 def test_gmflow_architecture_cpu_with_stub_attention(gm_golden, tag, monkeypatch):
     import fresco_amd.ops as ops
@@ -61,11 +85,6 @@ def test_gmflow_architecture_cpu_with_stub_attention(gm_golden, tag, monkeypatch
     ref = torch.from_numpy(gm_golden["flow_" + tag])
     assert tuple(flow.shape) == tuple(ref.shape)
     assert float(_epe(flow, ref).max()) < 5e-3   # fp32 op order; hard region split vs the additive -100 mask
-
-
-def _att64(q, k, v, scale):
-    s = (q.double() @ k.double().transpose(1, 2)) * scale
-    return (torch.softmax(s, -1) @ v.double()).float()
 
 
 @pytest.mark.gpu
