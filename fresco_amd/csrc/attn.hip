@@ -2,25 +2,33 @@
 // cross-frame passes (reference: src/diffusion_hacked.py:225-247, 250-254, 281-285, 303-305, 371).
 //
 // Two kernels:
-//   kv_pack_kernel  : gathers the selected K / V rows of one key group and writes them in the
-//                     tile order the MFMA loop consumes:  Kp[g][h][Mpad][DPK]  (rows = keys, head
-//                     dim zero-padded to a multiple of 16) and  Vt[g][h][DPV][Mpad]  (V transposed:
-//                     rows = head dim padded to a multiple of 32, keys contiguous).  HBM-bound.
-//   attn_flash_kernel: flash-style attention on v_mfma_f32_32x32x16_f16.  One wave owns 32 query
-//                     rows; S^T = K Q^T is computed "swapped" so that every lane holds the scores
-//                     of ONE query (its column of the 32x32 MFMA C tile): the exponentiated scores
-//                     are already laid out as the B operand of  O^T = V^T P^T.
-//                     K / V^T tiles of 64 keys are DMA'd into double-buffered LDS whose row strides
-//                     are odd multiples of 16 B (conflict-free ds_read_b128).
+//   kv_pack_kernel  : gathers the selected K / V rows of one key group and writes, per 64-key tile, the
+//                     exact LDS image the MFMA loop consumes (K fragments ‖ V^T fragments, 16-byte chunks
+//                     in ds_read_b128-conflict-free order).  HBM-bound, a few MB.
+//   attn_flash_kernel: flash-style attention.  One wave owns 32*QB query rows, a workgroup 4 waves.
+//                     S^T = K Q^T runs on v_mfma_f32_32x32x16_f16 "swapped", so every lane holds the scores
+//                     of ONE query (its column of the 32x32 C tile) and the softmax needs no cross-lane
+//                     traffic.  The exponentiated scores are packed to fp16 and one v_permlane16_swap per
+//                     register turns the 32x32 C layout into the B operand of v_mfma_f32_16x16x32_f16, on
+//                     which O^T = V^T P^T runs: 16-row output tiles, so a head dim of 40 pays for 48 rows
+//                     (not 64), the spare row 40 holding ones and delivering the softmax denominator.
+//                     Key tiles arrive by DMA (global_load_lds_dwordx4, a linear 1 KiB copy per wave
+//                     instruction) into a 3-deep LDS ring, two tiles ahead, behind counted vmcnt waits and
+//                     ONE workgroup barrier per tile; K fragments for tile t+1 are read into registers
+//                     before the PV MFMAs of tile t, V^T fragments of tile t before its softmax, so no
+//                     MFMA waits on an LDS round trip.
 //                     The softmax bookkeeping rides in the MFMAs wherever the head dim leaves room:
-//                     a ones ROW in V^T makes the PV product deliver the row sum, a ones COLUMN in K
-//                     against -m in Q's spare column makes the QK product subtract the running max.
+//                     the ones ROW in V^T, and a ones COLUMN in K against -m in Q's spare column makes the
+//                     QK product subtract the running max.
 //                     Per wave, from the key norms kv_pack records (Cauchy-Schwarz bound on the logits):
 //                     the max search is dropped when no exponent can leave fp16 range, and the exponent
 //                     scale is folded into the fp16 Q only while that costs no more than P's own rounding.
 //
-// MFMA 32x32x16 f16 operand layout used below (gfx950): lane l supplies 8 consecutive k for
-// row/col (l & 31), k-chunk (l >> 5); C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
+// MFMA operand layouts used below (gfx950):
+//   32x32x16 f16: lane l supplies 8 consecutive k for row/col (l & 31), k-chunk (l >> 5);
+//                 C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = 0..15.
+//   16x16x32 f16: lane l supplies 8 consecutive k for row/col (l & 15), k-chunk (l >> 4);
+//                 C/D: col = l & 15, row = 4*(l >> 4) + r, r = 0..3.
 #include "common.h"
 #include <type_traits>
 
@@ -29,40 +37,32 @@ namespace fresco {
 template <int D>
 struct AttnCfg {
     static constexpr int DPK = (D + 15) / 16 * 16;  // head dim padded for the QK^T contraction
-    static constexpr int DPV = (D + 31) / 32 * 32;  // head dim padded for the O^T row blocks
+    static constexpr int DPV = (D + 15) / 16 * 16;  // head dim padded to whole 16-row blocks of O^T
     static constexpr int NKS = DPK / 16;            // MFMA k-steps per QK^T block
-    static constexpr int NDB = DPV / 32;            // 32-row blocks of O^T
-    static constexpr int NKC = DPK / 8;             // 16-byte chunks per K row
-    static constexpr int KROW = DPK * 2 + (((DPK * 2 / 16) % 2 == 0) ? 16 : 0);  // LDS bytes per K row
-    static constexpr int VROW = 64 * 2 + 16;                                     // LDS bytes per V^T row
-    static constexpr int KCR = KROW / 16;  // 16-byte chunks per LDS K row (data + pad)
-    static constexpr int VCR = VROW / 16;
-    static constexpr int KTILE = 64 * KROW;                          // multiple of 1 KiB (64 rows)
-    static constexpr int VTILE = (DPV * VROW + 1023) / 1024 * 1024;  // rounded up: whole 1 KiB DMA pieces
-    static constexpr int KDMA = KTILE / 1024;                        // wave-level DMA instructions per tile
-    static constexpr int VDMA = VTILE / 1024;
-    static constexpr int NP = KDMA + VDMA;      // 1 KiB DMA pieces per tile
-    static constexpr int PW = (NP + 3) / 4;     // pieces per wave and tile (the last ones may be pad pieces)
-    static constexpr int BUFB = PW * 4 * 1024;  // LDS bytes per buffer: K tile, V^T tile, pad pieces
-    static constexpr int LDS_BYTES = 2 * BUFB;
-    static constexpr int KCH = 64 * NKC;  // 16-byte chunks in a K tile
-    static constexpr int VCH = DPV * 8;   // 16-byte chunks in a V^T tile
+    static constexpr int NDT = DPV / 16;            // 16-row blocks of O^T
+    // LDS / packed image of one 64-key tile, in 16-byte chunks (8 halfs):
+    //   K  : chunk ((ks*2 + c)*64 + key)          = K[key][ks*16 + c*8 .. +8]          (c = MFMA k-chunk)
+    //   V^T: chunk ((kb*4 + c)*DPV + d)           = V[kb*32 + slot(c, e)][d],  e = 0..7 (kb = 32-key block)
+    //        slot(c, e) = (e & 3) + 8*(e >> 2) + 16*(c & 1) + 4*(c >> 1): the key order the permlane16-swapped
+    //        P fragments carry (see the softmax below).
+    // A 16-lane ds_read_b128 group always reads 16 different keys (or 16 different d) at a chunk stride of 1,
+    // displaced by multiples of 64 (or DPV, a multiple of 16) chunks: conflict-free without padding.
+    static constexpr int KTILE = DPK * 128;  // bytes
+    static constexpr int VTILE = DPV * 128;
+    static constexpr int TILE = KTILE + VTILE;
+    static constexpr int NP = TILE / 1024;  // 1 KiB DMA pieces per tile: DPK / 4, always a multiple of 4
+    static constexpr int PW = NP / 4;       // pieces per wave and tile
+    static_assert(NP % 4 == 0, "a tile is a whole number of 1 KiB pieces per wave");
+    static constexpr int TILE_LDS = TILE;   // LDS bytes per ring slot
+    static constexpr int NBUF = 3;
+    static constexpr int LDS_BYTES = NBUF * TILE_LDS;
     static constexpr bool ONES = DPV > D;  // spare V^T row D holds ones: the PV MFMA also yields the row sum
     static constexpr bool MCOL = DPK > D;  // spare K column D holds ones: Q column D carries -m_run, so the
                                            // QK MFMA subtracts the running max (no C operand to keep around)
-    static constexpr int KPT = (KCH + 255) / 256;
-    static constexpr int VPT = (VCH + 255) / 256;
 };
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float floatx2 __attribute__((ext_vector_type(2)));
-
-// Ablation switch for tools/ablate_attn.hip (timing experiments only; the product build uses 0):
-// 1 = no exp (P = exponent argument), 2 = no softmax VALU at all, 3 = no PV MFMAs, 4 = no QK MFMAs,
-// 5 = no K/V staging (tile 0 reused, no barrier), 6 = no LDS fragment reads (constant fragments)
-#ifndef FRESCO_ABL
-#define FRESCO_ABL 0
-#endif
 
 // online softmax: skip the O rescale while the tile max grows by less than this (log2 units);
 // P then reaches at most 2^8 = 256, far inside fp16 range, and stays exactly normalised by the row sum
@@ -72,22 +72,23 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 // largest |exponent| (log2 units) for which the scale is folded into the fp16 Q
 #define FOLD_MAX 16.0f
 
-static inline int mpad_of(int M) { return (M + 63) / 64 * 64; }
+static inline int ntiles_of(int M) { return (M + 63) / 64; }
 
 // ---------------------------------------------------------------------------------------------
-// pack: grid (Mpad/64, H, G), 256 threads
+// pack: grid (nT, H, G), 256 threads
 // ---------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__ k,
                                                        const half_t* __restrict__ v,
                                                        const int32_t* __restrict__ kv_rows,
-                                                       half_t* __restrict__ kp, half_t* __restrict__ vt,
-                                                       float* __restrict__ ktmax, int H, int M, int Mpad,
-                                                       int64_t group_rows, int64_t kv_ld) {
+                                                       char* __restrict__ img, float* __restrict__ ktmax,
+                                                       int H, int M, int nT, int64_t group_rows,
+                                                       int64_t kv_ld) {
     using Cfg = AttnCfg<D>;
     const int tile = blockIdx.x, h = blockIdx.y, g = blockIdx.z;
     __shared__ int32_t rows[64];
-    __shared__ __attribute__((aligned(16))) half_t vs[64][D + 8];  // +8 halfs: 16-B aligned rows
+    __shared__ __attribute__((aligned(16))) half_t ks[64][D + 8];  // +8 halfs: 16-B aligned rows
+    __shared__ __attribute__((aligned(16))) half_t vs[64][D + 8];
 
     if (threadIdx.x < 64) {
         const int m = tile * 64 + threadIdx.x;
@@ -97,34 +98,59 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
     }
     __syncthreads();
 
+    // stage the 64 x D slabs of K and V (each row D halfs contiguous in global memory)
     const uint4 zero = make_uint4(0, 0, 0, 0);
-    // K: 64 keys x NKC chunks, written contiguously
-    half_t* kdst = kp + ((int64_t)(g * H + h) * Mpad + tile * 64) * Cfg::DPK;
-    for (int c = threadIdx.x; c < 64 * Cfg::NKC; c += 256) {
-        const int row = c / Cfg::NKC, dc = c % Cfg::NKC;
-        uint4 val = zero;
+    for (int c = threadIdx.x; c < 64 * (D / 8); c += 256) {
+        const int row = c / (D / 8), dc = c % (D / 8);
+        uint4 kv = zero, vv = zero;
         const int32_t r = rows[row];
-        if (r >= 0 && dc * 8 < D)
-            val = *reinterpret_cast<const uint4*>(k + ((int64_t)g * group_rows + r) * kv_ld + h * D + dc * 8);
-        else if (Cfg::MCOL && r >= 0 && dc * 8 == D)
-            val.x = 0x3C00u;  // K[key][D] = 1.0: with Q[query][D] = -m the QK MFMA delivers  q.k - m
-        *reinterpret_cast<uint4*>(kdst + (int64_t)c * 8) = val;
+        if (r >= 0) {
+            const int64_t off = ((int64_t)g * group_rows + r) * kv_ld + h * D + dc * 8;
+            kv = *reinterpret_cast<const uint4*>(k + off);
+            vv = *reinterpret_cast<const uint4*>(v + off);
+        }
+        *reinterpret_cast<uint4*>(&ks[row][dc * 8]) = kv;
+        *reinterpret_cast<uint4*>(&vs[row][dc * 8]) = vv;
     }
-    // largest squared key norm of the tile (one thread per key, fixed summation order): the flash kernel
+    __syncthreads();
+
+    char* dst = img + ((int64_t)(g * H + h) * nT + tile) * Cfg::TILE;
+    // K chunks
+    for (int c = threadIdx.x; c < Cfg::NKS * 128; c += 256) {
+        const int key = c & 63, d0 = (c >> 6) * 8;
+        uint4 val = zero;
+        if (d0 < D)
+            val = *reinterpret_cast<const uint4*>(&ks[key][d0]);
+        else if (Cfg::MCOL && d0 == D && rows[key] >= 0)
+            val.x = 0x3C00u;  // K[key][D] = 1.0: with Q[query][D] = -m the QK MFMA delivers  q.k - m
+        *reinterpret_cast<uint4*>(dst + (int64_t)c * 16) = val;
+    }
+    // V^T chunks
+    for (int c = threadIdx.x; c < 8 * Cfg::DPV; c += 256) {
+        const int d = c % Cfg::DPV, cc = (c / Cfg::DPV) & 3, kb = c / (4 * Cfg::DPV);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 16 * (cc & 1) + 4 * (cc >> 1);
+            half_t val = (half_t)0;
+            if (d < D)
+                val = vs[key][d];
+            else if (Cfg::ONES && d == D && rows[key] >= 0)
+                val = (half_t)1;  // ones row: only real keys count towards the softmax denominator
+            o[e] = val;
+        }
+        *reinterpret_cast<half8_t*>(dst + Cfg::KTILE + (int64_t)c * 16) = o;
+    }
+    // largest squared key norm of the tile (four threads per key, fixed summation order): the flash kernel
     // bounds every logit of a query by |q| max|k| (Cauchy-Schwarz) and drops the running-max search when
     // that bound cannot leave fp16 range
     {
-        // four threads per key, each a fixed subset of the 16-byte chunks; combined in a fixed order
         const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
-        const int32_t r = rows[row];
         float n2 = 0.f;
-        if (r >= 0) {
-            const half_t* kr = k + ((int64_t)g * group_rows + r) * kv_ld + h * D;
-            for (int dc = part; dc < D / 8; dc += 4) {
-                const half8_t kk = *reinterpret_cast<const half8_t*>(kr + dc * 8);
+        for (int dc = part; dc < D / 8; dc += 4) {
+            const half8_t kk = *reinterpret_cast<const half8_t*>(&ks[row][dc * 8]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) n2 = fmaf((float)kk[e], (float)kk[e], n2);
-            }
+            for (int e = 0; e < 8; ++e) n2 = fmaf((float)kk[e], (float)kk[e], n2);
         }
         n2 += __shfl_xor(n2, 1, 64);
         n2 += __shfl_xor(n2, 2, 64);
@@ -134,52 +160,26 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
         if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = n2;
         __syncthreads();
         if (threadIdx.x == 0)
-            ktmax[(int64_t)(g * H + h) * (Mpad / 64) + tile] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-    }
-    // V: stage the 64 x D slab, then write it transposed
-    for (int c = threadIdx.x; c < 64 * (D / 8); c += 256) {
-        const int row = c / (D / 8), dc = c % (D / 8);
-        uint4 val = zero;
-        const int32_t r = rows[row];
-        if (r >= 0)
-            val = *reinterpret_cast<const uint4*>(v + ((int64_t)g * group_rows + r) * kv_ld + h * D + dc * 8);
-        *reinterpret_cast<uint4*>(&vs[row][dc * 8]) = val;
-    }
-    __syncthreads();
-    half_t* vdst = vt + (int64_t)(g * H + h) * Cfg::DPV * Mpad + tile * 64;
-    for (int c = threadIdx.x; c < Cfg::DPV * 8; c += 256) {
-        const int d = c >> 3, kc = c & 7;
-        half8_t o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            half_t val = (half_t)0;
-            if (d < D)
-                val = vs[kc * 8 + j][d];
-            else if (Cfg::ONES && d == D && rows[kc * 8 + j] >= 0)
-                val = (half_t)1;  // ones row: only real keys count towards the softmax denominator
-            o[j] = val;
-        }
-        *reinterpret_cast<half8_t*>(vdst + (int64_t)d * Mpad + kc * 8) = o;
+            ktmax[(int64_t)(g * H + h) * nT + tile] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // flash attention: grid (H * nQblk * B), 256 threads = 4 waves x QB blocks of 32 query rows
 // blockIdx.x = (b * nQblk + qblk) * H + h   -> head h lands on XCD (h % 8): each XCD's L2 holds
-// only its own heads' packed K / V^T.
-// QB query blocks per wave (the product instantiates QB = 1, see launch_attn).
+// only its own heads' packed key images.
 // ---------------------------------------------------------------------------------------------
-template <int D, int QB, int MINW>
+template <int D, int QB, int MINW, bool KPRE>
 __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __restrict__ q,
-                                                          const half_t* __restrict__ kp,
-                                                          const half_t* __restrict__ vt,
+                                                          const char* __restrict__ img,
                                                           const float* __restrict__ ktmax,
                                                           half_t* __restrict__ out, int B, int H, int Lq,
-                                                          int M, int Mpad, int batch_per_group,
+                                                          int M, int nT, int batch_per_group,
                                                           float scale_log2, float diag_bias_log2, int64_t q_ld) {
     using Cfg = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = 128 * QB;  // query rows per workgroup
+    constexpr int NQT = 2 * QB;     // 16-query tiles of O^T per wave
 
     const int nQblk = (Lq + ROWS - 1) / ROWS;
     const int h = blockIdx.x % H;
@@ -191,10 +191,8 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
+    const int l15 = lane & 15, l4 = lane >> 4;
     const int qrow0 = qblk * ROWS + wave * 32 * QB + l31;  // row of query block 0; block j: + 32*j
-    // S^T row (lane & 31) is fed with key  swap_bits_2_3(lane & 31): the C-tile registers of a
-    // lane then hold keys 16*(r>>3) + 8*hi + (r&7), i.e. 8 consecutive keys per MFMA k-chunk.
-    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
 
     // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
     half8_t qf[QB][Cfg::NKS];
@@ -226,10 +224,9 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     // Accumulator units u: exponent argument = cmul * u, with (qs, cmul) = (c, 1) folded or (1, c) exact.
     float kmax;
     {
-        const int nTk = Mpad / 64;
-        const float* km = ktmax + (int64_t)(g * H + h) * nTk;
+        const float* km = ktmax + (int64_t)(g * H + h) * nT;
         float k2 = 0.f;
-        for (int i = lane; i < nTk; i += 64) k2 = fmaxf(k2, km[i]);
+        for (int i = lane; i < nT; i += 64) k2 = fmaxf(k2, km[i]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, off, 64));
         kmax = sqrtf(k2);
@@ -255,46 +252,27 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     const float resc_thr = RESCALE_THR / cmul;  // thresholds and the diagonal bias in accumulator units
     const float diag_u = diag_bias_log2 / cmul;
 
-    const char* kg = reinterpret_cast<const char*>(kp + (int64_t)(g * H + h) * Mpad * Cfg::DPK);
-    const char* vg = reinterpret_cast<const char*>(vt + (int64_t)(g * H + h) * Cfg::DPV * Mpad);
-    const int nT = Mpad / 64;
-
     // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4), no register round trip ---------
-    // One wave-level instruction fills 1 KiB of LDS: destination = wave-uniform base + lane * 16, the
-    // source address is per lane.  The K tile and the V^T tile are contiguous in LDS and both whole
-    // KiB, so a tile is NP pieces (rounded up to 4 per round); piece p = i*4 + wave is issued by wave p % 4.  Everything that does
-    // not change from tile to tile is computed once: a per-lane byte offset inside the packed image
-    // (the pad chunks of the LDS row layout point at a valid dummy source) and a wave-uniform running
-    // base that advances by one tile per issue -- the loop body carries scalar adds and the DMA
-    // instructions only (no per-tile address VALU, no exec-mask branches).
+    // The packed image of a tile IS its LDS image, so a tile is NP linear 1 KiB copies; piece p = i*4 + wave
+    // is issued by wave p % 4 (destination = wave-uniform M0 base + lane*16, source per lane).  The DMA is
+    // inline asm on purpose: the compiler must not see these LDS writes, or it would drain vmcnt to zero in
+    // front of every fragment read; ordering is by the counted s_waitcnt + s_barrier in `ring_sync`.
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    uint64_t dma_addr[Cfg::PW];  // this lane's source address of piece i*4 + wave in the next tile to stage
-    int dma_step[Cfg::PW];       // bytes per tile (wave-uniform): K rows are tile-contiguous, V^T advances 64 keys
-#pragma unroll
-    for (int i = 0; i < Cfg::PW; ++i) {
-        const int p = i * 4 + wave_s;
-        const bool isk = p < Cfg::KDMA;
-        const int ck = p * 64 + lane;  // linear 16-byte chunk of the LDS K tile
-        const int krw = ck / Cfg::KCR, kdc = ck % Cfg::KCR;
-        const uint32_t koff = kdc < Cfg::NKC ? (uint32_t)(krw * Cfg::NKC + kdc) * 16u : 0u;
-        const int cv = (p - Cfg::KDMA) * 64 + lane;
-        const int vd = cv / Cfg::VCR, vkc = cv % Cfg::VCR;
-        // pieces past the tile (p >= NP, when NP is not a multiple of 4) re-read chunk 0 into the pad KiBs
-        const uint32_t voff = (vd < Cfg::DPV && vkc < 8) ? (uint32_t)(vd * Mpad + vkc * 8) * 2u : 0u;
-        dma_addr[i] = reinterpret_cast<uint64_t>(isk ? kg : vg) + (isk ? koff : voff);
-        dma_step[i] = isk ? Cfg::KCH * 16 : 128;
-    }
-    auto stage_next = [&](int buf) __attribute__((always_inline)) {  // issues the next not-yet-staged tile into LDS buffer `buf`
-        char* dst = smem + buf * Cfg::BUFB + wave_s * 1024;
+    const uint32_t lds0 =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+    const char* src = img + (int64_t)(g * H + h) * nT * Cfg::TILE + (wave_s * 64 + lane) * 16;
+    auto stage = [&](int t, int slot) __attribute__((always_inline)) {
+        const char* s = src + (int64_t)t * Cfg::TILE;
+        const uint32_t dstb = lds0 + slot * Cfg::TILE_LDS + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < Cfg::PW; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_addr[i]),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
-            dma_addr[i] += dma_step[i];
+            const char* sp = s + i * 4096;
+            const uint32_t m0v = dstb + i * 4096;
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sp), "s"(m0v) : "memory");
         }
     };
 
-    floatx16 o[QB][Cfg::NDB];
+    floatx4 o[NQT][Cfg::NDT];
     // The accumulators must come out as  c*s - m_run  (no per-score subtraction).  MCOL: -m_run rides in Q's
     // spare column D against the ones column of the packed K (m_run is kept on the fp16 grid so that the
     // value the MFMA subtracts is exactly the one the rescale factors are computed from).  Otherwise
@@ -308,14 +286,33 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
         l_run[j] = 0.f;  // row sum when V^T has no spare row for the ones-trick (this lane's keys)
 #pragma unroll
         for (int r = 0; r < 16; ++r) negm[j][r] = 0.f;
-#pragma unroll
-        for (int db = 0; db < Cfg::NDB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[j][db][r] = 0.f;
     }
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < Cfg::NDT; ++dt) o[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    stage_next(0);
-    __syncthreads();
+    // ---- prologue: tiles 0 and 1 in flight, tile 0 landed, its K fragments in registers ----------
+    stage(0, 0);
+    if (nT > 1) {
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Cfg::PW) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // per-lane fragment offsets inside a ring slot
+    const int koff = (hi * 64 + l31) * 16;                   // + (ks*128 + kb*32)*16
+    const int voff = Cfg::KTILE + (l4 * Cfg::DPV + l15) * 16;  // + (kb*4*DPV + dt*16)*16
+    half8_t kf[2][Cfg::NKS];
+    auto read_k = [&](int slot) __attribute__((always_inline)) {
+        const char* kb_ = smem + slot * Cfg::TILE_LDS + koff;
+#pragma unroll
+        for (int ks = 0; ks < Cfg::NKS; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                kf[kb][ks] = *reinterpret_cast<const half8_t*>(kb_ + (ks * 128 + kb * 32) * 16);
+    };
+    if (KPRE) read_k(0);
 
     const bool need_diag = diag_bias_log2 != 0.f;
 
@@ -325,79 +322,65 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     // argument can exceed NOMAX_THR): the running-max search and the rescale test are dropped -- P is then
     // at most 2^NOMAX_THR, inside fp16 range, and the row sum normalises it exactly as before.
     // EXACT = the wave keeps Q unscaled: scores are multiplied by c in fp32 before the exponential.
-    auto tile = [&](int t, auto fix_c, auto nomax_c, auto exact_c) __attribute__((always_inline)) {
+    auto tile = [&](int t, int slot, auto fix_c, auto nomax_c, auto exact_c) __attribute__((always_inline)) {
         constexpr bool FIX = decltype(fix_c)::value;
         constexpr bool NOMAX = decltype(nomax_c)::value;
         constexpr bool EXACT = decltype(exact_c)::value;
         const float cm = EXACT ? cmul : 1.f;
-        const int buf = (FRESCO_ABL == 5) ? 0 : (t & 1);
-        const char* kb = smem + buf * Cfg::BUFB;
-        const char* vb = kb + Cfg::KTILE;
+        const int slot1 = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
+        const int slot2 = slot1 == Cfg::NBUF - 1 ? 0 : slot1 + 1;
 
-        // ---- S^T = K Q^T : per query block two independent 32-key accumulators ------------------
+        // ---- phase 1: S^T = K Q^T, 2*QB independent 32x32 accumulators; K fragments already in registers
+        // (KPRE) or read here (large head dims, where the registers for a second fragment set are not there)
+        if (!KPRE) read_k(slot);
         floatx16 s[QB][2];
 #pragma unroll
-        for (int j = 0; j < QB; ++j) {
+        for (int j = 0; j < QB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 s[j][0][r] = Cfg::MCOL ? 0.f : negm[j][r];
                 s[j][1][r] = Cfg::MCOL ? 0.f : negm[j][r];
             }
-        }
-        const char* kr = kb + krow * Cfg::KROW + hi * 16;
 #pragma unroll
-        for (int ks = 0; ks < Cfg::NKS; ++ks) {
-            half8_t a0, a1;
-            if (FRESCO_ABL == 6) {
-                a0 = qf[0][ks];
-                a1 = qf[0][ks];
-            } else {
-                a0 = *reinterpret_cast<const half8_t*>(kr + ks * 32);
-                a1 = *reinterpret_cast<const half8_t*>(kr + 32 * Cfg::KROW + ks * 32);
-            }
+        for (int ks = 0; ks < Cfg::NKS; ++ks)
 #pragma unroll
-            for (int j = 0; j < QB; ++j) {
-                if (FRESCO_ABL == 4) {
-                    s[j][0][ks] += (float)a0[0];
-                    s[j][1][ks] += (float)a1[0];
-                } else {
-                    s[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[j][ks], s[j][0], 0, 0, 0);
-                    s[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[j][ks], s[j][1], 0, 0, 0);
-                }
-            }
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < QB; ++j)
+                    s[j][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[j][ks], s[j][kb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- phase 2: V^T fragments of this tile -> registers; DMA of tile t+2 into the slot tile t-1 left
+        half8_t vf[2][Cfg::NDT];
+        {
+            const char* vb_ = smem + slot * Cfg::TILE_LDS + voff;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int dt = 0; dt < Cfg::NDT; ++dt)
+                    vf[kb][dt] = *reinterpret_cast<const half8_t*>(vb_ + (kb * 4 * Cfg::DPV + dt * 16) * 16);
         }
+        if (t + 2 < nT) stage(t + 2, slot2);
+        __builtin_amdgcn_sched_barrier(0);
 
-        // every wave has left tile t-1 (barrier below), so its buffer can be refilled while tile t runs;
-        // issued here, the scalar adds + DMA instructions sit in the shadow of the QK MFMAs
-        // (the sites without fix-ups only run tiles t < nT - 1: there is always a next tile)
-        if (FRESCO_ABL != 5 && (!FIX || t + 1 < nT)) stage_next(buf ^ 1);
-
-        half8_t pf[QB][4];
+        // ---- phase 3: online softmax, one query per lane -> P^T fragments for the 16x16x32 PV MFMAs
+        half8_t pb[QB][2][2];  // [query block][key block][16-query half]
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
-            if (FRESCO_ABL == 2) {  // keep S live, skip all softmax arithmetic
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    asm volatile("" ::"v"(s[j][0][r]), "v"(s[j][1][r]));
-                    pf[j][r >> 3][r & 7] = (half_t)0.01f;
-                    pf[j][2 + (r >> 3)][r & 7] = (half_t)0.01f;
-                }
-                continue;
-            }
             if (FIX) {
                 const int qr = qrow0 + 32 * j;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key0 = t * 64 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    const int key0 = t * 64 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (need_diag && key0 == qr) s[j][0][r] += diag_u;
                     if (need_diag && key0 + 32 == qr) s[j][1][r] += diag_u;
                     if (key0 >= M) s[j][0][r] = -1e30f;
                     if (key0 + 32 >= M) s[j][1][r] = -1e30f;
                 }
             }
-            // ---- online softmax, one query per lane.  s = exponent argument relative to m_run; the
-            // reference point moves (and O, l are rescaled) only when the tile max exceeds it by more than
-            // RESCALE_THR -- or on tile 0, which anchors it at the row's first-tile max.
+            // s = exponent argument relative to m_run; the reference point moves (and O, l are rescaled)
+            // only when the tile max exceeds it by more than RESCALE_THR -- or on tile 0, which anchors it
+            // at the row's first-tile max.
             float mt = 0.f;
             if (!NOMAX) {
                 mt = fmaxf(s[j][0][0], s[j][1][0]);
@@ -425,44 +408,72 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
                     s[j][0][r] -= delta;
                     s[j][1][r] -= delta;
                 }
+                // O^T tiles hold query (16*sub + lane&15) of this block: fetch its factor from the lane
+                // that owns that query in the S^T layout
 #pragma unroll
-                for (int db = 0; db < Cfg::NDB; ++db)
+                for (int sub = 0; sub < 2; ++sub) {
+                    const float ao = __shfl(alpha, 16 * sub + l15, 64);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[j][db][r] *= alpha;
+                    for (int dt = 0; dt < Cfg::NDT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[2 * j + sub][dt][r] *= ao;
+                }
             }
             float psum = 0.f;
 #pragma unroll
-            for (int kbk = 0; kbk < 2; ++kbk)
+            for (int kb = 0; kb < 2; ++kb) {
+                uint32_t w[8];
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float x0 = EXACT ? s[j][kbk][r] * cm : s[j][kbk][r];
-                    const float x1 = EXACT ? s[j][kbk][r + 1] * cm : s[j][kbk][r + 1];
-                    const float p0 = (FRESCO_ABL == 1) ? x0 : __builtin_amdgcn_exp2f(x0);
-                    const float p1 = (FRESCO_ABL == 1) ? x1 : __builtin_amdgcn_exp2f(x1);
+                    const float x0 = EXACT ? s[j][kb][r] * cm : s[j][kb][r];
+                    const float x1 = EXACT ? s[j][kb][r + 1] * cm : s[j][kb][r + 1];
+                    const float p0 = __builtin_amdgcn_exp2f(x0);
+                    const float p1 = __builtin_amdgcn_exp2f(x1);
                     if (!Cfg::ONES) psum += p0 + p1;
-                    pf[j][kbk * 2 + (r >> 3)][r & 7] = (half_t)p0;
-                    pf[j][kbk * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
+                    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                    const half2_t hp = {(half_t)p0, (half_t)p1};
+                    w[r >> 1] = __builtin_bit_cast(uint32_t, hp);
                 }
+                // C layout of the 32x32 tile -> B operand of the 16x16x32 MFMA: lanes 16-31 / 48-63 trade
+                // their first 8 keys for the last 8 keys of lanes 0-15 / 32-47 (one v_permlane16_swap per
+                // register): afterwards every 16-lane row holds ONE 16-query half and k-chunk (lane >> 4)
+                u32x4 lo, hi4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x2 sw = __builtin_amdgcn_permlane16_swap(w[i], w[4 + i], false, false);
+                    lo[i] = sw[0];
+                    hi4[i] = sw[1];
+                }
+                pb[j][kb][0] = __builtin_bit_cast(half8_t, lo);
+                pb[j][kb][1] = __builtin_bit_cast(half8_t, hi4);
+            }
             if (!Cfg::ONES) l_run[j] += psum;
         }
+        __builtin_amdgcn_sched_barrier(0);
 
-        // ---- O^T += V^T P^T  (row D of V^T is all ones when it is spare: O^T[D] = row sum) ---------
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const char* vr = vb + l31 * Cfg::VROW + (kc * 16 + hi * 8) * 2;
-#pragma unroll
-            for (int db = 0; db < Cfg::NDB; ++db) {
-                const half8_t a = (FRESCO_ABL == 6) ? qf[0][0] : *reinterpret_cast<const half8_t*>(vr + db * 32 * Cfg::VROW);
-#pragma unroll
-                for (int j = 0; j < QB; ++j) {
-                    if (FRESCO_ABL == 3)
-                        o[j][db][kc] += (float)a[0] * (float)pf[j][kc][0];
-                    else
-                        o[j][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[j][kc], o[j][db], 0, 0, 0);
-                }
-            }
+        // ---- phase 4: tile t+1 has landed (own pieces: counted vmcnt; everyone's: barrier); its K
+        // fragments go to registers under the PV MFMAs below
+        if (t + 1 < nT) {
+            if (t + 2 < nT)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Cfg::PW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (KPRE) read_k(slot1);
         }
-        if (FRESCO_ABL != 5) __syncthreads();  // also drains this wave's DMA pieces (vmcnt) before release
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- phase 5: O^T += V^T P^T  (row D of V^T is all ones when it is spare: O^T[D] = row sum)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int dt = 0; dt < Cfg::NDT; ++dt)
+#pragma unroll
+                for (int j = 0; j < QB; ++j)
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+                        o[2 * j + sub][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kb][dt], pb[j][kb][sub],
+                                                                                    o[2 * j + sub][dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     const std::integral_constant<bool, true> yes;
@@ -471,11 +482,15 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     // once `qbound` allows it; the fix-up form for the last tile (padded keys) or, with a diagonal bias, for
     // every tile.
     auto run = [&](auto exact_c) __attribute__((always_inline)) {
-        int t = 0;
+        int t = 0, slot = 0;
+        auto next = [&]() __attribute__((always_inline)) {
+            ++t;
+            slot = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
+        };
         if (!need_diag) {
             bool nomax = false;
-            for (; t < nT - 1 && !nomax; ++t) {
-                tile(t, no, no, exact_c);
+            for (; t < nT - 1 && !nomax; next()) {
+                tile(t, slot, no, no, exact_c);
                 if (t == 0) {
                     bool safe = true;
 #pragma unroll
@@ -483,9 +498,9 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
                     nomax = __builtin_amdgcn_readfirstlane((int)__all(safe)) != 0;
                 }
             }
-            for (; t < nT - 1; ++t) tile(t, no, yes, exact_c);
+            for (; t < nT - 1; next()) tile(t, slot, no, yes, exact_c);
         }
-        for (; t < nT; ++t) tile(t, yes, no, exact_c);
+        for (; t < nT; next()) tile(t, slot, yes, no, exact_c);
     };
     if (folded)
         run(no);
@@ -493,52 +508,53 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
         run(yes);
 
     // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
+    // O^T tile (qt, dt): lane holds query 16*qt + (lane & 15), head dims 16*dt + 4*(lane >> 4) + 0..3
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
-        float l_tot;
-        if (Cfg::ONES) {
-            // O^T row D: C-tile row rr = D % 32 lives in register (rr&3) + 4*(rr>>3) of lanes with hi = (rr>>2)&1
-            constexpr int rr = D % 32;
-            l_tot = __shfl(o[j][D / 32][(rr & 3) + 4 * (rr >> 3)], l31 + 32 * ((rr >> 2) & 1), 64);
-        } else {
-            l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
-        }
-        const float inv = 1.f / l_tot;
-        const int qr = qrow0 + 32 * j;
-        if (qr < Lq) {
-            half_t* op = out + ((int64_t)b * Lq + qr) * C + h * D;
+        float l_s = 0.f;  // row sum in the S^T layout (query = lane & 31)
+        if (!Cfg::ONES) l_s = l_run[j] + __shfl_xor(l_run[j], 32, 64);
 #pragma unroll
-            for (int db = 0; db < Cfg::NDB; ++db)
+        for (int sub = 0; sub < 2; ++sub) {
+            const int qt = 2 * j + sub;
+            float l_tot;
+            if (Cfg::ONES) {
+                // O^T row D: tile D/16, C row D%16 lives in register (D%4) of the lanes with (lane >> 4) == (D%16)/4
+                l_tot = __shfl(o[qt][D / 16][D % 4], l15 + 16 * ((D % 16) / 4), 64);
+            } else {
+                l_tot = __shfl(l_s, 16 * sub + l15, 64);
+            }
+            const float inv = 1.f / l_tot;
+            const int qr = qblk * ROWS + wave * 32 * QB + 16 * qt + l15;
+            if (qr < Lq) {
+                half_t* op = out + ((int64_t)b * Lq + qr) * C + h * D;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int d0 = db * 32 + g4 * 8 + hi * 4;
+                for (int dt = 0; dt < Cfg::NDT; ++dt) {
+                    const int d0 = dt * 16 + l4 * 4;
                     if (d0 < D) {
                         half4_t w;
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) w[jj] = (half_t)(o[j][db][g4 * 4 + jj] * inv);
+                        for (int jj = 0; jj < 4; ++jj) w[jj] = (half_t)(o[qt][dt][jj] * inv);
                         *reinterpret_cast<half4_t*>(op + d0) = w;
                     }
                 }
+            }
         }
     }
 }
 
-template <int D, int QB, int MINW>
-static void launch_flash(const half_t* q, const half_t* kp, const half_t* vt, half_t* out, int B, int H,
-                         int Lq, int M, int Mpad, int n_groups, float scale, float diag_bias, int64_t q_ld,
-                         const float* ktmax, hipStream_t st) {
+template <int D, int QB, int MINW, bool KPRE>
+static void launch_flash(const half_t* q, const char* img, half_t* out, int B, int H, int Lq, int M, int nT,
+                         int n_groups, float scale, float diag_bias, int64_t q_ld, const float* ktmax,
+                         hipStream_t st) {
     using Cfg = AttnCfg<D>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<D, QB, MINW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        attr_set = true;
-    }
+    // (per device and cheap: set on every launch rather than cached in a process-global flag)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<D, QB, MINW, KPRE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     const int nQblk = (Lq + 128 * QB - 1) / (128 * QB);
     const float log2e = 1.4426950408889634f;
     ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
-    hipLaunchKernelGGL((attn_flash_kernel<D, QB, MINW>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
-                       kp, vt, ktmax, out, B, H, Lq, M, Mpad, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
+    hipLaunchKernelGGL((attn_flash_kernel<D, QB, MINW, KPRE>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
+                       img, ktmax, out, B, H, Lq, M, nT, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
 }
 
 template <int D>
@@ -547,29 +563,29 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
                        int64_t group_rows, float scale, float diag_bias, int64_t q_ld, int64_t kv_ld,
                        hipStream_t st) {
     using Cfg = AttnCfg<D>;
-    const int Mpad = mpad_of(M);
-    half_t* kp = reinterpret_cast<half_t*>(ws);
-    half_t* vt = kp + (size_t)n_groups * H * Mpad * Cfg::DPK;
-    float* ktmax = reinterpret_cast<float*>(vt + (size_t)n_groups * H * Mpad * Cfg::DPV);
-    dim3 pg(Mpad / 64, H, n_groups);
+    const int nT = ntiles_of(M);
+    char* img = ws;
+    float* ktmax = reinterpret_cast<float*>(ws + align_up((size_t)n_groups * H * nT * Cfg::TILE, 256));
+    dim3 pg(nT, H, n_groups);
     {
         ProfScope ps(FRESCO_PROF_KV_PACK, n_groups, H, M, D, st);
-        hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, kp, vt, ktmax, H, M, Mpad,
+        hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, img, ktmax, H, M, nT,
                            group_rows, kv_ld);
     }
-    // One query block per wave; waves per SIMD the register allocator is asked to make room for.  Measured on
-    // MI355X (round 1): two query blocks per wave (QB = 2, halves the LDS reads per MFMA) 15-25 % slower at the
-    // one or two waves per SIMD they leave; one more wave per SIMD forced by launch bounds (spills) 5 % slower.
-    constexpr int MINW = D <= 40 ? 3 : (D <= 80 ? 2 : 1);
-    launch_flash<D, 1, MINW>(q, kp, vt, out, B, H, Lq, M, Mpad, n_groups, scale, diag_bias, q_ld, ktmax, st);
+    // Two query blocks (64 rows) per wave while the accumulators leave room for two waves per SIMD: every K /
+    // V^T fragment read from LDS then feeds two (four) MFMAs.  Head dims above 64: no second K fragment set.
+    if constexpr (D <= 48 && Cfg::MCOL)
+        launch_flash<D, 2, 2, true>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
+    else
+        launch_flash<D, 1, 2, (D <= 64)>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
     return check_launch();
 }
 
 static size_t attn_ws_bytes(int n_groups, int H, int M, int D) {
-    const size_t Mpad = mpad_of(M);
-    const size_t dpk = (D + 15) / 16 * 16, dpv = (D + 31) / 32 * 32;
-    return align_up((size_t)n_groups * H * Mpad * (dpk + dpv) * sizeof(half_t) +
-                        (size_t)n_groups * H * (Mpad / 64) * sizeof(float), 256);
+    const size_t nT = ntiles_of(M);
+    const size_t dp = (D + 15) / 16 * 16;
+    return align_up((size_t)n_groups * H * nT * (2 * dp * 128), 256) +
+           align_up((size_t)n_groups * H * nT * sizeof(float), 256);
 }
 
 }  // namespace fresco
