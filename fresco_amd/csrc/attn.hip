@@ -5,30 +5,35 @@
 //   kv_pack_kernel  : gathers the selected K / V rows of one key group and writes, per 64-key tile, the
 //                     exact LDS image the MFMA loop consumes (K fragments ‖ V^T fragments, 16-byte chunks
 //                     in ds_read_b128-conflict-free order).  HBM-bound, a few MB.
-//   attn_flash_kernel: flash-style attention.  One wave owns 32*QB query rows, a workgroup 4 waves.
-//                     S^T = K Q^T runs on v_mfma_f32_32x32x16_f16 "swapped", so every lane holds the scores
-//                     of ONE query (its column of the 32x32 C tile) and the softmax needs no cross-lane
-//                     traffic.  The exponentiated scores are packed to fp16 and one v_permlane16_swap per
-//                     register turns the 32x32 C layout into the B operand of v_mfma_f32_16x16x32_f16, on
-//                     which O^T = V^T P^T runs: 16-row output tiles, so a head dim of 40 pays for 48 rows
-//                     (not 64), the spare row 40 holding ones and delivering the softmax denominator.
-//                     Key tiles arrive by DMA (global_load_lds_dwordx4, a linear 1 KiB copy per wave
-//                     instruction) into a 3-deep LDS ring, two tiles ahead, behind counted vmcnt waits and
-//                     ONE workgroup barrier per tile; K fragments for tile t+1 are read into registers
-//                     before the PV MFMAs of tile t, V^T fragments of tile t before its softmax, so no
-//                     MFMA waits on an LDS round trip.
-//                     The softmax bookkeeping rides in the MFMAs wherever the head dim leaves room:
-//                     the ones ROW in V^T, and a ones COLUMN in K against -m in Q's spare column makes the
-//                     QK product subtract the running max.
-//                     Per wave, from the key norms kv_pack records (Cauchy-Schwarz bound on the logits):
-//                     the max search is dropped when no exponent can leave fp16 range, and the exponent
-//                     scale is folded into the fp16 Q only while that costs no more than P's own rounding.
+//   attn_flash_kernel: flash-style attention on v_mfma_f32_32x32x16_f16.  One wave owns 32*QB query rows, a
+//                     workgroup 4 waves; two workgroups share a CU (two waves per SIMD, 256 registers each).
+//                     S^T = K Q^T is computed "swapped", so every lane holds the scores of ONE query (its
+//                     column of the 32x32 C tile): the softmax needs no cross-lane traffic and the
+//                     exponentiated scores, packed to fp16, already ARE the B operand of O^T = V^T P^T (the
+//                     key order inside each 16-key MFMA step is the C-tile row order; kv_pack writes V^T in it).
 //
-// MFMA operand layouts used below (gfx950):
-//   32x32x16 f16: lane l supplies 8 consecutive k for row/col (l & 31), k-chunk (l >> 5);
-//                 C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = 0..15.
-//   16x16x32 f16: lane l supplies 8 consecutive k for row/col (l & 15), k-chunk (l >> 4);
-//                 C/D: col = l & 15, row = 4*(l >> 4) + r, r = 0..3.
+// What bounds this kernel on gfx950 (tools/ubench_rates.hip, profiles/r02_ubench_rates.txt): not the matrix
+// pipe alone but the SIMD's one VALU/issue port, which v_exp_f32 holds for 8.25 cycles, v_cvt_pk_f16_f32 for
+// 4.3 and every MFMA issue for ~7 -- from either of the two waves of the SIMD; MFMA execution (32 cycles per
+// 32x32x16) overlaps with the partner wave's VALU work, but nothing overlaps on the port itself.  Per 64 keys
+// x 64 queries at D = 40: port = 64 exp + 32 cvt + 28 MFMA issues ~ 880 cycles, matrix pipe = 28 x 32 = 896.
+// Hence: as few and as large MFMAs as possible (32x32x16 for both products; a 16x16x32 PV product would save
+// pipe time but costs more issues plus a permlane per P register: measured slower), no per-score VALU besides
+// exp and cvt (the scale is folded into Q, the running max rides in the QK product, the row sum in the PV
+// product, see below), and nothing that stalls BOTH waves of a SIMD at once:
+//   * key tiles arrive by DMA (global_load_lds_dwordx4, a linear 1 KiB copy per wave instruction) into a
+//     3-slot LDS ring, two tiles ahead, behind counted vmcnt waits and ONE workgroup barrier per tile;
+//   * K fragments of tile t+1 are read into registers under the PV MFMAs of tile t, V^T fragments of tile t
+//     under its softmax, so no MFMA waits on an LDS round trip;
+//   * two query blocks per wave at D <= 48: every fragment read feeds two MFMAs.
+// The softmax bookkeeping rides in the MFMAs wherever the head dim leaves room: a ones ROW in V^T makes the
+// PV product deliver the row sum, a ones COLUMN in K against -m in Q's spare column makes the QK product
+// subtract the running max.  Per wave, from the key norms kv_pack records (Cauchy-Schwarz bound on the
+// logits): the max search is dropped when no exponent can leave fp16 range, and the exponent scale is folded
+// into the fp16 Q only while that costs no more than P's own rounding.
+//
+// MFMA 32x32x16 f16 operand layout (gfx950): lane l supplies 8 consecutive k for row/col (l & 31), k-chunk
+// (l >> 5); C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = 0..15.
 #include "common.h"
 #include <type_traits>
 
@@ -37,25 +42,21 @@ namespace fresco {
 template <int D>
 struct AttnCfg {
     static constexpr int DPK = (D + 15) / 16 * 16;  // head dim padded for the QK^T contraction
-    static constexpr int DPV = (D + 15) / 16 * 16;  // head dim padded to whole 16-row blocks of O^T
+    static constexpr int DPV = (D + 31) / 32 * 32;  // head dim padded to whole 32-row blocks of O^T
     static constexpr int NKS = DPK / 16;            // MFMA k-steps per QK^T block
-    static constexpr int NDT = DPV / 16;            // 16-row blocks of O^T
+    static constexpr int NDB = DPV / 32;            // 32-row blocks of O^T
     // LDS / packed image of one 64-key tile, in 16-byte chunks (8 halfs):
-    //   K  : chunk ((ks*2 + c)*64 + key)          = K[key][ks*16 + c*8 .. +8]          (c = MFMA k-chunk)
-    //   V^T: chunk ((kb*4 + c)*DPV + d)           = V[kb*32 + slot(c, e)][d],  e = 0..7 (kb = 32-key block)
-    //        slot(c, e) = (e & 3) + 8*(e >> 2) + 16*(c & 1) + 4*(c >> 1): the key order the permlane16-swapped
-    //        P fragments carry (see the softmax below).
-    // A 16-lane ds_read_b128 group always reads 16 different keys (or 16 different d) at a chunk stride of 1,
-    // displaced by multiples of 64 (or DPV, a multiple of 16) chunks: conflict-free without padding.
+    //   K  : chunk ((ks*2 + c)*64 + key)   = K[key][ks*16 + c*8 .. +8]                     (c = MFMA k-chunk)
+    //   V^T: chunk ((kc*2 + c)*DPV + d)    = V[kc*16 + slot(c, e)][d],  e = 0..7           (kc = 16-key MFMA step)
+    //        slot(c, e) = (e & 3) + 8*(e >> 2) + 4*c: the order in which a lane's C-tile registers hold the keys
+    // A 16-lane ds_read_b128 group reads 16 different keys (or 16 different d) at a chunk stride of 1 and one
+    // c: conflict-free without padding.
     static constexpr int KTILE = DPK * 128;  // bytes
     static constexpr int VTILE = DPV * 128;
     static constexpr int TILE = KTILE + VTILE;
-    static constexpr int NP = TILE / 1024;  // 1 KiB DMA pieces per tile: DPK / 4, always a multiple of 4
-    static constexpr int PW = NP / 4;       // pieces per wave and tile
-    static_assert(NP % 4 == 0, "a tile is a whole number of 1 KiB pieces per wave");
-    static constexpr int TILE_LDS = TILE;   // LDS bytes per ring slot
-    static constexpr int NBUF = 3;
-    static constexpr int LDS_BYTES = NBUF * TILE_LDS;
+    static constexpr int NP = TILE / 1024;  // 1 KiB DMA pieces per tile
+    static constexpr int NBUF = 3;          // ring slots
+    static constexpr int LDS_BYTES = NBUF * TILE;
     static constexpr bool ONES = DPV > D;  // spare V^T row D holds ones: the PV MFMA also yields the row sum
     static constexpr bool MCOL = DPK > D;  // spare K column D holds ones: Q column D carries -m_run, so the
                                            // QK MFMA subtracts the running max (no C operand to keep around)
@@ -73,6 +74,28 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FOLD_MAX 16.0f
 
 static inline int ntiles_of(int M) { return (M + 63) / 64; }
+
+// Wave timeline trace for tools/attn_trace.hip (not compiled into the product): s_memtime stamps at the phase
+// boundaries of tiles 8..15 of every wave, parked in the lanes of one VGPR and written out at the end.
+#ifdef FRESCO_ATTN_TRACE
+__device__ unsigned int* g_attn_trace;
+#define TR_STAMP(i) asm volatile("s_memtime %0" : "=s"(tr_ts[i]));
+#define TR_WRITELANE(val, ln)                                                                        \
+    {                                                                                                \
+        const unsigned int v_ = (val);                                                               \
+        const int l_ = __builtin_amdgcn_readfirstlane(ln);                                           \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(tr_v) : "s"(v_), "s"(l_));      \
+    }
+#define TR_COLLECT(t)                                                                                          \
+    if ((t) >= 8 && (t) < 16) {                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                    \
+                     : "+s"(tr_ts[0]), "+s"(tr_ts[1]), "+s"(tr_ts[2]), "+s"(tr_ts[3]), "+s"(tr_ts[4]), "+s"(tr_ts[5])); \
+        for (int i_ = 0; i_ < 6; ++i_) TR_WRITELANE((unsigned int)tr_ts[i_], ((t)-8) * 6 + i_)                 \
+    }
+#else
+#define TR_STAMP(i)
+#define TR_COLLECT(t)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // pack: grid (nT, H, G), 256 threads
@@ -127,11 +150,11 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
     }
     // V^T chunks
     for (int c = threadIdx.x; c < 8 * Cfg::DPV; c += 256) {
-        const int d = c % Cfg::DPV, cc = (c / Cfg::DPV) & 3, kb = c / (4 * Cfg::DPV);
+        const int d = c % Cfg::DPV, cc = (c / Cfg::DPV) & 1, kc = c / (2 * Cfg::DPV);
         half8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 16 * (cc & 1) + 4 * (cc >> 1);
+            const int key = kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * cc;
             half_t val = (half_t)0;
             if (d < D)
                 val = vs[key][d];
@@ -169,8 +192,13 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
 // blockIdx.x = (b * nQblk + qblk) * H + h   -> head h lands on XCD (h % 8): each XCD's L2 holds
 // only its own heads' packed key images.
 // ---------------------------------------------------------------------------------------------
-template <int D, int QB, int MINW, bool KPRE>
-__global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __restrict__ q,
+template <int N>
+__device__ __forceinline__ void ring_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int D, int QB>
+__global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __restrict__ q,
                                                           const char* __restrict__ img,
                                                           const float* __restrict__ ktmax,
                                                           half_t* __restrict__ out, int B, int H, int Lq,
@@ -179,7 +207,6 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     using Cfg = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = 128 * QB;  // query rows per workgroup
-    constexpr int NQT = 2 * QB;     // 16-query tiles of O^T per wave
 
     const int nQblk = (Lq + ROWS - 1) / ROWS;
     const int h = blockIdx.x % H;
@@ -191,8 +218,8 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int l15 = lane & 15, l4 = lane >> 4;
     const int qrow0 = qblk * ROWS + wave * 32 * QB + l31;  // row of query block 0; block j: + 32*j
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 
     // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
     half8_t qf[QB][Cfg::NKS];
@@ -220,7 +247,7 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     //    rounding of c*q) and the MFMA delivers exponent arguments directly.  That rounding perturbs an
     //    exponent by at most 2^-12 * c|q||k|, so it is taken only while c|q||k| <= FOLD_MAX (error of the
     //    order of P's own fp16 rounding); otherwise Q stays exact and every score is multiplied by c in fp32.
-    //  * no running-max search (NOMAX, below) when the bound cannot leave fp16 range.
+    //  * no running-max search (nomax, below) when the bound cannot leave fp16 range.
     // Accumulator units u: exponent argument = cmul * u, with (qs, cmul) = (c, 1) folded or (1, c) exact.
     float kmax;
     {
@@ -234,8 +261,8 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     bool fold_ok = true;
 #pragma unroll
     for (int j = 0; j < QB; ++j) fold_ok = fold_ok && (scale_log2 * sqrtf(q2[j]) * kmax <= FOLD_MAX);
-    // (readfirstlane: tells the compiler the vote is wave-uniform, so the paths below are scalar branches)
-    const bool folded = __builtin_amdgcn_readfirstlane((int)__all(fold_ok)) != 0;
+    // (flags are ints read from scalar values: the branches on them stay scalar branches)
+    const int folded = __builtin_amdgcn_readfirstlane((int)__all(fold_ok));
     const float qs = folded ? scale_log2 : 1.f;
     const float cmul = folded ? 1.f : scale_log2;
     float qbound[QB];  // bound on the accumulators (units u), with a margin for the roundings above
@@ -253,26 +280,41 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
     const float diag_u = diag_bias_log2 / cmul;
 
     // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4), no register round trip ---------
-    // The packed image of a tile IS its LDS image, so a tile is NP linear 1 KiB copies; piece p = i*4 + wave
-    // is issued by wave p % 4 (destination = wave-uniform M0 base + lane*16, source per lane).  The DMA is
-    // inline asm on purpose: the compiler must not see these LDS writes, or it would drain vmcnt to zero in
-    // front of every fragment read; ordering is by the counted s_waitcnt + s_barrier in `ring_sync`.
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    // A packed tile IS its LDS image, so it is NP linear 1 KiB copies; wave w issues pieces w, w+4, ...
+    // (destination = wave-uniform M0 base + lane*16, source = scalar base + one per-lane offset).  The DMA
+    // is inline asm on purpose: the compiler must not see these LDS writes, or it would drain vmcnt to zero
+    // in front of every fragment read; ordering is by the counted s_waitcnt + s_barrier of `ring_sync`.
+    constexpr int NPW_LO = Cfg::NP / 4, NPW_HI = (Cfg::NP + 3) / 4, NREM = Cfg::NP % 4;
+    const int many = wave_s < NREM ? 1 : 0;  // this wave issues NPW_HI pieces per tile (else NPW_LO)
     const uint32_t lds0 =
         __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
-    const char* src = img + (int64_t)(g * H + h) * nT * Cfg::TILE + (wave_s * 64 + lane) * 16;
-    auto stage = [&](int t, int slot) __attribute__((always_inline)) {
-        const char* s = src + (int64_t)t * Cfg::TILE;
-        const uint32_t dstb = lds0 + slot * Cfg::TILE_LDS + wave_s * 1024;
+    const char* src = img + (int64_t)(g * H + h) * nT * Cfg::TILE;
+    const uint32_t lane_off = (wave * 64 + lane) * 16;
+    auto stage = [&](int t, int slot) __attribute__((always_inline)) {  // tile t -> ring slot
+        const char* sp = src + (int64_t)t * Cfg::TILE;
+        const uint32_t dstb = lds0 + slot * Cfg::TILE + wave_s * 1024;
 #pragma unroll
-        for (int i = 0; i < Cfg::PW; ++i) {
-            const char* sp = s + i * 4096;
-            const uint32_t m0v = dstb + i * 4096;
-            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sp), "s"(m0v) : "memory");
+        for (int i = 0; i < NPW_HI; ++i) {
+            if (i < NPW_LO || many) {
+                const uint32_t m0v = dstb + i * 4096;
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(sp), "s"(m0v)
+                             : "memory");
+                sp += 4096;
+            }
+        }
+    };
+    // wait until at most `keep` of this wave's newest tiles are still in flight, then the workgroup barrier
+    auto wait_barrier = [&](int keep) __attribute__((always_inline)) {
+        if (keep == 0) {
+            ring_wait_barrier<0>();
+        } else if (many) {
+            ring_wait_barrier<NPW_HI>();
+        } else {
+            ring_wait_barrier<NPW_LO>();
         }
     };
 
-    floatx4 o[NQT][Cfg::NDT];
+    floatx16 o[QB][Cfg::NDB];
     // The accumulators must come out as  c*s - m_run  (no per-score subtraction).  MCOL: -m_run rides in Q's
     // spare column D against the ones column of the packed K (m_run is kept on the fp16 grid so that the
     // value the MFMA subtracts is exactly the one the rescale factors are computed from).  Otherwise
@@ -286,53 +328,54 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
         l_run[j] = 0.f;  // row sum when V^T has no spare row for the ones-trick (this lane's keys)
 #pragma unroll
         for (int r = 0; r < 16; ++r) negm[j][r] = 0.f;
+#pragma unroll
+        for (int db = 0; db < Cfg::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[j][db][r] = 0.f;
     }
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-        for (int dt = 0; dt < Cfg::NDT; ++dt) o[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: tiles 0 and 1 in flight, tile 0 landed, its K fragments in registers ----------
-    stage(0, 0);
-    if (nT > 1) {
-        stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Cfg::PW) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    // per-lane fragment offsets inside a ring slot
-    const int koff = (hi * 64 + l31) * 16;                   // + (ks*128 + kb*32)*16
-    const int voff = Cfg::KTILE + (l4 * Cfg::DPV + l15) * 16;  // + (kb*4*DPV + dt*16)*16
-    half8_t kf[2][Cfg::NKS];
-    auto read_k = [&](int slot) __attribute__((always_inline)) {
-        const char* kb_ = smem + slot * Cfg::TILE_LDS + koff;
+    // per-lane fragment offset inside a ring slot (K: + (ks*128 + kb*32)*16; V^T: + KTILE + (kc*2*DPV + db*32)*16)
+    const int koff = (hi * 64 + l31) * 16;
+    const int voff = Cfg::KTILE + (hi * Cfg::DPV + l31) * 16;
+    auto read_k = [&](half8_t (&kf)[2][Cfg::NKS], int slot) __attribute__((always_inline)) {
+        const char* kb_ = smem + slot * Cfg::TILE + koff;
 #pragma unroll
         for (int ks = 0; ks < Cfg::NKS; ++ks)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
                 kf[kb][ks] = *reinterpret_cast<const half8_t*>(kb_ + (ks * 128 + kb * 32) * 16);
     };
-    if (KPRE) read_k(0);
 
-    const bool need_diag = diag_bias_log2 != 0.f;
+    // ---- prologue: tiles 0 and 1 in flight, tile 0 landed, its K fragments in registers ----------
+    stage(0, 0);
+    if (nT > 1) stage(1, 1);
+    wait_barrier(nT > 1 ? 1 : 0);
+    half8_t kf[2][Cfg::NKS];
+    read_k(kf, 0);
 
-    // One 64-key tile.  FIX = true adds the per-element fix-ups (padded keys of the last tile,
-    // diagonal bias); it is a separate instantiation so that the common path carries none of it.
-    // NOMAX = true (only after tile 0 has anchored m_run, and only when `qbound` proves that no exponent
-    // argument can exceed NOMAX_THR): the running-max search and the rescale test are dropped -- P is then
-    // at most 2^NOMAX_THR, inside fp16 range, and the row sum normalises it exactly as before.
-    // EXACT = the wave keeps Q unscaled: scores are multiplied by c in fp32 before the exponential.
-    auto tile = [&](int t, int slot, auto fix_c, auto nomax_c, auto exact_c) __attribute__((always_inline)) {
-        constexpr bool FIX = decltype(fix_c)::value;
-        constexpr bool NOMAX = decltype(nomax_c)::value;
-        constexpr bool EXACT = decltype(exact_c)::value;
-        const float cm = EXACT ? cmul : 1.f;
+    const int need_diag = diag_bias_log2 != 0.f ? 1 : 0;
+
+    // One 64-key tile.  One loop body; what differs between tiles and waves is three wave-uniform
+    // (scalar-branch) passes in front of the exponentials:
+    //  * fix   : per-element fix-ups -- padded keys of the last tile, diagonal bias (then on every tile);
+    //  * search: running-max search + deferred rescale.  Dropped (nomax) after tile 0 has anchored m_run when
+    //            `qbound` proves that no exponent argument can exceed NOMAX_THR: P is then at most
+    //            2^NOMAX_THR, inside fp16 range, and the row sum normalises it exactly as before;
+    //  * exact : the wave keeps Q unscaled: scores are multiplied by c in fp32 before the exponential.
+    // LAST = the final tile: nothing to prefetch.
+    int nomax = 0;
+#ifdef FRESCO_ATTN_TRACE
+    unsigned long long tr_ts[6];
+    int tr_v = 0;
+#endif
+    auto tile = [&](int t, int slot, auto last_c) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_c)::value;
+        const int fix = LAST ? 1 : need_diag;
         const int slot1 = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
         const int slot2 = slot1 == Cfg::NBUF - 1 ? 0 : slot1 + 1;
 
-        // ---- phase 1: S^T = K Q^T, 2*QB independent 32x32 accumulators; K fragments already in registers
-        // (KPRE) or read here (large head dims, where the registers for a second fragment set are not there)
-        if (!KPRE) read_k(slot);
+        TR_STAMP(0)
+        // ---- phase 1: S^T = K Q^T, 2*QB independent 32x32 accumulators, K fragments already in registers
         floatx16 s[QB][2];
 #pragma unroll
         for (int j = 0; j < QB; ++j)
@@ -349,212 +392,192 @@ __global__ __launch_bounds__(256, MINW) void attn_flash_kernel(const half_t* __r
                 for (int j = 0; j < QB; ++j)
                     s[j][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[j][ks], s[j][kb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        TR_STAMP(1)
 
-        // ---- phase 2: V^T fragments of this tile -> registers; DMA of tile t+2 into the slot tile t-1 left
-        half8_t vf[2][Cfg::NDT];
+        // ---- phase 2: V^T fragments of this tile -> registers (in flight under the softmax); DMA of tile
+        // t+2 into the slot tile t-1 left
+        half8_t vf[4][Cfg::NDB];
         {
-            const char* vb_ = smem + slot * Cfg::TILE_LDS + voff;
+            const char* vb_ = smem + slot * Cfg::TILE + voff;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
-                for (int dt = 0; dt < Cfg::NDT; ++dt)
-                    vf[kb][dt] = *reinterpret_cast<const half8_t*>(vb_ + (kb * 4 * Cfg::DPV + dt * 16) * 16);
+                for (int db = 0; db < Cfg::NDB; ++db)
+                    vf[kc][db] = *reinterpret_cast<const half8_t*>(vb_ + (kc * 2 * Cfg::DPV + db * 32) * 16);
         }
-        if (t + 2 < nT) stage(t + 2, slot2);
+        if (!LAST && t + 2 < nT) stage(t + 2, slot2);
         __builtin_amdgcn_sched_barrier(0);
+        TR_STAMP(2)
 
-        // ---- phase 3: online softmax, one query per lane -> P^T fragments for the 16x16x32 PV MFMAs
-        half8_t pb[QB][2][2];  // [query block][key block][16-query half]
+        // ---- phase 3: online softmax, one query per lane; the packed P registers are the PV B operands
+        half8_t pf[QB][4];
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
-            if (FIX) {
+            if (fix) {
                 const int qr = qrow0 + 32 * j;
+                int kbase = t * 64 + 4 * hi;
+                asm volatile("" : "+v"(kbase));  // keeps the index arithmetic of this rare pass inside its branch
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key0 = t * 64 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int key0 = kbase + (r & 3) + 8 * (r >> 2);
                     if (need_diag && key0 == qr) s[j][0][r] += diag_u;
                     if (need_diag && key0 + 32 == qr) s[j][1][r] += diag_u;
                     if (key0 >= M) s[j][0][r] = -1e30f;
                     if (key0 + 32 >= M) s[j][1][r] = -1e30f;
                 }
             }
-            // s = exponent argument relative to m_run; the reference point moves (and O, l are rescaled)
-            // only when the tile max exceeds it by more than RESCALE_THR -- or on tile 0, which anchors it
-            // at the row's first-tile max.
-            float mt = 0.f;
-            if (!NOMAX) {
-                mt = fmaxf(s[j][0][0], s[j][1][0]);
+            // s = exponent argument (units u) relative to m_run; the reference point moves (and O, l are
+            // rescaled) only when the tile max exceeds it by more than RESCALE_THR -- or on tile 0, which
+            // anchors it at the row's first-tile max.
+            if (!nomax) {
+                float mt = fmaxf(s[j][0][0], s[j][1][0]);
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[j][0][r]), s[j][1][r]);  // v_max3_f32
                 mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            }
-            if (!NOMAX && (t == 0 || __builtin_amdgcn_readfirstlane((int)__any(mt > resc_thr)) != 0)) {
-                float delta = (t == 0) ? mt : fmaxf(mt, 0.f);
-                if (Cfg::MCOL) {
-                    // stays fp16-representable (and finite: logits beyond +-6e4 log2 units saturate)
-                    const float m_new = (float)(half_t)fminf(fmaxf(m_run[j] + delta, -6.0e4f), 6.0e4f);
-                    delta = m_new - m_run[j];
-                    m_run[j] = m_new;
-                    const half_t nm = (half_t)(-m_new);
-                    qf[j][MKS][ME] = (hi == MHI) ? nm : qf[j][MKS][ME];
-                } else {
-                    m_run[j] += delta;
+                if (t == 0 || __builtin_amdgcn_readfirstlane((int)__any(mt > resc_thr)) != 0) {
+                    float delta = (t == 0) ? mt : fmaxf(mt, 0.f);
+                    if (Cfg::MCOL) {
+                        // stays fp16-representable (and finite: logits beyond +-6e4 log2 units saturate)
+                        const float m_new = (float)(half_t)fminf(fmaxf(m_run[j] + delta, -6.0e4f), 6.0e4f);
+                        delta = m_new - m_run[j];
+                        m_run[j] = m_new;
+                        const half_t nm = (half_t)(-m_new);
+                        qf[j][MKS][ME] = (hi == MHI) ? nm : qf[j][MKS][ME];
+                    } else {
+                        m_run[j] += delta;
+                    }
+                    const float alpha = __builtin_amdgcn_exp2f(-delta * cmul);
+                    l_run[j] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (!Cfg::MCOL) negm[j][r] = -m_run[j];
+                        s[j][0][r] -= delta;
+                        s[j][1][r] -= delta;
+                    }
+#pragma unroll
+                    for (int db = 0; db < Cfg::NDB; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[j][db][r] *= alpha;
                 }
-                const float alpha = __builtin_amdgcn_exp2f(-delta * cm);
-                l_run[j] *= alpha;
+            }
+            if (!folded) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (!Cfg::MCOL) negm[j][r] = -m_run[j];
-                    s[j][0][r] -= delta;
-                    s[j][1][r] -= delta;
-                }
-                // O^T tiles hold query (16*sub + lane&15) of this block: fetch its factor from the lane
-                // that owns that query in the S^T layout
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    const float ao = __shfl(alpha, 16 * sub + l15, 64);
-#pragma unroll
-                    for (int dt = 0; dt < Cfg::NDT; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[2 * j + sub][dt][r] *= ao;
+                    s[j][0][r] *= cmul;
+                    s[j][1][r] *= cmul;
                 }
             }
             float psum = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                uint32_t w[8];
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float x0 = EXACT ? s[j][kb][r] * cm : s[j][kb][r];
-                    const float x1 = EXACT ? s[j][kb][r + 1] * cm : s[j][kb][r + 1];
-                    const float p0 = __builtin_amdgcn_exp2f(x0);
-                    const float p1 = __builtin_amdgcn_exp2f(x1);
+                    const float p0 = __builtin_amdgcn_exp2f(s[j][kb][r]);
+                    const float p1 = __builtin_amdgcn_exp2f(s[j][kb][r + 1]);
                     if (!Cfg::ONES) psum += p0 + p1;
-                    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-                    const half2_t hp = {(half_t)p0, (half_t)p1};
-                    w[r >> 1] = __builtin_bit_cast(uint32_t, hp);
+                    pf[j][kb * 2 + (r >> 3)][r & 7] = (half_t)p0;
+                    pf[j][kb * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
                 }
-                // C layout of the 32x32 tile -> B operand of the 16x16x32 MFMA: lanes 16-31 / 48-63 trade
-                // their first 8 keys for the last 8 keys of lanes 0-15 / 32-47 (one v_permlane16_swap per
-                // register): afterwards every 16-lane row holds ONE 16-query half and k-chunk (lane >> 4)
-                u32x4 lo, hi4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const u32x2 sw = __builtin_amdgcn_permlane16_swap(w[i], w[4 + i], false, false);
-                    lo[i] = sw[0];
-                    hi4[i] = sw[1];
-                }
-                pb[j][kb][0] = __builtin_bit_cast(half8_t, lo);
-                pb[j][kb][1] = __builtin_bit_cast(half8_t, hi4);
-            }
             if (!Cfg::ONES) l_run[j] += psum;
+            // (pins the exponentials in front of the barrier below: without a use here the compiler sinks the
+            // whole softmax behind the inline-asm barrier, where every wave of the workgroup runs it at once)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) asm volatile("" : "+v"(pf[j][kc]));
         }
         __builtin_amdgcn_sched_barrier(0);
+        TR_STAMP(3)
 
         // ---- phase 4: tile t+1 has landed (own pieces: counted vmcnt; everyone's: barrier); its K
         // fragments go to registers under the PV MFMAs below
-        if (t + 1 < nT) {
-            if (t + 2 < nT)
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Cfg::PW) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (KPRE) read_k(slot1);
+        if (!LAST) {
+            wait_barrier(t + 2 < nT ? 1 : 0);
+            read_k(kf, slot1);
         }
         __builtin_amdgcn_sched_barrier(0);
+        TR_STAMP(4)
 
         // ---- phase 5: O^T += V^T P^T  (row D of V^T is all ones when it is spare: O^T[D] = row sum)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
-            for (int dt = 0; dt < Cfg::NDT; ++dt)
+            for (int db = 0; db < Cfg::NDB; ++db)
 #pragma unroll
                 for (int j = 0; j < QB; ++j)
-#pragma unroll
-                    for (int sub = 0; sub < 2; ++sub)
-                        o[2 * j + sub][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kb][dt], pb[j][kb][sub],
-                                                                                    o[2 * j + sub][dt], 0, 0, 0);
+                    o[j][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kc][db], pf[j][kc], o[j][db], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        TR_STAMP(5)
     };
 
     const std::integral_constant<bool, true> yes;
     const std::integral_constant<bool, false> no;
-    // Three call sites per precision variant: search + deferred rescale from tile 0 on; without the search
-    // once `qbound` allows it; the fix-up form for the last tile (padded keys) or, with a diagonal bias, for
-    // every tile.
-    auto run = [&](auto exact_c) __attribute__((always_inline)) {
-        int t = 0, slot = 0;
-        auto next = [&]() __attribute__((always_inline)) {
-            ++t;
-            slot = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
-        };
-        if (!need_diag) {
-            bool nomax = false;
-            for (; t < nT - 1 && !nomax; next()) {
-                tile(t, slot, no, no, exact_c);
-                if (t == 0) {
-                    bool safe = true;
+    int slot = 0;
+    for (int t = 0; t < nT - 1; ++t) {
+        tile(t, slot, no);
+        TR_COLLECT(t)
+        slot = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
+        if (t == 0 && !need_diag) {
+            bool safe = true;
 #pragma unroll
-                    for (int j = 0; j < QB; ++j) safe = safe && (cmul * (qbound[j] - m_run[j]) <= NOMAX_THR);
-                    nomax = __builtin_amdgcn_readfirstlane((int)__all(safe)) != 0;
-                }
-            }
-            for (; t < nT - 1; next()) tile(t, slot, no, yes, exact_c);
+            for (int j = 0; j < QB; ++j) safe = safe && (cmul * (qbound[j] - m_run[j]) <= NOMAX_THR);
+            nomax = __builtin_amdgcn_readfirstlane((int)__all(safe));
         }
-        for (; t < nT; next()) tile(t, slot, yes, no, exact_c);
-    };
-    if (folded)
-        run(no);
-    else
-        run(yes);
+    }
+    nomax = 0;  // the last tile has padded keys at -1e30: its maximum must be looked at
+    tile(nT - 1, slot, yes);
+#ifdef FRESCO_ATTN_TRACE
+    {
+        unsigned int hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+        TR_WRITELANE(hwid, 62)
+        TR_WRITELANE(xcc, 63)
+        g_attn_trace[((size_t)blockIdx.x * 4 + wave) * 64 + lane] = (unsigned int)tr_v;
+    }
+#endif
 
     // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
-    // O^T tile (qt, dt): lane holds query 16*qt + (lane & 15), head dims 16*dt + 4*(lane >> 4) + 0..3
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
-        float l_s = 0.f;  // row sum in the S^T layout (query = lane & 31)
-        if (!Cfg::ONES) l_s = l_run[j] + __shfl_xor(l_run[j], 32, 64);
+        float l_tot;
+        if (Cfg::ONES) {
+            // O^T row D: C-tile row rr = D % 32 lives in register (rr&3) + 4*(rr>>3) of lanes with hi = (rr>>2)&1
+            constexpr int rr = D % 32;
+            l_tot = __shfl(o[j][D / 32][(rr & 3) + 4 * (rr >> 3)], l31 + 32 * ((rr >> 2) & 1), 64);
+        } else {
+            l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
+        }
+        const float inv = 1.f / l_tot;
+        const int qr = qrow0 + 32 * j;
+        if (qr < Lq) {
+            half_t* op = out + ((int64_t)b * Lq + qr) * C + h * D;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int qt = 2 * j + sub;
-            float l_tot;
-            if (Cfg::ONES) {
-                // O^T row D: tile D/16, C row D%16 lives in register (D%4) of the lanes with (lane >> 4) == (D%16)/4
-                l_tot = __shfl(o[qt][D / 16][D % 4], l15 + 16 * ((D % 16) / 4), 64);
-            } else {
-                l_tot = __shfl(l_s, 16 * sub + l15, 64);
-            }
-            const float inv = 1.f / l_tot;
-            const int qr = qblk * ROWS + wave * 32 * QB + 16 * qt + l15;
-            if (qr < Lq) {
-                half_t* op = out + ((int64_t)b * Lq + qr) * C + h * D;
+            for (int db = 0; db < Cfg::NDB; ++db)
 #pragma unroll
-                for (int dt = 0; dt < Cfg::NDT; ++dt) {
-                    const int d0 = dt * 16 + l4 * 4;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = db * 32 + g4 * 8 + hi * 4;
                     if (d0 < D) {
                         half4_t w;
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) w[jj] = (half_t)(o[qt][dt][jj] * inv);
+                        for (int jj = 0; jj < 4; ++jj) w[jj] = (half_t)(o[j][db][g4 * 4 + jj] * inv);
                         *reinterpret_cast<half4_t*>(op + d0) = w;
                     }
                 }
-            }
         }
     }
 }
 
-template <int D, int QB, int MINW, bool KPRE>
+template <int D, int QB>
 static void launch_flash(const half_t* q, const char* img, half_t* out, int B, int H, int Lq, int M, int nT,
                          int n_groups, float scale, float diag_bias, int64_t q_ld, const float* ktmax,
                          hipStream_t st) {
     using Cfg = AttnCfg<D>;
     // (per device and cheap: set on every launch rather than cached in a process-global flag)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<D, QB, MINW, KPRE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<D, QB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     const int nQblk = (Lq + 128 * QB - 1) / (128 * QB);
     const float log2e = 1.4426950408889634f;
     ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
-    hipLaunchKernelGGL((attn_flash_kernel<D, QB, MINW, KPRE>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q,
-                       img, ktmax, out, B, H, Lq, M, nT, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
+    hipLaunchKernelGGL((attn_flash_kernel<D, QB>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q, img,
+                       ktmax, out, B, H, Lq, M, nT, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
 }
 
 template <int D>
@@ -572,19 +595,19 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
         hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, img, ktmax, H, M, nT,
                            group_rows, kv_ld);
     }
-    // Two query blocks (64 rows) per wave while the accumulators leave room for two waves per SIMD: every K /
-    // V^T fragment read from LDS then feeds two (four) MFMAs.  Head dims above 64: no second K fragment set.
+    // Two query blocks (64 rows) per wave while the accumulators leave room (two waves per SIMD = 256
+    // registers each): every K / V^T fragment read from LDS then feeds two (four) MFMAs.
     if constexpr (D <= 48 && Cfg::MCOL)
-        launch_flash<D, 2, 2, true>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
+        launch_flash<D, 2>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
     else
-        launch_flash<D, 1, 2, (D <= 64)>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
+        launch_flash<D, 1>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
     return check_launch();
 }
 
 static size_t attn_ws_bytes(int n_groups, int H, int M, int D) {
     const size_t nT = ntiles_of(M);
-    const size_t dp = (D + 15) / 16 * 16;
-    return align_up((size_t)n_groups * H * nT * (2 * dp * 128), 256) +
+    const size_t dpk = (D + 15) / 16 * 16, dpv = (D + 31) / 32 * 32;
+    return align_up((size_t)n_groups * H * nT * ((dpk + dpv) * 128), 256) +
            align_up((size_t)n_groups * H * nT * sizeof(float), 256);
 }
 

@@ -1,10 +1,11 @@
 #!/bin/bash
 # PMC counter passes over the cross-frame attention kernels (separate passes, kernel-trace only).
 TAG=${1:-p}
+GAIN=${2:-1.0}
 REPO=$PWD
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
-python tools/run_attn_only.py 20 | tee $OUT/timing.txt
+python tools/run_attn_only.py 20 $GAIN | tee $OUT/timing.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
@@ -12,9 +13,11 @@ P2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACT
 P3="FETCH_SIZE"
 P4="WRITE_SIZE"
 i=0
+PASSES=${PASSES:-4}
 for P in "$P1" "$P2" "$P3" "$P4"; do
+  [ $i -ge $PASSES ] && break
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python $REPO/tools/run_attn_only.py 3 > $OUT/pass$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python $REPO/tools/run_attn_only.py 3 $GAIN > $OUT/pass$i.log 2>&1
 done
 cd $REPO
 TAG=$TAG python - <<'PY'

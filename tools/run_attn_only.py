@@ -6,12 +6,13 @@ sys.path.insert(0, ROOT)
 from fresco_amd import ops
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+gain = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0  # 0.5: logits small enough for the no-max-search path (the bench regime)
 g = torch.Generator().manual_seed(0)
 for (HW, C, D) in ((4096, 320, 40), (1024, 640, 80)):
     N, chunk, H = 8, 2, 8
     B = chunk * N
-    q = torch.randn(B, HW, C, generator=g).half().cuda()
-    k = torch.randn(B, HW, C, generator=g).half().cuda()
+    q = (gain * torch.randn(B, HW, C, generator=g)).half().cuda()
+    k = (gain * torch.randn(B, HW, C, generator=g)).half().cuda()
     v = torch.randn(B, HW, C, generator=g).half().cuda()
     mask = torch.rand(N, HW, generator=g) < 0.004
     mask[0] = True

@@ -94,27 +94,30 @@ DEFK(k_m16_e1, MIX16(E1, 0) MIX16(E1, 4) MIX16(E1, 8) MIX16(E1, 12) MIX16(E1, 16
 DEFK(k_m16_e2, MIX16(E2, 0) MIX16(E2, 4) MIX16(E2, 8) MIX16(E2, 12) MIX16(E2, 16) MIX16(E2, 20) MIX16(E2, 24) MIX16(E2, 28), 8)
 DEFK(k_m16_u2, MIX16(MULb(72) MULb(73), 0) MIX16(MULb(72) MULb(73), 4) MIX16(MULb(72) MULb(73), 8) MIX16(MULb(72) MULb(73), 12) MIX16(MULb(72) MULb(73), 16) MIX16(MULb(72) MULb(73), 20) MIX16(MULb(72) MULb(73), 24) MIX16(MULb(72) MULb(73), 28), 8)
 
-// heterogeneous pair: waves 0-3 of the first resident block run MFMAs, a second co-resident block runs exps
-__global__ __launch_bounds__(256) void k_pair(unsigned long long* out, int iters, int mode) {
-    unsigned long long t0, t1;
-    // mode 0: even blocks MFMA32, odd blocks exp;  mode 1: even MFMA32, odd mul;  mode 2: even MFMA16, odd exp
-    const bool mf = (blockIdx.x & 1) == 0;
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0));
-    if (mf) {
-        if (mode == 2) {
-            for (int it = 0; it < iters; ++it) asm volatile(".rept 8\n" MF16x8 ".endr\n" ::: CLOBBER);
-        } else {
-            for (int it = 0; it < iters; ++it) asm volatile(".rept 8\n" MF32x4 ".endr\n" ::: CLOBBER);
-        }
-    } else {
-        if (mode == 1) {
-            for (int it = 0; it < iters; ++it) asm volatile(".rept 8\n" B16(MUL) ".endr\n" ::: CLOBBER);
-        } else {
-            for (int it = 0; it < iters; ++it) asm volatile(".rept 8\n" B16(EXP) ".endr\n" ::: CLOBBER);
-        }
+// heterogeneous pair inside ONE 512-thread workgroup: waves 0-3 (one per SIMD) run body A, waves 4-7 (their
+// SIMD partners) run body B; prio = s_setprio level of the B waves
+template <int BODY>
+__device__ __forceinline__ void run_body(int iters) {
+    for (int it = 0; it < iters; ++it) {
+        if (BODY == 0) asm volatile(".rept 8\n" MF32x4 ".endr\n" ::: CLOBBER);
+        if (BODY == 1) asm volatile(".rept 8\n" B16(MUL) ".endr\n" ::: CLOBBER);
+        if (BODY == 2) asm volatile(".rept 8\n" MF16x8 ".endr\n" ::: CLOBBER);
+        if (BODY == 3) asm volatile(".rept 8\n" B16(CVT) ".endr\n" ::: CLOBBER);
+        if (BODY == 4) asm volatile(".rept 8\n" B16(EXP) ".endr\n" ::: CLOBBER);
+        if (BODY == 5) asm volatile(".rept 8\n v_permlane16_swap_b32 v0, v1\n v_permlane16_swap_b32 v2, v3\n v_permlane16_swap_b32 v4, v5\n v_permlane16_swap_b32 v6, v7\n .endr\n" ::: CLOBBER);
+        if (BODY == 6) asm volatile(".rept 8\n" B16(FMA) ".endr\n" ::: CLOBBER);
     }
+}
+template <int BA, int BB>
+__global__ __launch_bounds__(512) void k_pair(unsigned long long* out, int iters, int prio) {
+    unsigned long long t0, t1;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= 4 && prio == 1) __builtin_amdgcn_s_setprio(1);
+    __syncthreads();
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0));
+    if (w < 4) run_body<BA>(iters); else run_body<BB>(iters);
     asm volatile("s_nop 0\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1));
-    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
 typedef void (*kern_t)(unsigned long long*, int);
@@ -169,16 +172,29 @@ int main() {
     run("m16+1exp", k_m16_e1, 8, d, h);
     run("m16+2exp", k_m16_e2, 8, d, h);
     run("m16+2mul", k_m16_u2, 8, d, h);
-    for (int mode = 0; mode < 3; ++mode) {
-        const int iters = 200;
-        hipLaunchKernelGGL(k_pair, dim3(512), dim3(256), 0, 0, d, 10, mode);
-        hipLaunchKernelGGL(k_pair, dim3(512), dim3(256), 0, 0, d, iters, mode);
-        hipDeviceSynchronize();
-        hipMemcpy(h, d, 512 * 4 * 8, hipMemcpyDeviceToHost);
-        double a0 = 0, a1 = 0;
-        for (int b = 0; b < 512; ++b) for (int w = 0; w < 4; ++w) (b & 1 ? a1 : a0) += h[b * 4 + w];
-        printf("pair mode %d: MFMA waves %.1f ticks/body (4 or 8 MFMA), VALU waves %.1f ticks/body (16 inst)\n", mode,
-               a0 / (256 * 4) / (iters * 8), a1 / (256 * 4) / (iters * 8));
-    }
+    typedef void (*pk_t)(unsigned long long*, int, int);
+    struct { const char* name; pk_t k; } pairs[] = {
+        {"MFMA32 | exp", k_pair<0, 4>}, {"MFMA32 | mul", k_pair<0, 1>}, {"MFMA16 | exp", k_pair<2, 4>},
+        {"MFMA32 | cvt_pk", k_pair<0, 3>}, {"MFMA32 | MFMA32", k_pair<0, 0>}, {"exp | mul", k_pair<4, 1>},
+        {"exp | cvt_pk", k_pair<4, 3>}, {"exp | exp", k_pair<4, 4>}, {"exp | swap", k_pair<4, 5>},
+        {"cvt_pk | cvt_pk", k_pair<3, 3>}, {"mul | mul", k_pair<1, 1>}, {"fma | fma", k_pair<6, 6>},
+        {"cvt_pk | mul", k_pair<3, 1>}, {"swap | swap", k_pair<5, 5>}, {"MFMA32 | swap", k_pair<0, 5>}};
+    for (auto& pr : pairs)
+        for (int prio = 0; prio <= 1; ++prio) {
+            const int iters = 200;
+            hipLaunchKernelGGL(pr.k, dim3(256), dim3(512), 0, 0, d, 10, prio);
+            hipLaunchKernelGGL(pr.k, dim3(256), dim3(512), 0, 0, d, iters, prio);
+            hipDeviceSynchronize();
+            hipMemcpy(h, d, 256 * 8 * 8, hipMemcpyDeviceToHost);
+            double a0 = 0, a1 = 0, mn0 = 1e30, mx0 = 0, mn1 = 1e30, mx1 = 0;
+            for (int b = 0; b < 256; ++b)
+                for (int w = 0; w < 8; ++w) {
+                    const double v = (double)h[b * 8 + w] / (iters * 8);
+                    if (w < 4) { a0 += v; mn0 = v < mn0 ? v : mn0; mx0 = v > mx0 ? v : mx0; }
+                    else { a1 += v; mn1 = v < mn1 ? v : mn1; mx1 = v > mx1 ? v : mx1; }
+                }
+            printf("pair %-16s prio(B)=%2d: A waves %.1f ticks/body (min %.1f max %.1f), B waves %.1f (min %.1f max %.1f)\n",
+                   pr.name, prio, a0 / 1024, mn0, mx0, a1 / 1024, mn1, mx1);
+        }
     return 0;
 }
