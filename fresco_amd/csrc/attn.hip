@@ -55,7 +55,7 @@ struct AttnCfg {
     static constexpr int VTILE = DPV * 128;
     static constexpr int TILE = KTILE + VTILE;
     static constexpr int NP = TILE / 1024;  // 1 KiB DMA pieces per tile
-    static constexpr int NBUF = 3;          // ring slots
+    static constexpr int NBUF = 4;          // ring slots
     static constexpr int LDS_BYTES = NBUF * TILE;
     static constexpr bool ONES = DPV > D;  // spare V^T row D holds ones: the PV MFMA also yields the row sum
     static constexpr bool MCOL = DPK > D;  // spare K column D holds ones: Q column D carries -m_run, so the
@@ -75,26 +75,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static inline int ntiles_of(int M) { return (M + 63) / 64; }
 
-// Wave timeline trace for tools/attn_trace.hip (not compiled into the product): s_memtime stamps at the phase
-// boundaries of tiles 8..15 of every wave, parked in the lanes of one VGPR and written out at the end.
-#ifdef FRESCO_ATTN_TRACE
-__device__ unsigned int* g_attn_trace;
-#define TR_STAMP(i) asm volatile("s_memtime %0" : "=s"(tr_ts[i]));
-#define TR_WRITELANE(val, ln)                                                                        \
-    {                                                                                                \
-        const unsigned int v_ = (val);                                                               \
-        const int l_ = __builtin_amdgcn_readfirstlane(ln);                                           \
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(tr_v) : "s"(v_), "s"(l_));      \
-    }
-#define TR_COLLECT(t)                                                                                          \
-    if ((t) >= 8 && (t) < 16) {                                                                                \
-        asm volatile("s_waitcnt lgkmcnt(0)"                                                                    \
-                     : "+s"(tr_ts[0]), "+s"(tr_ts[1]), "+s"(tr_ts[2]), "+s"(tr_ts[3]), "+s"(tr_ts[4]), "+s"(tr_ts[5])); \
-        for (int i_ = 0; i_ < 6; ++i_) TR_WRITELANE((unsigned int)tr_ts[i_], ((t)-8) * 6 + i_)                 \
-    }
-#else
-#define TR_STAMP(i)
-#define TR_COLLECT(t)
+// Ablation switch for tools/attn_abl.hip (timing experiments only, results are wrong; the product builds 0):
+// 1 = no exp / cvt, 2 = no MFMAs, 5 = no DMA, no vmcnt wait (barrier kept), 6 = no LDS fragment reads,
+// 7 = no barrier at all (and no DMA)
+#ifndef FRESCO_ABL
+#define FRESCO_ABL 0
+#endif
+#ifndef FRESCO_PRIO_M
+#define FRESCO_PRIO_M 1
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -137,7 +125,9 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
     }
     __syncthreads();
 
-    char* dst = img + ((int64_t)(g * H + h) * nT + tile) * Cfg::TILE;
+    // pack p of the image = K fragments of tile p ‖ V^T fragments of tile p-1: what one loop step of the flash
+    // kernel reads (O^T += V^T P^T of tile p-1, S^T of tile p); nT + 1 packs
+    char* dst = img + ((int64_t)(g * H + h) * (nT + 1) + tile) * Cfg::TILE;
     // K chunks
     for (int c = threadIdx.x; c < Cfg::NKS * 128; c += 256) {
         const int key = c & 63, d0 = (c >> 6) * 8;
@@ -162,7 +152,7 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
                 val = (half_t)1;  // ones row: only real keys count towards the softmax denominator
             o[e] = val;
         }
-        *reinterpret_cast<half8_t*>(dst + Cfg::KTILE + (int64_t)c * 16) = o;
+        *reinterpret_cast<half8_t*>(dst + Cfg::TILE + Cfg::KTILE + (int64_t)c * 16) = o;
     }
     // largest squared key norm of the tile (four threads per key, fixed summation order): the flash kernel
     // bounds every logit of a query by |q| max|k| (Cauchy-Schwarz) and drops the running-max search when
@@ -188,9 +178,24 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// flash attention: grid (H * nQblk * B), 256 threads = 4 waves x QB blocks of 32 query rows
+// flash attention: grid (H * nQblk * B), 512 threads = 8 waves x QB blocks of 32 query rows
 // blockIdx.x = (b * nQblk + qblk) * H + h   -> head h lands on XCD (h % 8): each XCD's L2 holds
 // only its own heads' packed key images.
+//
+// Two waves share every SIMD, and what they share is the matrix pipe and the VALU port: left alone, the two
+// run their MFMA phases together (each at half rate) and then their softmax phases together, in lockstep
+// (measured: MFMA time + softmax time, no overlap).  So the workgroup is two groups of four waves (one per
+// SIMD each) that are held half a tile apart by WHERE in the tile they execute the workgroup's one barrier:
+//     group A:  softmax(u) | barrier | PV(u)  QK(u+1)            -> its MFMA block follows the barrier
+//     group B:  barrier | softmax(u)  PV(u)  QK(u+1)             -> its softmax follows the barrier
+// between two barriers a SIMD sees [A: 28 MFMAs || B: exp/cvt] and then [A: exp/cvt || B: 28 MFMAs].  The
+// softmax block (64 exp + 32 cvt, plus the issue slots the partner's MFMAs take) is a little shorter than the
+// MFMA block (28 x 32 cycles), so the matrix pipe is the pacing resource of both halves.
+//
+// Key tiles: pack p of the image = K fragments of tile p ‖ V^T fragments of tile p-1, what step u = p-1 of the
+// loop reads (PV(u), QK(u+1)).  Packs arrive by DMA into a 4-slot LDS ring, three steps ahead; a wave waits for
+// its own pieces of the pack after next (counted vmcnt) before the barrier, so every fragment read finds its
+// data landed one barrier earlier and no MFMA waits on global memory.
 // ---------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void ring_wait_barrier() {
@@ -198,7 +203,7 @@ __device__ __forceinline__ void ring_wait_barrier() {
 }
 
 template <int D, int QB>
-__global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __restrict__ q,
+__global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __restrict__ q,
                                                           const char* __restrict__ img,
                                                           const float* __restrict__ ktmax,
                                                           half_t* __restrict__ out, int B, int H, int Lq,
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
                                                           float scale_log2, float diag_bias_log2, int64_t q_ld) {
     using Cfg = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ROWS = 128 * QB;  // query rows per workgroup
+    constexpr int ROWS = 256 * QB;  // query rows per workgroup
 
     const int nQblk = (Lq + ROWS - 1) / ROWS;
     const int h = blockIdx.x % H;
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
     const int l31 = lane & 31, hi = lane >> 5;
     const int qrow0 = qblk * ROWS + wave * 32 * QB + l31;  // row of query block 0; block j: + 32*j
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int grpB = wave_s >= 4 ? 1 : 0;  // (flags are ints from scalar values: the branches on them stay scalar)
 
     // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
     half8_t qf[QB][Cfg::NKS];
@@ -280,26 +286,26 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
     const float diag_u = diag_bias_log2 / cmul;
 
     // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4), no register round trip ---------
-    // A packed tile IS its LDS image, so it is NP linear 1 KiB copies; wave w issues pieces w, w+4, ...
+    // A pack IS its LDS image, so it is NP linear 1 KiB copies; wave w issues pieces w, w+8, ...
     // (destination = wave-uniform M0 base + lane*16, source = scalar base + one per-lane offset).  The DMA
     // is inline asm on purpose: the compiler must not see these LDS writes, or it would drain vmcnt to zero
     // in front of every fragment read; ordering is by the counted s_waitcnt + s_barrier of `ring_sync`.
-    constexpr int NPW_LO = Cfg::NP / 4, NPW_HI = (Cfg::NP + 3) / 4, NREM = Cfg::NP % 4;
-    const int many = wave_s < NREM ? 1 : 0;  // this wave issues NPW_HI pieces per tile (else NPW_LO)
+    constexpr int NPW_LO = Cfg::NP / 8, NPW_HI = (Cfg::NP + 7) / 8, NREM = Cfg::NP % 8;
+    const int many = wave_s < NREM ? 1 : 0;  // this wave issues NPW_HI pieces per pack (else NPW_LO)
     const uint32_t lds0 =
         __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
-    const char* src = img + (int64_t)(g * H + h) * nT * Cfg::TILE;
+    const char* src = img + (int64_t)(g * H + h) * (nT + 1) * Cfg::TILE;
     const uint32_t lane_off = (wave * 64 + lane) * 16;
-    auto stage = [&](int t, int slot) __attribute__((always_inline)) {  // tile t -> ring slot
-        const char* sp = src + (int64_t)t * Cfg::TILE;
+    auto stage = [&](int p, int slot) __attribute__((always_inline)) {  // pack p -> ring slot
+        const char* sp = src + (int64_t)p * Cfg::TILE;
         const uint32_t dstb = lds0 + slot * Cfg::TILE + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < NPW_HI; ++i) {
             if (i < NPW_LO || many) {
-                const uint32_t m0v = dstb + i * 4096;
+                const uint32_t m0v = dstb + i * 8192;
                 asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(sp), "s"(m0v)
                              : "memory");
-                sp += 4096;
+                sp += 8192;
             }
         }
     };
@@ -308,9 +314,9 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
         if (keep == 0) {
             ring_wait_barrier<0>();
         } else if (many) {
-            ring_wait_barrier<NPW_HI>();
+            if (keep == 1) ring_wait_barrier<NPW_HI>(); else ring_wait_barrier<2 * NPW_HI>();
         } else {
-            ring_wait_barrier<NPW_LO>();
+            if (keep == 1) ring_wait_barrier<NPW_LO>(); else ring_wait_barrier<2 * NPW_LO>();
         }
     };
 
@@ -346,37 +352,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
                 kf[kb][ks] = *reinterpret_cast<const half8_t*>(kb_ + (ks * 128 + kb * 32) * 16);
     };
 
-    // ---- prologue: tiles 0 and 1 in flight, tile 0 landed, its K fragments in registers ----------
-    stage(0, 0);
-    if (nT > 1) stage(1, 1);
-    wait_barrier(nT > 1 ? 1 : 0);
-    half8_t kf[2][Cfg::NKS];
-    read_k(kf, 0);
-
-    const int need_diag = diag_bias_log2 != 0.f ? 1 : 0;
-
-    // One 64-key tile.  One loop body; what differs between tiles and waves is three wave-uniform
-    // (scalar-branch) passes in front of the exponentials:
-    //  * fix   : per-element fix-ups -- padded keys of the last tile, diagonal bias (then on every tile);
-    //  * search: running-max search + deferred rescale.  Dropped (nomax) after tile 0 has anchored m_run when
-    //            `qbound` proves that no exponent argument can exceed NOMAX_THR: P is then at most
-    //            2^NOMAX_THR, inside fp16 range, and the row sum normalises it exactly as before;
-    //  * exact : the wave keeps Q unscaled: scores are multiplied by c in fp32 before the exponential.
-    // LAST = the final tile: nothing to prefetch.
-    int nomax = 0;
-#ifdef FRESCO_ATTN_TRACE
-    unsigned long long tr_ts[6];
-    int tr_v = 0;
-#endif
-    auto tile = [&](int t, int slot, auto last_c) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(last_c)::value;
-        const int fix = LAST ? 1 : need_diag;
-        const int slot1 = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
-        const int slot2 = slot1 == Cfg::NBUF - 1 ? 0 : slot1 + 1;
-
-        TR_STAMP(0)
-        // ---- phase 1: S^T = K Q^T, 2*QB independent 32x32 accumulators, K fragments already in registers
-        floatx16 s[QB][2];
+    floatx16 s[QB][2];  // S^T of the tile whose softmax comes next
+    auto qk = [&](half8_t (&kf)[2][Cfg::NKS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < QB; ++j)
 #pragma unroll
@@ -389,13 +366,66 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int j = 0; j < QB; ++j)
-                    s[j][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[j][ks], s[j][kb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        TR_STAMP(1)
+                for (int j = 0; j < QB; ++j) {
+                    if (FRESCO_ABL == 2)
+                        s[j][kb][ks] += (float)kf[kb][ks][0] * (float)qf[j][ks][1];
+                    else
+                        s[j][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[j][ks], s[j][kb], 0, 0, 0);
+                }
+    };
 
-        // ---- phase 2: V^T fragments of this tile -> registers (in flight under the softmax); DMA of tile
-        // t+2 into the slot tile t-1 left
+    // ---- prologue: packs 0 .. 3 in flight (pack p = step p-1, slot (p+3) & 3), packs 0 and 1 landed,
+    // S^T of tile 0 computed
+    stage(0, 3);
+    stage(1, 0);
+    if (nT > 1) stage(2, 1);
+    if (nT > 2) stage(3, 2);
+    wait_barrier(nT > 2 ? 2 : (nT > 1 ? 1 : 0));
+    {
+        half8_t kf[2][Cfg::NKS];
+        read_k(kf, 3);
+        qk(kf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int need_diag = diag_bias_log2 != 0.f ? 1 : 0;
+
+    // Step u: softmax of tile u, O^T += V^T(u) P^T(u), S^T(u+1) = K(u+1) Q^T.  One loop body; what differs
+    // between tiles and waves is three wave-uniform (scalar-branch) passes in front of the exponentials:
+    //  * fix   : per-element fix-ups -- padded keys of the last tile, diagonal bias (then on every tile);
+    //  * search: running-max search + deferred rescale.  Dropped (nomax) after tile 0 has anchored m_run when
+    //            `qbound` proves that no exponent argument can exceed NOMAX_THR: P is then at most
+    //            2^NOMAX_THR, inside fp16 range, and the row sum normalises it exactly as before;
+    //  * exact : the wave keeps Q unscaled: scores are multiplied by c in fp32 before the exponential.
+    // LAST = the final tile: no S^T to compute for a next one.
+    // FAST = the common case as an instantiation of its own with ONE scalar branch left (the max search): scale
+    // folded, no fix-ups, and (u + 3 < nT) so that the ring handling is unconditional.  (A taken scalar branch costs a wave an
+    // instruction-fetch bubble; the generic body skips over its rare passes with a dozen of them per tile.)
+    int nomax = 0;
+    auto step = [&](int u, auto last_c, auto fast_c) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_c)::value;
+        constexpr bool FAST = decltype(fast_c)::value;
+        const int slot = u & 3;
+        const int fix = FAST ? 0 : (LAST ? 1 : need_diag);
+        const int search = !nomax;
+        const int exact = FAST ? 0 : !folded;
+        // barrier u: pack u+2 (step u+1) has landed for everyone; its predecessor's slot takes pack u+4
+        auto ring_sync = [&]() __attribute__((always_inline)) {
+            if (FAST && FRESCO_ABL == 7) {
+            } else if (FAST && FRESCO_ABL == 5) {
+                asm volatile("s_barrier" ::: "memory");
+            } else if (FAST) {
+                ring_wait_barrier<NPW_LO>();  // (waves with an extra piece per pack wait for one piece more)
+                stage(u + 4, (u + 3) & 3);
+            } else {
+                wait_barrier(u + 2 < nT ? 1 : 0);
+                if (u + 3 < nT) stage(u + 4, (u + 3) & 3);
+            }
+        };
+        if (grpB) ring_sync();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- V^T fragments of tile u -> registers (landed one barrier ago), in flight under the softmax
         half8_t vf[4][Cfg::NDB];
         {
             const char* vb_ = smem + slot * Cfg::TILE + voff;
@@ -403,19 +433,17 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
             for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
                 for (int db = 0; db < Cfg::NDB; ++db)
-                    vf[kc][db] = *reinterpret_cast<const half8_t*>(vb_ + (kc * 2 * Cfg::DPV + db * 32) * 16);
+                    vf[kc][db] = (FAST && FRESCO_ABL == 6) ? qf[0][0] : *reinterpret_cast<const half8_t*>(vb_ + (kc * 2 * Cfg::DPV + db * 32) * 16);
         }
-        if (!LAST && t + 2 < nT) stage(t + 2, slot2);
         __builtin_amdgcn_sched_barrier(0);
-        TR_STAMP(2)
 
-        // ---- phase 3: online softmax, one query per lane; the packed P registers are the PV B operands
+        // ---- online softmax, one query per lane; the packed P registers are the PV B operands
         half8_t pf[QB][4];
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
             if (fix) {
                 const int qr = qrow0 + 32 * j;
-                int kbase = t * 64 + 4 * hi;
+                int kbase = u * 64 + 4 * hi;
                 asm volatile("" : "+v"(kbase));  // keeps the index arithmetic of this rare pass inside its branch
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -429,13 +457,13 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
             // s = exponent argument (units u) relative to m_run; the reference point moves (and O, l are
             // rescaled) only when the tile max exceeds it by more than RESCALE_THR -- or on tile 0, which
             // anchors it at the row's first-tile max.
-            if (!nomax) {
+            if (search) {
                 float mt = fmaxf(s[j][0][0], s[j][1][0]);
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[j][0][r]), s[j][1][r]);  // v_max3_f32
                 mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-                if (t == 0 || __builtin_amdgcn_readfirstlane((int)__any(mt > resc_thr)) != 0) {
-                    float delta = (t == 0) ? mt : fmaxf(mt, 0.f);
+                if (u == 0 || __builtin_amdgcn_readfirstlane((int)__any(mt > resc_thr)) != 0) {
+                    float delta = (u == 0) ? mt : fmaxf(mt, 0.f);
                     if (Cfg::MCOL) {
                         // stays fp16-representable (and finite: logits beyond +-6e4 log2 units saturate)
                         const float m_new = (float)(half_t)fminf(fmaxf(m_run[j] + delta, -6.0e4f), 6.0e4f);
@@ -460,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
                         for (int r = 0; r < 16; ++r) o[j][db][r] *= alpha;
                 }
             }
-            if (!folded) {
+            if (exact) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     s[j][0][r] *= cmul;
@@ -472,6 +500,14 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
+                    if (FRESCO_ABL == 1) {
+                        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                        const half2_t hp = __builtin_bit_cast(half2_t, __builtin_bit_cast(uint32_t, s[j][kb][r]) ^
+                                                                           __builtin_bit_cast(uint32_t, s[j][kb][r + 1]));
+                        pf[j][kb * 2 + (r >> 3)][r & 7] = hp[0];
+                        pf[j][kb * 2 + (r >> 3)][(r & 7) + 1] = hp[1];
+                        continue;
+                    }
                     const float p0 = __builtin_amdgcn_exp2f(s[j][kb][r]);
                     const float p1 = __builtin_amdgcn_exp2f(s[j][kb][r + 1]);
                     if (!Cfg::ONES) psum += p0 + p1;
@@ -479,60 +515,70 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const half_t* __rest
                     pf[j][kb * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
                 }
             if (!Cfg::ONES) l_run[j] += psum;
-            // (pins the exponentials in front of the barrier below: without a use here the compiler sinks the
-            // whole softmax behind the inline-asm barrier, where every wave of the workgroup runs it at once)
+            // (pins the exponentials in front of group A's barrier below: being free of side effects they would
+            // otherwise be sunk behind the inline-asm barrier, into the MFMA block)
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) asm volatile("" : "+v"(pf[j][kc]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        TR_STAMP(3)
 
-        // ---- phase 4: tile t+1 has landed (own pieces: counted vmcnt; everyone's: barrier); its K
-        // fragments go to registers under the PV MFMAs below
-        if (!LAST) {
-            wait_barrier(t + 2 < nT ? 1 : 0);
-            read_k(kf, slot1);
+        if (!grpB) ring_sync();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- K fragments of tile u+1 (same pack), in flight under the PV MFMAs
+        half8_t kf[2][Cfg::NKS];
+        if (FAST && FRESCO_ABL == 6) {
+#pragma unroll
+            for (int ks = 0; ks < Cfg::NKS; ++ks) kf[0][ks] = kf[1][ks] = qf[0][ks];
+        } else if (!LAST) {
+            read_k(kf, slot);
         }
         __builtin_amdgcn_sched_barrier(0);
-        TR_STAMP(4)
 
-        // ---- phase 5: O^T += V^T P^T  (row D of V^T is all ones when it is spare: O^T[D] = row sum)
+        // The MFMA block runs at raised priority: against a partner wave in its softmax, an MFMA wave that loses the
+        // issue arbitration (it does when it is the younger one) leaves the matrix pipe idle between MFMAs
+        // (tools/ubench_rates.hip: 28 MFMAs beside a prioritised exp/cvt stream take 1590 cycles instead of 900).
+        __builtin_amdgcn_s_setprio(FRESCO_PRIO_M);
+        // ---- O^T += V^T P^T  (row D of V^T is all ones when it is spare: O^T[D] = row sum)
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
             for (int db = 0; db < Cfg::NDB; ++db)
 #pragma unroll
-                for (int j = 0; j < QB; ++j)
-                    o[j][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kc][db], pf[j][kc], o[j][db], 0, 0, 0);
+                for (int j = 0; j < QB; ++j) {
+                    if (FRESCO_ABL == 2)
+                        o[j][db][kc] += (float)vf[kc][db][0] * (float)pf[j][kc][1];
+                    else
+                        o[j][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kc][db], pf[j][kc], o[j][db], 0, 0, 0);
+                }
         __builtin_amdgcn_sched_barrier(0);
-        TR_STAMP(5)
+        // ---- S^T of tile u+1
+        if (!LAST) qk(kf);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     const std::integral_constant<bool, true> yes;
-    const std::integral_constant<bool, false> no;
-    int slot = 0;
-    for (int t = 0; t < nT - 1; ++t) {
-        tile(t, slot, no);
-        TR_COLLECT(t)
-        slot = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
-        if (t == 0 && !need_diag) {
-            bool safe = true;
-#pragma unroll
-            for (int j = 0; j < QB; ++j) safe = safe && (cmul * (qbound[j] - m_run[j]) <= NOMAX_THR);
-            nomax = __builtin_amdgcn_readfirstlane((int)__all(safe));
-        }
-    }
-    nomax = 0;  // the last tile has padded keys at -1e30: its maximum must be looked at
-    tile(nT - 1, slot, yes);
-#ifdef FRESCO_ATTN_TRACE
+    const std::integral_constant<bool, false> no_last, no;
+    const std::integral_constant<bool, true> fast;
     {
-        unsigned int hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
-        TR_WRITELANE(hwid, 62)
-        TR_WRITELANE(xcc, 63)
-        g_attn_trace[((size_t)blockIdx.x * 4 + wave) * 64 + lane] = (unsigned int)tr_v;
+        int u = 0;
+        if (nT > 1) {
+            step(0, no_last, no);
+            u = 1;
+            if (!need_diag) {
+                bool safe = true;
+#pragma unroll
+                for (int j = 0; j < QB; ++j) safe = safe && (cmul * (qbound[j] - m_run[j]) <= NOMAX_THR);
+                nomax = __builtin_amdgcn_readfirstlane((int)__all(safe));
+            }
+            if (folded && !need_diag)
+                for (; u + 3 < nT; ++u) step(u, no_last, fast);
+            for (; u < nT - 1; ++u) step(u, no_last, no);
+        }
+        nomax = 0;  // the last tile has padded keys at -1e30: its maximum must be looked at
+        step(u, yes, no);
     }
-#endif
 
     // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
 #pragma unroll
@@ -573,10 +619,10 @@ static void launch_flash(const half_t* q, const char* img, half_t* out, int B, i
     // (per device and cheap: set on every launch rather than cached in a process-global flag)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<D, QB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    const int nQblk = (Lq + 128 * QB - 1) / (128 * QB);
+    const int nQblk = (Lq + 256 * QB - 1) / (256 * QB);
     const float log2e = 1.4426950408889634f;
     ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
-    hipLaunchKernelGGL((attn_flash_kernel<D, QB>), dim3(H * nQblk * B), dim3(256), Cfg::LDS_BYTES, st, q, img,
+    hipLaunchKernelGGL((attn_flash_kernel<D, QB>), dim3(H * nQblk * B), dim3(512), Cfg::LDS_BYTES, st, q, img,
                        ktmax, out, B, H, Lq, M, nT, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
 }
 
@@ -588,7 +634,7 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
     using Cfg = AttnCfg<D>;
     const int nT = ntiles_of(M);
     char* img = ws;
-    float* ktmax = reinterpret_cast<float*>(ws + align_up((size_t)n_groups * H * nT * Cfg::TILE, 256));
+    float* ktmax = reinterpret_cast<float*>(ws + align_up((size_t)n_groups * H * (nT + 1) * Cfg::TILE, 256));
     dim3 pg(nT, H, n_groups);
     {
         ProfScope ps(FRESCO_PROF_KV_PACK, n_groups, H, M, D, st);
@@ -607,7 +653,7 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
 static size_t attn_ws_bytes(int n_groups, int H, int M, int D) {
     const size_t nT = ntiles_of(M);
     const size_t dpk = (D + 15) / 16 * 16, dpv = (D + 31) / 32 * 32;
-    return align_up((size_t)n_groups * H * nT * ((dpk + dpv) * 128), 256) +
+    return align_up((size_t)n_groups * H * (nT + 1) * ((dpk + dpv) * 128), 256) +
            align_up((size_t)n_groups * H * nT * sizeof(float), 256);
 }
 

@@ -78,6 +78,13 @@ DEFK(k_pkfmah, B16(PKFMAH), 8)
 DEFK(k_exph, B16(EXPH), 8)
 DEFK(k_mov, B16(MOV), 8)
 DEFK(k_m32, MF32x4, 8)
+DEFK(k_m32_dep1, M32(0) M32(0) M32(0) M32(0), 8)
+DEFK(k_m32_dep2, M32(0) M32(16) M32(0) M32(16), 8)
+DEFK(k_m16_dep1, M16(0) M16(0) M16(0) M16(0) M16(0) M16(0) M16(0) M16(0), 8)
+DEFK(k_m16_dep2, M16(0) M16(4) M16(0) M16(4) M16(0) M16(4) M16(0) M16(4), 8)
+#define DSR(i) "ds_read_b128 v[" S(i) "*4:" S(i) "*4+3], v120 offset:" S(i) "*1024\n"
+DEFK(k_dsread, "v_mov_b32 v120, 0\n" DSR(0) DSR(1) DSR(2) DSR(3) DSR(4) DSR(5) DSR(6) DSR(7) "s_waitcnt lgkmcnt(0)\n", 8)
+DEFK(k_m32_ds, "v_mov_b32 v120, 0\n" M32(0) DSR(16) M32(16) DSR(17) M32(32) DSR(18) M32(48) DSR(19) "s_waitcnt lgkmcnt(0)\n", 8)
 DEFK(k_m16, MF16x8, 8)
 DEFK(k_m32_e1, MIX_E(E1, 0) MIX_E(E1, 16) MIX_E(E1, 32) MIX_E(E1, 48), 8)
 DEFK(k_m32_e2, MIX_E(E2, 0) MIX_E(E2, 16) MIX_E(E2, 32) MIX_E(E2, 48), 8)
@@ -96,9 +103,21 @@ DEFK(k_m16_u2, MIX16(MULb(72) MULb(73), 0) MIX16(MULb(72) MULb(73), 4) MIX16(MUL
 
 // heterogeneous pair inside ONE 512-thread workgroup: waves 0-3 (one per SIMD) run body A, waves 4-7 (their
 // SIMD partners) run body B; prio = s_setprio level of the B waves
+// realistic blocks of the flash kernel (per 64 keys x 64 queries of one wave), tools/ubench_bodies.h:
+//  SMX: 64 exponentials on 64 registers, then the 32 packs that depend on them
+//  MBL: 28 MFMA 32x32x16 on 8 accumulators (v0..v127), operands static
+//  MBD: the same, 14 operand fragments freshly read from LDS in front
+#include "ubench_bodies.h"
+#define CLOBBER2 CLOBBER, "v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v250"
+
 template <int BODY>
 __device__ __forceinline__ void run_body(int iters) {
     for (int it = 0; it < iters; ++it) {
+        if (BODY == 10) asm volatile(".rept 8\n" BODY_SMX ".endr\n" ::: CLOBBER2);
+        if (BODY == 11) asm volatile(".rept 8\n" BODY_MBL ".endr\n" ::: CLOBBER2);
+        if (BODY == 12) asm volatile(".rept 8\n" BODY_MBD ".endr\n" ::: CLOBBER2);
+        if (BODY == 13) asm volatile(".rept 8\n" BODY_SMX BODY_MBL ".endr\n" ::: CLOBBER2);
+        if (BODY == 14) asm volatile(".rept 8\n" BODY_MBL BODY_SMX ".endr\n" ::: CLOBBER2);
         if (BODY == 0) asm volatile(".rept 8\n" MF32x4 ".endr\n" ::: CLOBBER);
         if (BODY == 1) asm volatile(".rept 8\n" B16(MUL) ".endr\n" ::: CLOBBER);
         if (BODY == 2) asm volatile(".rept 8\n" MF16x8 ".endr\n" ::: CLOBBER);
@@ -160,6 +179,12 @@ int main() {
     run("mov_b32", k_mov, 16, d, h);
     run("mfma32x4", k_m32, 4, d, h);
     run("mfma16x8", k_m16, 8, d, h);
+    run("mfma32 dep1", k_m32_dep1, 4, d, h);
+    run("mfma32 dep2", k_m32_dep2, 4, d, h);
+    run("mfma16 dep1", k_m16_dep1, 8, d, h);
+    run("mfma16 dep2", k_m16_dep2, 8, d, h);
+    run("ds_read_b128x8", k_dsread, 8, d, h);
+    run("m32+ds_read", k_m32_ds, 4, d, h);
     run("m32+1exp", k_m32_e1, 4, d, h);
     run("m32+2exp", k_m32_e2, 4, d, h);
     run("m32+3exp", k_m32_e3, 4, d, h);
@@ -178,7 +203,9 @@ int main() {
         {"MFMA32 | cvt_pk", k_pair<0, 3>}, {"MFMA32 | MFMA32", k_pair<0, 0>}, {"exp | mul", k_pair<4, 1>},
         {"exp | cvt_pk", k_pair<4, 3>}, {"exp | exp", k_pair<4, 4>}, {"exp | swap", k_pair<4, 5>},
         {"cvt_pk | cvt_pk", k_pair<3, 3>}, {"mul | mul", k_pair<1, 1>}, {"fma | fma", k_pair<6, 6>},
-        {"cvt_pk | mul", k_pair<3, 1>}, {"swap | swap", k_pair<5, 5>}, {"MFMA32 | swap", k_pair<0, 5>}};
+        {"cvt_pk | mul", k_pair<3, 1>}, {"swap | swap", k_pair<5, 5>}, {"MFMA32 | swap", k_pair<0, 5>},
+        {"SMX | SMX", k_pair<10, 10>}, {"MBL | MBL", k_pair<11, 11>}, {"MBL | SMX", k_pair<11, 10>},
+        {"MBD | SMX", k_pair<12, 10>}, {"SM+MB | MB+SM", k_pair<13, 14>}, {"SM+MB | SM+MB", k_pair<13, 13>}};
     for (auto& pr : pairs)
         for (int prio = 0; prio <= 1; ++prio) {
             const int iters = 200;
