@@ -398,8 +398,8 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
     //            2^NOMAX_THR, inside fp16 range, and the row sum normalises it exactly as before;
     //  * exact : the wave keeps Q unscaled: scores are multiplied by c in fp32 before the exponential.
     // LAST = the final tile: no S^T to compute for a next one.
-    // FAST = the common case as an instantiation of its own with ONE scalar branch left (the max search): scale
-    // folded, no fix-ups, and (u + 3 < nT) so that the ring handling is unconditional.  (A taken scalar branch costs a wave an
+    // FAST = the common case as an instantiation of its own: no fix-ups (only the max search and the exact-scale
+    // pass keep their scalar branches), and (u + 3 < nT) so that the ring handling is unconditional.  (A taken scalar branch costs a wave an
     // instruction-fetch bubble; the generic body skips over its rare passes with a dozen of them per tile.)
     int nomax = 0;
     auto step = [&](int u, auto last_c, auto fast_c) __attribute__((always_inline)) {
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         const int slot = u & 3;
         const int fix = FAST ? 0 : (LAST ? 1 : need_diag);
         const int search = !nomax;
-        const int exact = FAST ? 0 : !folded;
+        const int exact = !folded;
         // barrier u: pack u+2 (step u+1) has landed for everyone; its predecessor's slot takes pack u+4
         auto ring_sync = [&]() __attribute__((always_inline)) {
             if (FAST && FRESCO_ABL == 7) {
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
                 for (int j = 0; j < QB; ++j) safe = safe && (cmul * (qbound[j] - m_run[j]) <= NOMAX_THR);
                 nomax = __builtin_amdgcn_readfirstlane((int)__all(safe));
             }
-            if (folded && !need_diag)
+            if (!need_diag)
                 for (; u + 3 < nT; ++u) step(u, no_last, fast);
             for (; u < nT - 1; ++u) step(u, no_last, no);
         }
