@@ -38,12 +38,15 @@ SIGNATURES = {
     "fresco_attn_fwd_ld": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i64, _f, _f, _i64, _i64, _vp]),
     "fresco_temporal_attn_ld": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i64, _i64, _i64, _vp]),
     "fresco_temporal_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "fresco_temporal_attn_sharded": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
+    "fresco_temporal_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
+    "fresco_temporal_attn_packed": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "fresco_temporal_unpack": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fresco_flow_warp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fresco_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "fresco_max_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "fresco_dilate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "fresco_linear": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
+    "fresco_linear": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i,
+                           _vp]),
     "fresco_attn_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "fresco_flow_occlusion": (_i, [_vp] * 5 + [_i, _i, _i, _i, _f, _f, _f, _vp]),
     "fresco_warp_fuse_chain": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i, _vp]),

@@ -1057,11 +1057,11 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
     const dim3 egrid((hw + 255) / 256, (C + ECPT - 1) / ECPT, B);
     // S V on fp16 MFMA (V = Vh + Vl) whenever rows are 16-byte aligned; FRESCO_OPT_SV=f32 forces the
     // fp32-MFMA kernel (A/B measurements)
-    static int sv_mode = -1;
-    if (sv_mode < 0) {
+    // (a pure function of the environment, initialised once, thread-safely)
+    static const int sv_mode = [] {
         const char* e = getenv("FRESCO_OPT_SV");
-        sv_mode = (e && e[0] == 'f' && e[1] == '3') ? 1 : 0;
-    }
+        return (e && e[0] == 'f' && e[1] == '3') ? 1 : 0;
+    }();
     const bool f16_sv = (hw % 16 == 0) && sv_mode == 0;
     if (has_t) {
         dim3 grid((hw + 255) / 256, (C + OCPT - 1) / OCPT, B);

@@ -39,8 +39,9 @@ struct ProjCfg {
 
 template <int K, int NWV>
 __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void linear_kernel(
-    const half_t* __restrict__ x, int64_t x_ld, const half_t* __restrict__ W, const half_t* __restrict__ bias,
-    half_t* __restrict__ out0, half_t* __restrict__ out1, half_t* __restrict__ out2, int64_t ld0, int64_t ld1,
+    const half_t* __restrict__ x, int64_t x_ld, const half_t* __restrict__ W0, const half_t* __restrict__ W1,
+    const half_t* __restrict__ W2, const half_t* __restrict__ b0, const half_t* __restrict__ b1,
+    const half_t* __restrict__ b2, half_t* __restrict__ out0, half_t* __restrict__ out1, half_t* __restrict__ out2, int64_t ld0, int64_t ld1,
     int64_t ld2, int M, int N, int nF, int tiles_per_split) {
     using Cfg = ProjCfg<K, NWV>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,9 +78,13 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void
         const int r = c / Cfg::CPR, dc = c % Cfg::CPR;
         dma_off[i] = (r < Cfg::TF && dc < Cfg::CPR - 1) ? (uint32_t)(r * K * 2 + dc * 16) : 0u;
     }
-    const char* wbase = reinterpret_cast<const char*>(W);
+    // feature tile ft belongs to projection ft / tiles_per_out: every projection keeps its own (live) weight
+    // matrix, nothing is stacked or cached on the host side
+    const int tiles_per_out = N / Cfg::TF;
     auto stage = [&](int ft, int kc, int buf) __attribute__((always_inline)) {
-        const char* src = wbase + ((int64_t)ft * Cfg::TF * K + kc * Cfg::KC) * 2;  // wave-uniform
+        const int jw = ft / tiles_per_out;
+        const char* wbase = reinterpret_cast<const char*>(jw == 0 ? W0 : (jw == 1 ? W1 : W2));
+        const char* src = wbase + ((int64_t)(ft - jw * tiles_per_out) * Cfg::TF * K + kc * Cfg::KC) * 2;  // wave-uniform
         char* dst = smem + buf * Cfg::BUFB + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < Cfg::PW; ++i)
@@ -88,7 +93,6 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void
     };
 
     // output cursor of this split: which tensor, which column
-    const int tiles_per_out = N / Cfg::TF;
     int j = ft0 / tiles_per_out;
     int col = (ft0 % tiles_per_out) * Cfg::TF;
 
@@ -129,8 +133,9 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void
             for (int half = 0; half < 2; ++half) {
                 half8_t w;
                 float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const half_t* bias = (j == 0) ? b0 : (j == 1 ? b1 : b2);
                 if (bias) {
-                    const half8_t b8 = *reinterpret_cast<const half8_t*>(bias + (int64_t)j * N + col + half * 16 + hi * 8);
+                    const half8_t b8 = *reinterpret_cast<const half8_t*>(bias + col + half * 16 + hi * 8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bv[e] = (float)b8[e];
                 }
@@ -148,16 +153,13 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void
 }
 
 template <int K, int NWV>
-static int launch_linear(const half_t* x, int64_t x_ld, const half_t* W, const half_t* bias, half_t* out0,
-                         half_t* out1, half_t* out2, int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N,
-                         hipStream_t st) {
+static int launch_linear(const half_t* x, int64_t x_ld, const half_t* const* W, const half_t* const* bias,
+                         half_t* out0, half_t* out1, half_t* out2, int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M,
+                         int N, hipStream_t st) {
     using Cfg = ProjCfg<K, NWV>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<K, NWV>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        attr_set = true;
-    }
+    // (per device and cheap: set on every launch rather than cached in a process-global flag)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<K, NWV>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     const int nF = nw * N / Cfg::TF;
     const int row_blocks = (M + NWV * 32 - 1) / (NWV * 32);
     // enough workgroups for two rounds of the 256 CUs; every extra split re-reads x once
@@ -167,8 +169,8 @@ static int launch_linear(const half_t* x, int64_t x_ld, const half_t* W, const h
     const int tiles_per_split = (nF + splits - 1) / splits;
     splits = (nF + tiles_per_split - 1) / tiles_per_split;
     ProfScope ps(FRESCO_PROF_LINEAR, M, N, K, nw, st);
-    hipLaunchKernelGGL((linear_kernel<K, NWV>), dim3(row_blocks, splits), dim3(NWV * 64), Cfg::LDS_BYTES, st, x, x_ld, W, bias,
-                       out0, out1, out2, ld0, ld1, ld2, M, N, nF, tiles_per_split);
+    hipLaunchKernelGGL((linear_kernel<K, NWV>), dim3(row_blocks, splits), dim3(NWV * 64), Cfg::LDS_BYTES, st, x, x_ld, W[0], W[1],
+                       W[2], bias[0], bias[1], bias[2], out0, out1, out2, ld0, ld1, ld2, M, N, nF, tiles_per_split);
     return check_launch();
 }
 
@@ -176,11 +178,11 @@ static int launch_linear(const half_t* x, int64_t x_ld, const half_t* W, const h
 
 using namespace fresco;
 
-extern "C" int fresco_linear(const void* x, int64_t x_ld, const void* W, const void* bias, void* out0, void* out1,
-                             void* out2, int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N, int K,
-                             void* stream) {
-    if (!x || !W || !out0 || nw < 1 || nw > 3 || M <= 0 || N <= 0 || K <= 0) return FRESCO_EINVAL;
-    if ((nw > 1 && !out1) || (nw > 2 && !out2)) return FRESCO_EINVAL;
+extern "C" int fresco_linear(const void* x, int64_t x_ld, const void* W0, const void* W1, const void* W2,
+                             const void* b0, const void* b1, const void* b2, void* out0, void* out1, void* out2,
+                             int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N, int K, void* stream) {
+    if (!x || !W0 || !out0 || nw < 1 || nw > 3 || M <= 0 || N <= 0 || K <= 0) return FRESCO_EINVAL;
+    if ((nw > 1 && (!out1 || !W1)) || (nw > 2 && (!out2 || !W2))) return FRESCO_EINVAL;
     if (x_ld < K || x_ld % 8 != 0) return FRESCO_EINVAL;
     if (ld0 < N || ld0 % 8 != 0 || (nw > 1 && (ld1 < N || ld1 % 8 != 0)) || (nw > 2 && (ld2 < N || ld2 % 8 != 0)))
         return FRESCO_EINVAL;
@@ -188,8 +190,8 @@ extern "C" int fresco_linear(const void* x, int64_t x_ld, const void* W, const v
     if ((int64_t)(M + 127) / 128 > 0x7fffffff) return FRESCO_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const half_t* xh = static_cast<const half_t*>(x);
-    const half_t* wh = static_cast<const half_t*>(W);
-    const half_t* bh = static_cast<const half_t*>(bias);
+    const half_t* wh[3] = {static_cast<const half_t*>(W0), static_cast<const half_t*>(W1), static_cast<const half_t*>(W2)};
+    const half_t* bh[3] = {static_cast<const half_t*>(b0), static_cast<const half_t*>(b1), static_cast<const half_t*>(b2)};
     half_t* o0 = static_cast<half_t*>(out0);
     half_t* o1 = static_cast<half_t*>(out1);
     half_t* o2 = static_cast<half_t*>(out2);

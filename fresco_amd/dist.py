@@ -3,21 +3,24 @@ reference is single-GPU).
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank r owns the n_loc =
 N / world consecutive frames [r*n_loc, (r+1)*n_loc) of BOTH CFG halves; its local batch axis is
-(c, f_loc).  Everything per-frame (projections, spatial-guided pass, the queries of every pass) stays
-local.  Two exchange steps per layer, both plain all-gathers into rank-major buffers:
+(c, f_loc).  Everything per-frame (projections, spatial-guided pass, the queries of the cross-frame pass)
+stays local.  Exchange steps per layer (every byte crosses the fabric once, nothing is replicated that is
+not read):
 
-  1. K|V, fused into one (2, B_loc, HW, C) message  ->  (world, 2, B_loc, HW, C).
-     The cross-frame kernel reads its compacted key rows straight out of that buffer: the flat
-     (frame, pixel) indices of controller.attn_mask are remapped once per batch to buffer rows
-     (`remap_kv_rows`), so no re-layout pass runs after the collective.  The gather is launched right
-     after the K / V projections and overlaps the Q projection and the spatial-guided pass.
-  2. the cross-frame output (the temporal pass's V)  ->  (world, B_loc, HW, C), only while the
-     temporal-guided pass is active.  The temporal kernel gathers K from buffer 1 and V from buffer 2
-     along the trajectories and writes only the local frames' rows (fresco_temporal_attn_sharded).
-
-Payload per rank and layer at 8 x 512^2 on 8 GPUs: K|V 10.5 MB (up_blocks.3) / 5.2 MB (up_blocks.2);
-xGMI is point-to-point (7 links x ~153 GB/s), so a direct all-gather moves each shard over its own
-link: ~70 us -- comparable to the sharded kernels, hence the overlap.
+  1. cross-frame keys (`exchange_cf`): the efficient cross-frame pass reads frame 0 (all tokens) and the
+     occluded tokens of the other frames (controller.attn_mask, src/diffusion_hacked.py:935-938).  Frame 0's fused
+     K|V rows are BROADCAST from their owner; the other frames' selected rows are compacted per rank, padded
+     to the largest rank's count (the mask is replicated, so every rank knows the counts) and ALL-GATHERED.
+     Both land in one (chunk, HW + world*Rmax, 2C) buffer whose rows the kernel addresses through the
+     remapped row table of `cf_plan` -- no re-layout pass after the collectives.  At 8 x 512^2 on 8 GPUs a
+     rank receives 10.5 MB + 0.1 MB per up_blocks.3 call instead of the 73 MB of an all-gather of every
+     frame's K|V.  The collectives are launched right after the K / V projection and overlap the spatial pass.
+  2. temporal-guided pass (`temporal`): sharded by TRAJECTORY, not by frame.  fresco_temporal_pack gathers the
+     local frames' q | k | v rows along the trajectories into per-destination ranges, an ALL-TO-ALL delivers
+     to rank r all N frames of its HW/world trajectories, the packed kernel runs on them, and the way back
+     mirrors it (all-to-all, fresco_temporal_unpack).  Fabric bytes per rank: 4 x (local rows) x (world-1)/world
+     -- a quarter of what all-gathering K and V of every frame costs at 8 ranks -- and the kernel's HBM
+     traffic is 1/world of the single-GPU pass.
 
 optimize_feature: Gram loss, normalisation, Adam and AdaIN are per frame (local); the temporal L1 term
 couples frame f with f+-1, so every Adam iteration starts with a halo exchange of the ranks' boundary
@@ -38,24 +41,42 @@ def local_batch_index(N, chunk, rank, world):
     return torch.tensor([c * N + f0 + fl for c in range(chunk) for fl in range(n_loc)], dtype=torch.long)
 
 
-def remap_kv_rows(rows, N, HW, chunk, world):
-    """Flat indices into one CFG half's (N*HW) token grid -> rows of the fused K|V gather buffer
-    (world, 2, chunk*n_loc, HW) for group 0; group g adds g*group_rows with group_rows = n_loc*HW,
-    and V is the same row + chunk*n_loc*HW (passed as a pointer offset)."""
+def cf_plan(mask, N, HW, world, rank):
+    """Index plan of the sparse cross-frame exchange for one feature scale.  mask: (N, HW) bool on any device
+    (row 0 all True: the reference builds it so, src/diffusion_hacked.py:937-938), or None for "every frame uses
+    frame 0" (former_frame_index, :227).
+    Returns a dict:
+      table      int32 (M,): row of the m-th key (row-major over (frame, pixel), the reference's order, :239) inside
+                 one CFG half's slab of the exchange buffer: frame 0's pixel p -> p; a selected token of frame f >= 1
+                 owned by rank r, the i-th such token of that rank -> HW + r*Rmax + i
+      group_rows HW + world*Rmax: rows per CFG half's slab
+      Rmax       largest per-rank count of selected tokens in frames >= 1
+      local_sel  int64 (Rmax,): this rank's selected rows, as indices into its (n_loc*HW) local token grid (padded
+                 with 0: the pad rows travel but no table entry points at them)"""
     n_loc = N // world
-    B_loc = chunk * n_loc
-    rows = rows.to(torch.int64)
-    f = rows // HW
-    pix = rows - f * HW
-    r = f // n_loc
-    fl = f - r * n_loc
-    out = r * (2 * B_loc * HW) + fl * HW + pix
-    return out.to(torch.int32), n_loc * HW
-
-
-def gathered_batch(g_frame, c, n_loc, rank_stride):
-    """Batch index (units of HW rows) of frame g, CFG half c inside a rank-major gather buffer."""
-    return (g_frame // n_loc) * rank_stride + c * n_loc + g_frame % n_loc
+    if mask is None:
+        sel = torch.zeros(N, HW, dtype=torch.bool)
+        sel[0] = True
+    else:
+        sel = mask.detach().to("cpu", torch.bool).reshape(N, HW).clone()
+        if not bool(sel[0].all()):
+            raise ValueError("fresco_amd: the cross-frame mask must select every token of frame 0")
+    flat = sel.reshape(-1).nonzero().squeeze(1)  # (M,) row-major (frame, pixel)
+    f = flat // HW
+    pix = flat - f * HW
+    owner = f // n_loc
+    rest = f > 0
+    counts = [int(((owner == r) & rest).sum()) for r in range(world)]
+    Rmax = max(counts) if counts else 0
+    table = pix.clone()
+    for r in range(world):
+        m = (owner == r) & rest
+        table[m] = HW + r * Rmax + torch.arange(int(m.sum()))
+    mine = (owner == rank) & rest
+    local_sel = torch.zeros(Rmax, dtype=torch.int64)
+    local_sel[: int(mine.sum())] = (f[mine] - rank * n_loc) * HW + pix[mine]
+    return dict(table=table.to(torch.int32), group_rows=HW + world * Rmax, Rmax=Rmax, local_sel=local_sel,
+                M=int(flat.numel()))
 
 
 class FrameShard:
@@ -100,16 +121,84 @@ class FrameShard:
         right = (self.rank + 1) % self.world
         return allb[left, 1], allb[right, 0]
 
-    def kv_rows(self, rows, HW, key, device):
-        """Remapped int32 key rows (on `device`) + group_rows for the fused K|V gather buffer;
-        rows = flat (frame, pixel) indices of the cross-frame mask, or None for "frame 0 only"."""
+    def _host_staged(self, x):
+        # functional testing of the multi-process path without RCCL (several ranks on one GPU): gloo, via host memory
+        return x.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def broadcast(self, x, src, async_op=False):
+        """in place; returns work-or-None"""
+        if self._host_staged(x):
+            xc = x.cpu()
+            dist.broadcast(xc, src=src, group=self.group)
+            x.copy_(xc)
+            return None
+        return dist.broadcast(x, src=src, group=self.group, async_op=async_op)
+
+    def all_gather_into(self, out, x, async_op=False):
+        """out (world*rows, ...) contiguous view <- every rank's x (rows, ...); returns work-or-None"""
+        if self._host_staged(x):
+            oc = out.cpu()
+            dist.all_gather_into_tensor(oc, x.contiguous().cpu(), group=self.group)
+            out.copy_(oc)
+            return None
+        return dist.all_gather_into_tensor(out, x.contiguous(), group=self.group, async_op=async_op)
+
+    def all_to_all(self, x):
+        """x (world, ...) contiguous: slab d goes to rank d; returns (world, ...) with slab s = what rank s sent here"""
+        x = x.contiguous()
+        if self._host_staged(x):
+            xc = x.cpu()
+            oc = torch.empty_like(xc)
+            dist.all_to_all_single(oc, xc, group=self.group)
+            return oc.to(x.device)
+        out = torch.empty_like(x)
+        dist.all_to_all_single(out, x, group=self.group)
+        return out
+
+    def cf_plan(self, mask, HW, device):
+        """cached `cf_plan` of a mask tensor (or None) for this rank, index tensors on `device`"""
+        key = ("none", HW) if mask is None else (mask.data_ptr(), tuple(mask.shape), mask._version)
         hit = self._rows_cache.get(key)
         if hit is None:
             if len(self._rows_cache) > 16:
                 self._rows_cache.clear()
-            if rows is None:
-                rows = torch.arange(HW)
-            remapped, group_rows = remap_kv_rows(rows.cpu(), self.N, HW, self.chunk, self.world)
-            hit = (remapped.to(device), group_rows)
+            hit = cf_plan(mask, self.N, HW, self.world, self.rank)
+            hit["table"] = hit["table"].to(device)
+            hit["local_sel"] = hit["local_sel"].to(device)
             self._rows_cache[key] = hit
         return hit
+
+    def exchange_cf(self, kv_loc, plan):
+        """kv_loc: this rank's fused K|V rows (chunk*n_loc, HW, 2C).  Starts the broadcast of frame 0's rows and the
+        all-gather of the other frames' selected rows into one (chunk, HW + world*Rmax, 2C) buffer; returns
+        (buffer, [works]) -- wait on the works before the kernel reads the buffer."""
+        Bl, HW, C2 = kv_loc.shape
+        Rmax = plan["Rmax"]
+        buf = torch.empty(self.chunk, HW + self.world * Rmax, C2, dtype=kv_loc.dtype, device=kv_loc.device)
+        x = kv_loc.view(self.chunk, self.n_loc, HW, C2)
+        works = []
+        if self.rank == 0:  # frame 0 lives on rank 0
+            buf[:, :HW].copy_(x[:, 0])
+        for c in range(self.chunk):
+            works.append(self.broadcast(buf[c, :HW], src=0, async_op=True))
+        if Rmax > 0:
+            mine = x.reshape(self.chunk, self.n_loc * HW, C2).index_select(1, plan["local_sel"])  # (chunk, Rmax, 2C)
+            for c in range(self.chunk):
+                works.append(self.all_gather_into(buf[c, HW:], mine[c], async_op=True))
+        return buf, [w for w in works if w is not None]
+
+    def temporal(self, q, k, v, fwd_map, mask, heads, scale):
+        """trajectory-sharded temporal-guided pass: q, k, v local (chunk*n_loc, HW, C); returns the local rows"""
+        from . import ops
+        Bl, HW, C = q.shape
+        if HW % self.world != 0:
+            raise ValueError("tokens (%d) must divide evenly over %d ranks" % (HW, self.world))
+        Pw = HW // self.world
+        fwd_map, mask = ops._prep_maps(fwd_map, mask, self.N, HW)
+        ops._check_permutations(fwd_map, HW)
+        send = ops.temporal_pack(q, k, v, fwd_map, self.chunk, self.n_loc, self.f0, self.world)
+        recv = self.all_to_all(send)  # (src, fl, c, pl, 3C) = (frame, c, pl, 3C)
+        outp = ops.temporal_attention_packed(recv.view(self.N, self.chunk, Pw, 3 * C),
+                                             mask[self.rank * Pw:(self.rank + 1) * Pw], heads, scale, self.chunk)
+        back = self.all_to_all(outp.view(self.world, self.n_loc, self.chunk, Pw, C))
+        return ops.temporal_unpack(back, fwd_map, self.chunk, self.n_loc, self.f0, self.world)

@@ -105,17 +105,30 @@ def linear_supported(K, N, dtype):
     return dtype == torch.float16 and K in (320, 640) and N % 32 == 0
 
 
-def linear(x, W, bias=None, nw=1, outs=None):
-    """out_j = x W_j^T (+ b_j): x (..., K) fp16 read once, W (nw*N, K) fp16 = the stacked nn.Linear weights,
-    bias (nw*N,) fp16 or None.  Returns nw tensors shaped x.shape[:-1] + (N,); `outs` may supply them (dense in
-    the last dim, uniformly strided rows -- e.g. the two halves of a fused K|V buffer)."""
-    _need_gpu(x, W, bias)
+def linear(x, weights, biases=None, outs=None):
+    """out_j = x W_j^T (+ b_j) for the 1..3 weight matrices in `weights` (each (N, K) fp16, read where it lives --
+    nothing is stacked or cached), x (..., K) fp16 read once; `biases`: None or a list of (N,) fp16 / None.
+    Returns len(weights) tensors shaped x.shape[:-1] + (N,); `outs` may supply them (dense in the last dim,
+    uniformly strided rows -- e.g. the two halves of a fused K|V buffer)."""
+    if torch.is_tensor(weights):
+        weights = [weights]
+    weights = list(weights)
+    nw = len(weights)
+    if biases is None:
+        biases = [None] * nw
+    elif torch.is_tensor(biases):
+        biases = [biases]
+    _need_gpu(x, *weights, *[b for b in biases if b is not None])
     K = x.shape[-1]
-    if W.dtype != torch.float16 or x.dtype != torch.float16 or W.shape[1] != K or W.shape[0] % nw != 0:
-        raise ValueError("linear: x (...,K) and W (nw*N,K) must be fp16 with matching K")
-    if not W.is_contiguous():
-        W = W.contiguous()
-    N = W.shape[0] // nw
+    N = weights[0].shape[0]
+    if not 1 <= nw <= 3 or len(biases) != nw:
+        raise ValueError("linear: 1..3 weights and as many biases (or None)")
+    for W in weights:
+        if W.dtype != torch.float16 or x.dtype != torch.float16 or tuple(W.shape) != (N, K) or not W.is_contiguous():
+            raise ValueError("linear: x (...,K) and every W (N,K) must be contiguous fp16 with matching shapes")
+    for b in biases:
+        if b is not None and (b.dtype != torch.float16 or tuple(b.shape) != (N,) or not b.is_contiguous()):
+            raise ValueError("linear: a bias must be a contiguous (N,) fp16 tensor")
     x2, x_ld, M = _rows(x)
     if outs is None:
         outs = [torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device) for _ in range(nw)]
@@ -126,13 +139,13 @@ def linear(x, W, bias=None, nw=1, outs=None):
             raise ValueError("linear: every output must be a (M,N) fp16 tensor with uniformly strided rows")
         ptrs.append(t.data_ptr())
         lds.append(ld)
+    wp = [W.data_ptr() for W in weights] + [None] * (3 - nw)
+    bp = [_ptr(b) for b in biases] + [None] * (3 - nw)
     while len(ptrs) < 3:
         ptrs.append(None)
         lds.append(0)
-    if bias is not None:
-        bias = bias.to(torch.float16).contiguous()
-    rc = _lib.load().fresco_linear(x2.data_ptr(), x_ld, W.data_ptr(), _ptr(bias), ptrs[0], ptrs[1], ptrs[2], lds[0],
-                                   lds[1], lds[2], nw, M, N, K, _stream())
+    rc = _lib.load().fresco_linear(x2.data_ptr(), x_ld, wp[0], wp[1], wp[2], bp[0], bp[1], bp[2], ptrs[0], ptrs[1],
+                                   ptrs[2], lds[0], lds[1], lds[2], nw, M, N, K, _stream())
     _lib.check(rc, "fresco_linear(M=%d,N=%d,K=%d,nw=%d)" % (M, N, K, nw))
     return outs
 
@@ -173,6 +186,14 @@ def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, gro
             raise TypeError("kv_rows must be int32")
         kv_rows = kv_rows.contiguous()
         M = kv_rows.numel()
+        limit = min(k_rows, v_rows)
+
+        def run(kv_rows=kv_rows, limit=limit):
+            lo, hi = int(kv_rows.min()), int(kv_rows.max())
+            if lo < 0 or hi + (n_groups - 1) * group_rows >= limit:
+                raise ValueError("kv_rows address rows %d..%d (+%d groups of %d) but k/v have %d rows"
+                                 % (lo, hi, n_groups, group_rows, limit))
+        _check_once(("rows", kv_rows.data_ptr(), M, kv_rows._version, n_groups, int(group_rows), limit), kv_rows, run)
     if kv_rows is None and ((n_groups - 1) * group_rows + M > min(k_rows, v_rows)):
         raise ValueError("k/v have %d/%d rows, grouping needs %d" % (k_rows, v_rows, (n_groups - 1) * group_rows + M))
     lib = _lib.load()
@@ -202,50 +223,113 @@ def attention_f32(q, k, v, scale):
     return out
 
 
-def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk, shard=None):
-    """fresco_temporal_attn: q, k, v (chunk*N, HW, C) fp16; fwd_map (N,HW) int64; mask (HW,N,N) bool.
+_checked_tables = {}
 
-    shard = (N, n_loc, f0, k_rank_stride, v_rank_stride): frame-sharded form -- q is local
-    (chunk*n_loc, HW, C) and k, v are all-gathered buffers holding all N frames (see
-    fresco_temporal_attn_sharded in include/fresco_hip.h)."""
-    _need_gpu(q, k, v, fwd_map, mask)
-    if q.dtype != torch.float16 or k.dtype != torch.float16 or v.dtype != torch.float16:
-        raise TypeError("fresco_amd.temporal_attention: fp16 tensors required")
-    Bt, HW, C = q.shape
-    if shard is None:
-        N = Bt // chunk
-        n_loc, f0, krs, vrs = N, 0, 0, 0
-    else:
-        N, n_loc, f0, krs, vrs = shard
-        assert Bt == chunk * n_loc
-    D = C // heads
-    if shard is None:
-        q, q_ld, _ = _rows(q)
-        k, k_ld, _ = _rows(k)
-        v, v_ld, _ = _rows(v)
-    else:
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+
+def _check_once(key, tensor, fn):
+    """Run the (synchronising) validity check `fn` once per index table; the verdict is cached with the table
+    (address, size, version; a weak reference guards against a recycled address)."""
+    import weakref
+    hit = _checked_tables.get(key)
+    if hit is not None and hit() is tensor:
+        return
+    if len(_checked_tables) > 64:
+        _checked_tables.clear()
+    fn()
+    _checked_tables[key] = weakref.ref(tensor)
+
+
+def _check_permutations(fwd_map, HW):
+    """every row of fwd_map (N, HW) must be a permutation of 0..HW-1: the temporal kernel writes
+    out[f][fwd_map[f][p]], so anything else leaves rows of the result unwritten (the reference's
+    get_mapping_ind always produces permutations, src/flow_utils.py:99-101, 134-135)"""
+    def run():
+        srt = torch.sort(fwd_map, dim=1).values
+        ok = bool((srt == torch.arange(HW, device=fwd_map.device, dtype=fwd_map.dtype)).all())
+        if not ok:
+            raise ValueError("fresco_amd.temporal_attention: fwd_mapping rows must be permutations of 0..%d" % (HW - 1))
+    _check_once(("perm", fwd_map.data_ptr(), tuple(fwd_map.shape), fwd_map._version), fwd_map, run)
+
+
+def _prep_maps(fwd_map, mask, N, HW):
     fwd_map = fwd_map.reshape(N, HW)
     if fwd_map.dtype != torch.int64:
         fwd_map = fwd_map.to(torch.int64)
     fwd_map = fwd_map.contiguous()
-    mask = mask.reshape(HW, N, N)
+    mask = mask.reshape(-1, N, N)
     if mask.dtype == torch.bool:
         mask = mask.contiguous().view(torch.uint8)
     elif mask.dtype != torch.uint8:
         mask = (mask != 0).contiguous().view(torch.uint8)
-    mask = mask.contiguous()
+    return fwd_map, mask.contiguous()
+
+
+def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk):
+    """fresco_temporal_attn: q, k, v (chunk*N, HW, C) fp16; fwd_map (N,HW) int64 (a permutation per frame,
+    checked once per table); mask (HW,N,N) bool."""
+    _need_gpu(q, k, v, fwd_map, mask)
+    if q.dtype != torch.float16 or k.dtype != torch.float16 or v.dtype != torch.float16:
+        raise TypeError("fresco_amd.temporal_attention: fp16 tensors required")
+    Bt, HW, C = q.shape
+    N = Bt // chunk
+    D = C // heads
+    q, q_ld, _ = _rows(q)
+    k, k_ld, _ = _rows(k)
+    v, v_ld, _ = _rows(v)
+    fwd_map, mask = _prep_maps(fwd_map, mask, N, HW)
+    _check_permutations(fwd_map, HW)
     out = torch.empty((Bt, HW, C), dtype=q.dtype, device=q.device)
-    if shard is None:
-        rc = _lib.load().fresco_temporal_attn_ld(q.data_ptr(), k.data_ptr(), v.data_ptr(), fwd_map.data_ptr(),
-                                                 mask.data_ptr(), out.data_ptr(), chunk, N, HW, heads, D,
-                                                 float(scale), q_ld, k_ld, v_ld, _stream())
-    else:
-        rc = _lib.load().fresco_temporal_attn_sharded(q.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                                      fwd_map.data_ptr(), mask.data_ptr(), out.data_ptr(), chunk,
-                                                      N, HW, heads, D, float(scale), n_loc, f0, krs, vrs,
-                                                      _stream())
-    _lib.check(rc, "fresco_temporal_attn(chunk=%d,N=%d,n_loc=%d,HW=%d,H=%d,D=%d)" % (chunk, N, n_loc, HW, heads, D))
+    rc = _lib.load().fresco_temporal_attn_ld(q.data_ptr(), k.data_ptr(), v.data_ptr(), fwd_map.data_ptr(),
+                                             mask.data_ptr(), out.data_ptr(), chunk, N, HW, heads, D,
+                                             float(scale), q_ld, k_ld, v_ld, _stream())
+    _lib.check(rc, "fresco_temporal_attn(chunk=%d,N=%d,HW=%d,H=%d,D=%d)" % (chunk, N, HW, heads, D))
+    return out
+
+
+def temporal_pack(q, k, v, fwd_map, chunk, n_loc, f0, world):
+    """Multi-GPU, way out (fresco_temporal_pack): this rank's frames [f0, f0+n_loc) of q, k, v (chunk*n_loc, HW, C)
+    gathered along the trajectories into per-destination ranges: returns (world, n_loc, chunk, HW/world, 3C)."""
+    _need_gpu(q, k, v, fwd_map)
+    Bl, HW, C = q.shape
+    q, q_ld, _ = _rows(q)
+    k, k_ld, _ = _rows(k)
+    v, v_ld, _ = _rows(v)
+    buf = torch.empty((world, n_loc, chunk, HW // world, 3 * C), dtype=torch.float16, device=q.device)
+    rc = _lib.load().fresco_temporal_pack(q.data_ptr(), k.data_ptr(), v.data_ptr(), fwd_map.data_ptr(), buf.data_ptr(),
+                                          chunk, n_loc, f0, HW, C, world, q_ld, k_ld, v_ld, _stream())
+    _lib.check(rc, "fresco_temporal_pack(chunk=%d,n_loc=%d,HW=%d,C=%d,world=%d)" % (chunk, n_loc, HW, C, world))
+    return buf
+
+
+def temporal_attention_packed(qkv, mask, heads, scale, chunk):
+    """fresco_temporal_attn_packed: qkv (N, chunk, P, 3C) fp16 = q | k | v rows already in trajectory order for a
+    range of P trajectories, mask (P, N, N) for that range -> (N, chunk, P, C)."""
+    _need_gpu(qkv, mask)
+    N, ch, P, C3 = qkv.shape
+    C = C3 // 3
+    D = C // heads
+    if ch != chunk or qkv.dtype != torch.float16 or not qkv.is_contiguous():
+        raise ValueError("temporal_attention_packed: contiguous fp16 (N, chunk, P, 3C) expected")
+    _, mask = _prep_maps(torch.zeros(N, 1, dtype=torch.int64), mask, N, 1)
+    if mask.shape[0] != P:
+        raise ValueError("temporal_attention_packed: mask must cover the %d trajectories of the range" % P)
+    out = torch.empty((N, chunk, P, C), dtype=torch.float16, device=qkv.device)
+    rc = _lib.load().fresco_temporal_attn_packed(qkv.data_ptr(), mask.data_ptr(), out.data_ptr(), chunk, N, P, heads,
+                                                 D, float(scale), _stream())
+    _lib.check(rc, "fresco_temporal_attn_packed(chunk=%d,N=%d,P=%d,H=%d,D=%d)" % (chunk, N, P, heads, D))
+    return out
+
+
+def temporal_unpack(buf, fwd_map, chunk, n_loc, f0, world):
+    """Multi-GPU, way back (fresco_temporal_unpack): buf (world, n_loc, chunk, HW/world, C) = this rank's frames'
+    result rows per trajectory range -> (chunk*n_loc, HW, C) in frame order."""
+    _need_gpu(buf, fwd_map)
+    w, nl, ch, Pw, C = buf.shape
+    HW = Pw * world
+    out = torch.empty((chunk * n_loc, HW, C), dtype=torch.float16, device=buf.device)
+    rc = _lib.load().fresco_temporal_unpack(buf.contiguous().data_ptr(), fwd_map.data_ptr(), out.data_ptr(), chunk,
+                                            n_loc, f0, HW, C, world, _stream())
+    _lib.check(rc, "fresco_temporal_unpack(chunk=%d,n_loc=%d,HW=%d,C=%d,world=%d)" % (chunk, n_loc, HW, C, world))
     return out
 
 

@@ -34,7 +34,6 @@ class FRESCOAttnProcessor2_0:
         self.controller = controller
         self._ws = ops.Workspace()
         self._rows_cache = {}
-        self._wcat_cache = {}
         self.shard = None  # fresco_amd.dist.FrameShard for frame-parallel multi-GPU runs
         self.fuse_projections = True  # q/k/v (and to_out at C = 320) through fresco_linear when they are plain Linears
 
@@ -42,28 +41,14 @@ class FRESCOAttnProcessor2_0:
     def _project(self, attn, x, names, outs=None):
         """[attn.<name>(x) for name in names] in ONE launch that reads x once (fresco_linear), when every module
         is a plain bias-free fp16 nn.Linear of a supported width; otherwise the modules are called as the
-        reference calls them (wrapped / LoRA / quantised layers keep their own forward)."""
+        reference calls them (wrapped / LoRA / quantised layers keep their own forward).  The kernel reads each
+        module's weight where it lives: nothing is stacked or cached, in-place weight updates are always seen."""
         mods = [getattr(attn, n) for n in names]
-        if self.fuse_projections and x.dtype == torch.float16 and x.is_cuda:
-            # the decision and the stacked weight are cached per (module, projection set) and re-validated by
-            # the identity of the modules and the (address, version) of their weights
-            key = (id(attn), names)
-            ws = [getattr(m, "weight", None) for m in mods]  # exotic wrappers may not expose one: never fused
-            sig = tuple((id(m), 0, 0) if not torch.is_tensor(w) else (id(m), w.data_ptr(), w._version)
-                        for m, w in zip(mods, ws))
-            hit = self._wcat_cache.get(key)
-            if hit is None or hit[0] != sig:
-                if len(self._wcat_cache) > 64:
-                    self._wcat_cache.clear()
-                w = None
-                if (all(_plain_linear(m, False) for m in mods)
-                        and len({(m.in_features, m.out_features) for m in mods}) == 1):
-                    w = mods[0].weight.detach() if len(mods) == 1 else torch.cat([m.weight.detach() for m in mods], 0)
-                    w = w.contiguous()
-                hit = (sig, w)
-                self._wcat_cache[key] = hit
-            if hit[1] is not None:
-                return ops.linear(x, hit[1], None, len(mods), outs)
+        if (self.fuse_projections and x.dtype == torch.float16 and x.is_cuda
+                and all(_plain_linear(m, False) for m in mods)
+                and len({(m.in_features, m.out_features) for m in mods}) == 1
+                and all(m.weight.is_contiguous() for m in mods)):
+            return ops.linear(x, [m.weight.detach() for m in mods], None, outs)
         res = [m(x) for m in mods]
         if outs is not None:
             for o, r in zip(outs, res):
@@ -76,7 +61,7 @@ class FRESCOAttnProcessor2_0:
         # a single C = 640 projection is faster in the library GEMM (csrc/proj.hip header): fuse only C = 320
         if (self.fuse_projections and hs.dtype == torch.float16 and hs.is_cuda and _plain_linear(lin, True)
                 and lin.in_features == 320):
-            return ops.linear(hs, lin.weight.detach(), lin.bias.detach(), 1)[0]
+            return ops.linear(hs, [lin.weight.detach()], [lin.bias.detach()])[0]
         return lin(hs)
 
     # flat int32 indices of the True entries of a (N, HW) mask, cached per mask tensor
@@ -181,8 +166,8 @@ class FRESCOAttnProcessor2_0:
 
 def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
     """Frame-parallel form of the FRESCO self-attention branch (fresco_amd/dist.py): this rank holds
-    `shard.n_loc` frames of both CFG halves; K|V (and the cross-frame output, for the temporal pass)
-    are all-gathered over RCCL, everything else is local."""
+    `shard.n_loc` frames of both CFG halves.  Cross-frame keys: broadcast of frame 0 + all-gather of the
+    other frames' selected rows; temporal pass: all-to-all to trajectory shards and back; the rest is local."""
     if input_ndim != 3:
         raise NotImplementedError("fresco_amd: frame-sharded attention expects (B, HW, C) hidden states")
     ctrl, sh = self.controller, self.shard
@@ -193,13 +178,21 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
     head_dim = C // heads
     sm_scale = 1.0 / math.sqrt(head_dim)
     assert B_loc == sh.B_loc and chunk == sh.chunk
-    # q, k, v in one pass over the hidden states; K and V land directly in the fused exchange buffer
+    # q, k, v in one pass over the hidden states; K and V land fused per row (K | V), the layout of the exchange
     query = torch.empty(B_loc, hw, C, dtype=hidden_states.dtype, device=hidden_states.device)
-    kv_loc = torch.empty(2, B_loc, hw, C, dtype=hidden_states.dtype, device=hidden_states.device)
-    self._project(attn, hidden_states, ("to_q", "to_k", "to_v"), outs=[query, kv_loc[0], kv_loc[1]])
-    key = kv_loc[0]
-    # exchange 1: fused K|V, launched before the local work it overlaps with
-    kv, work = sh.all_gather(kv_loc, async_op=True)
+    kv_loc = torch.empty(B_loc, hw, 2 * C, dtype=hidden_states.dtype, device=hidden_states.device)
+    key, value = kv_loc[..., :C], kv_loc[..., C:]
+    self._project(attn, hidden_states, ("to_q", "to_k", "to_v"), outs=[query, key, value])
+    works = []
+    if ctrl.use_cfattn:
+        mask = None
+        if ctrl.attn_mask is not None:
+            for m in ctrl.attn_mask:
+                if m.shape[1] == hw:
+                    mask = m
+        plan = sh.cf_plan(mask, hw, key.device)
+        # launched before the local work they overlap with
+        kvbuf, works = sh.exchange_cf(kv_loc, plan)
     q_att = query
     if ctrl.use_intraattn:
         ref = ctrl(None)
@@ -208,24 +201,14 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
         q_att = ops.attention(q_ref, k_ref, query, heads,
                               ctrl.intraattn_scale_factor * sm_scale, diag_bias=float(ctrl.intraattn_bias),
                               workspace=self._ws)
-    if work is not None:
-        work.wait()
-    kv_flat = kv.view(-1, C)  # rows of (world, 2, B_loc, HW)
+    for w in works:
+        w.wait()
     if ctrl.use_cfattn:
-        mask = None
-        if ctrl.attn_mask is not None:
-            for m in ctrl.attn_mask:
-                if m.shape[1] == hw:
-                    mask = m
-        if mask is not None:
-            key_id = (mask.data_ptr(), tuple(mask.shape), mask._version)
-            rows, group_rows = sh.kv_rows(self._kv_rows(mask), hw, key_id, key.device)
-        else:
-            rows, group_rows = sh.kv_rows(None, hw, ("frame0", hw), key.device)
-        hs = ops.attention(q_att, kv_flat, kv_flat[B_loc * hw:], heads, sm_scale, kv_rows=rows,
-                           n_groups=chunk, M=rows.numel(), group_rows=group_rows, workspace=self._ws)
+        flat = kvbuf.view(-1, 2 * C)
+        hs = ops.attention(q_att, flat[:, :C], flat[:, C:], heads, sm_scale, kv_rows=plan["table"],
+                           n_groups=chunk, M=plan["M"], group_rows=plan["group_rows"], workspace=self._ws)
     else:
-        hs = ops.attention(q_att, key, kv_loc[1], heads, sm_scale, workspace=self._ws)
+        hs = ops.attention(q_att, key, value, heads, sm_scale, workspace=self._ws)
     if ctrl.use_interattn:
         fwd_mapping = interattn_mask = None
         paras = ctrl.interattn_paras
@@ -233,11 +216,10 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
             if f.shape[2] == hw:
                 fwd_mapping = f
                 interattn_mask = paras["interattn_masks"][i]
-        # exchange 2: the cross-frame output of every frame is the temporal pass's V
-        hs_all, _ = sh.all_gather(hs)
-        hs = ops.temporal_attention(query, kv_flat, hs_all.view(-1, C), fwd_mapping, interattn_mask, heads,
-                                    ctrl.interattn_scale_factor * sm_scale, chunk,
-                                    shard=(sh.N, sh.n_loc, sh.f0, 2 * B_loc, B_loc))
+        if fwd_mapping is None:
+            raise ValueError("fresco_amd: no temporal-attention parameters for %d tokens" % hw)
+        hs = sh.temporal(query, key, hs, fwd_mapping, interattn_mask, heads,
+                         ctrl.interattn_scale_factor * sm_scale)
     hs = self._project_out(attn, hs.to(query.dtype))
     hs = attn.to_out[1](hs)
     if attn.residual_connection:

@@ -8,8 +8,8 @@
  *   - never allocates: scratch memory is passed in by the caller, sized by the matching
  *     *_workspace_bytes() query (host-only, no GPU needed);
  *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream);
- *   - no global state (except the opt-in fresco_prof_* timing log): concurrent calls on different
- *     streams with disjoint buffers are safe.
+ *   - no global state (except the opt-in fresco_prof_* timing log, and FRESCO_OPT_SV read once from the
+ *     environment): concurrent calls on different streams / devices with disjoint buffers are safe.
  *
  * Reference interface each entry point replaces (paths relative to the FRESCO tree):
  *   src/diffusion_hacked.py  = DH,  src/flow_utils.py = FU,  src/utils.py = UT,
@@ -98,15 +98,17 @@ size_t fresco_attn_workspace_bytes(int n_groups, int H, int M, int D);
  * (a1)  Fused linear projections  attn.to_q / to_k / to_v (DH:201, 214-215, 260-261) and to_out[0] (DH:375):
  *           out_j = x W_j^T (+ b_j),   j = 0 .. nw-1,  nw <= 3
  *   x    : (M, K) half, row stride x_ld (elements);  read once for all nw outputs
- *   W    : (nw*N, K) half row-major = the nn.Linear weights of the nw projections stacked along dim 0
- *   bias : (nw*N) half or NULL
+ *   W_j  : (N, K) half row-major = the weight of nn.Linear j, read where it lives (nothing is stacked or cached:
+ *          in-place updates of a module's weight are seen by the next call);  W1 / W2 unused beyond nw
+ *   b_j  : (N) half or NULL
  *   out_j: (M, N) half, row stride ld_j (elements); unused outputs NULL
  *   fp32 accumulation, one rounding to half at the end (what the library GEMM behind nn.Linear does).
  *   Supported: K in {320, 640} (SD-1.5 up_blocks.3 / up_blocks.2), N % 32 == 0; anything else returns
  *   FRESCO_EUNSUPPORTED and the caller keeps its own GEMM.
  * ------------------------------------------------------------------------------------------ */
-int fresco_linear(const void* x, int64_t x_ld, const void* W, const void* bias, void* out0, void* out1, void* out2,
-                  int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N, int K, void* stream);
+int fresco_linear(const void* x, int64_t x_ld, const void* W0, const void* W1, const void* W2, const void* b0,
+                  const void* b1, const void* b2, void* out0, void* out1, void* out2, int64_t ld0, int64_t ld1,
+                  int64_t ld2, int nw, int M, int N, int K, void* stream);
 
 
 int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* kv_rows,
@@ -134,7 +136,8 @@ int fresco_attn_fwd_ld(const void* q, const void* k, const void* v, const int32_
  *                                                 | mask[p,f,g] ) * v[c*N+g,row(g),h,:]
  *   q,k,v,out : (chunk*N, HW, H*D) half;  fwd_map : (N, HW) int64 (a permutation per frame);
  *   mask : (HW, N, N) uint8/bool, non-zero = may attend (diagonal always set, FU:120-131).
- *   N <= 32, D multiple of 8.
+ *   Any N with 6*N*H*D + 4*N bytes <= 160 KiB of LDS per trajectory; D in {8, 16, 32, 40, 64, 80}.  Row-table
+ *   entries outside [0, HW) are skipped (nothing is read or written for them).
  * ------------------------------------------------------------------------------------------ */
 int fresco_temporal_attn(const void* q, const void* k, const void* v, const int64_t* fwd_map,
                          const uint8_t* mask, void* out,
@@ -146,15 +149,24 @@ int fresco_temporal_attn_ld(const void* q, const void* k, const void* v, const i
                             int chunk, int N, int HW, int H, int D, float scale,
                             int64_t q_ld, int64_t k_ld, int64_t v_ld, void* stream);
 
-/* Frame-sharded form (multi-GPU): this rank owns the n_loc frames [f0, f0+n_loc) of
- * both CFG halves.  q, out : (chunk*n_loc, HW, H*D) local.  k, v hold ALL N frames as written by an
- * all-gather over ranks: frame g of CFG half c is batch  (g/n_loc)*rank_stride + c*n_loc + g%n_loc
- * (k_rank_stride / v_rank_stride in batches of HW rows; e.g. 2*chunk*n_loc for a fused K|V gather
- * buffer, chunk*n_loc for a plain one).  n_loc = N, f0 = 0 is fresco_temporal_attn. */
-int fresco_temporal_attn_sharded(const void* q, const void* k, const void* v, const int64_t* fwd_map,
-                                 const uint8_t* mask, void* out,
-                                 int chunk, int N, int HW, int H, int D, float scale,
-                                 int n_loc, int f0, int k_rank_stride, int v_rank_stride, void* stream);
+/* Multi-GPU: frames are sharded over ranks, the temporal pass is sharded by TRAJECTORY, so that
+ * every byte crosses the fabric once and the kernel's HBM traffic shrinks with the world size.  Rank r owns the
+ * n_loc frames [f0, f0+n_loc) of both CFG halves and the trajectory range [r*P, (r+1)*P), P = HW / world.
+ *   fresco_temporal_pack  : buf[(d*n_loc + fl)*chunk + c][pl][0:3C] = (q | k | v)[c*n_loc + fl][fwd_map[f0+fl][d*P + pl]]
+ *                           (q, k, v: local (chunk*n_loc, HW, C) with row strides q_ld / k_ld / v_ld); an all-to-all over
+ *                           the leading `world` dimension then leaves on rank r the rows of ALL N frames of its range as
+ *                           (N, chunk, P, 3C);
+ *   fresco_temporal_attn_packed : the attention on such rows, no row table: qkv (N, chunk, P, 3C), mask (P, N, N) = the
+ *                           mask rows of the range, out (N, chunk, P, C);
+ *   fresco_temporal_unpack: after the all-to-all back, buf (world, n_loc, chunk, P, C) holds this rank's frames' result rows
+ *                           per range:  out[c*n_loc + fl][fwd_map[f0+fl][d*P + pl]] = buf[(d*n_loc + fl)*chunk + c][pl]. */
+int fresco_temporal_pack(const void* q, const void* k, const void* v, const int64_t* fwd_map, void* buf, int chunk,
+                         int n_loc, int f0, int HW, int C, int world, int64_t q_ld, int64_t k_ld, int64_t v_ld,
+                         void* stream);
+int fresco_temporal_attn_packed(const void* qkv, const uint8_t* mask, void* out, int chunk, int N, int P, int H, int D,
+                                float scale, void* stream);
+int fresco_temporal_unpack(const void* buf, const int64_t* fwd_map, void* out, int chunk, int n_loc, int f0, int HW,
+                           int C, int world, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a8)  flow_warp / bilinear_sample  (GEO:41-72): bilinear, zeros padding, align_corners=True.

@@ -1,5 +1,6 @@
-"""Frame-sharding host logic on CPU: world_size-2 gloo run of the all-gather + index remapping that
-feed the sharded kernels (the kernels themselves are covered on the GPU by test_gpu_sharded.py)."""
+"""Frame-sharding host logic on CPU: world_size-2 gloo run of the collectives + index plans that feed the
+sharded kernels -- sparse cross-frame exchange (broadcast + all-gather), trajectory all-to-all, halos
+(the kernels themselves are covered on the GPU by test_gpu_sharded.py)."""
 import os
 import socket
 
@@ -22,42 +23,61 @@ def _worker(rank, world, port, N, chunk, HW, C, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from fresco_amd.dist import FrameShard, gathered_batch
+        from fresco_amd.dist import FrameShard
 
         g = torch.Generator().manual_seed(0)
         K = torch.randn(chunk * N, HW, C, generator=g)  # the global tensors every rank can rebuild
         V = torch.randn(chunk * N, HW, C, generator=g)
+        Q = torch.randn(chunk * N, HW, C, generator=g)
         mask = torch.rand(N, HW, generator=g) < 0.4
         mask[0] = True
         sh = FrameShard(N, chunk, rank, world)
         sel = sh.local_batch_index()
-        k_loc, v_loc = K[sel].contiguous(), V[sel].contiguous()
-        kv, work = sh.all_gather(torch.stack((k_loc, v_loc)), async_op=True)
-        work.wait()
-        flat = kv.view(-1, C)
-        B_loc = chunk * sh.n_loc
-        # (1) cross-frame key rows: C-ABI addressing g*group_rows + kv_rows[m] into the gather buffer
-        rows = mask.reshape(-1).nonzero().squeeze(1)
-        remapped, group_rows = sh.kv_rows(rows, HW, "m", "cpu")
+        kv_loc = torch.cat((K[sel], V[sel]), dim=-1).contiguous()  # fused K|V rows, the exchange layout
         ok = True
-        for grp in range(chunk):
-            got_k = flat[grp * group_rows + remapped.long()]
-            got_v = flat[B_loc * HW:][grp * group_rows + remapped.long()]
-            want_k = K.view(chunk, N * HW, C)[grp, rows]
-            want_v = V.view(chunk, N * HW, C)[grp, rows]
-            ok &= torch.equal(got_k, want_k) and torch.equal(got_v, want_v)
-        # frame-0-only fallback
-        r0, gr0 = sh.kv_rows(None, HW, "f0", "cpu")
-        for grp in range(chunk):
-            ok &= torch.equal(flat[grp * gr0 + r0.long()], K.view(chunk, N, HW, C)[grp, 0])
-        # (2) temporal pass addressing: frame g of half c inside the fused and the plain buffer
-        hs_all, _ = sh.all_gather(v_loc)
-        for c in range(chunk):
-            for gf in range(N):
-                kb = gathered_batch(gf, c, sh.n_loc, 2 * B_loc)
-                vb = gathered_batch(gf, c, sh.n_loc, B_loc)
-                ok &= torch.equal(kv.view(-1, HW, C)[kb], K[c * N + gf])
-                ok &= torch.equal(hs_all.view(-1, HW, C)[vb], V[c * N + gf])
+        # (1) sparse cross-frame exchange: broadcast of frame 0 + all-gather of the other frames' selected rows;
+        # C-ABI addressing g*group_rows + table[m] into the exchange buffer must give the reference's key rows
+        rows = mask.reshape(-1).nonzero().squeeze(1)
+        for m_ in (mask, None):
+            plan = sh.cf_plan(m_, HW, "cpu")
+            buf, works = sh.exchange_cf(kv_loc, plan)
+            for w in works:
+                w.wait()
+            flat = buf.view(-1, 2 * C)
+            want_rows = rows if m_ is not None else torch.arange(HW)
+            assert plan["M"] == want_rows.numel()
+            for grp in range(chunk):
+                got = flat[grp * plan["group_rows"] + plan["table"].long()]
+                ok &= torch.equal(got[:, :C], K.view(chunk, N * HW, C)[grp, want_rows])
+                ok &= torch.equal(got[:, C:], V.view(chunk, N * HW, C)[grp, want_rows])
+            # what crosses the fabric: frame 0 once + the padded selected rows, not every frame
+            n_rest = int(mask[1:].sum()) if m_ is not None else 0
+            assert buf.shape[1] <= HW + world * max(n_rest, 1) and buf.shape[1] < N * HW
+        # (2) the all-to-all that turns frame shards into trajectory shards and back (the pack / unpack kernels are
+        # emulated with index arithmetic here; the kernels themselves are checked on the GPU)
+        fwd = torch.stack([torch.randperm(HW, generator=g) for _ in range(N)])
+        Pw = HW // world
+        n_loc = sh.n_loc
+        send = torch.empty(world, n_loc, chunk, Pw, 3 * C)
+        for d in range(world):
+            for fl in range(n_loc):
+                r = fwd[sh.f0 + fl, d * Pw:(d + 1) * Pw]
+                for c in range(chunk):
+                    b = c * N + sh.f0 + fl
+                    send[d, fl, c] = torch.cat((Q[b, r], K[b, r], V[b, r]), dim=-1)
+        recv = sh.all_to_all(send).view(N, chunk, Pw, 3 * C)
+        for gf in range(N):
+            r = fwd[gf, rank * Pw:(rank + 1) * Pw]
+            for c in range(chunk):
+                ok &= torch.equal(recv[gf, c], torch.cat((Q[c * N + gf, r], K[c * N + gf, r], V[c * N + gf, r]), -1))
+        back = sh.all_to_all(recv[..., :C].contiguous().view(world, n_loc, chunk, Pw, C))  # "result" = the q rows
+        out = torch.empty(chunk * n_loc, HW, C)
+        for d in range(world):
+            for fl in range(n_loc):
+                r = fwd[sh.f0 + fl, d * Pw:(d + 1) * Pw]
+                for c in range(chunk):
+                    out[c * n_loc + fl, r] = back[d, fl, c]
+        ok &= torch.equal(out, Q[sel])
         # (3) optimize_feature halos: frame before / after the owned range (ring), and the pair list
         X = torch.randn(chunk * N, 3, 4, 5, generator=g)
         hl, hr = sh.exchange_halos(X[sel].contiguous())
@@ -89,3 +109,24 @@ def test_local_batch_index_partition():
     allidx = torch.cat([local_batch_index(N, chunk, r, world) for r in range(world)])
     assert sorted(allidx.tolist()) == list(range(chunk * N))
     assert local_batch_index(N, chunk, 1, world).tolist() == [2, 3, 10, 11]
+
+
+def test_cf_plan_tables():
+    from fresco_amd.dist import cf_plan
+
+    N, HW, world = 4, 6, 2
+    mask = torch.zeros(N, HW, dtype=torch.bool)
+    mask[0] = True
+    mask[1, [1, 4]] = True   # rank 0 (frames 0, 1)
+    mask[2, [0]] = True      # rank 1 (frames 2, 3)
+    mask[3, [2, 3, 5]] = True
+    p0, p1 = cf_plan(mask, N, HW, world, 0), cf_plan(mask, N, HW, world, 1)
+    assert p0["Rmax"] == p1["Rmax"] == 4 and p0["group_rows"] == HW + 2 * 4 and p0["M"] == HW + 6
+    assert p0["table"].tolist() == list(range(HW)) + [HW + 0, HW + 1] + [HW + 4 + i for i in range(4)]
+    assert torch.equal(p0["table"], p1["table"])
+    assert p0["local_sel"].tolist() == [HW + 1, HW + 4, 0, 0]          # frame 1 = local frame 1 of rank 0
+    assert p1["local_sel"].tolist() == [0, HW + 2, HW + 3, HW + 5]     # frames 2, 3 = local frames 0, 1 of rank 1
+    none = cf_plan(None, N, HW, world, 1)
+    assert none["Rmax"] == 0 and none["table"].tolist() == list(range(HW)) and none["group_rows"] == HW
+    with pytest.raises(ValueError):
+        cf_plan(~mask, N, HW, world, 0)

@@ -24,7 +24,9 @@ def test_linear_matches_fp32_matmul(K, N, nw, M, bias):
     x = torch.randn(M, K, generator=g).half()
     W = (torch.randn(nw * N, K, generator=g) / K ** 0.5).half()
     b = torch.randn(nw * N, generator=g).half() if bias else None
-    outs = ops.linear(x.to(DEV), W.to(DEV), None if b is None else b.to(DEV), nw)
+    Ws = [w.contiguous().to(DEV) for w in W.chunk(nw, 0)]
+    bs = None if b is None else [t.contiguous().to(DEV) for t in b.chunk(nw, 0)]
+    outs = ops.linear(x.to(DEV), Ws, bs)
     assert len(outs) == nw
     for o, r in zip(outs, _ref(x, W, b, nw)):
         assert o.dtype == torch.float16 and tuple(o.shape) == (M, N)
@@ -42,14 +44,14 @@ def test_linear_strided_views_and_batch_dims():
     x = torch.randn(B, HW, C, generator=g).half().to(DEV)
     W = (torch.randn(2 * C, C, generator=g) / C ** 0.5).half().to(DEV)
     kv = torch.zeros(2, B, HW, C, dtype=torch.float16, device=DEV)
-    outs = ops.linear(x, W, None, 2, outs=[kv[0], kv[1]])
+    outs = ops.linear(x, [W[:C].contiguous(), W[C:].contiguous()], None, outs=[kv[0], kv[1]])
     assert outs[0].data_ptr() == kv[0].data_ptr()
     ref = _ref(x.cpu(), W.cpu(), None, 2)
     assert float((kv[0].float().cpu() - ref[0]).abs().max()) < 3e-3
     assert float((kv[1].float().cpu() - ref[1]).abs().max()) < 3e-3
     # column-sliced input (row stride 2C)
     wide = torch.randn(B, HW, 2 * C, generator=g).half().to(DEV)
-    o = ops.linear(wide[..., C:], W[:C], None, 1)[0]
+    o = ops.linear(wide[..., C:], [W[:C].contiguous()])[0]
     r = _ref(wide[..., C:].cpu(), W[:C].cpu(), None, 1)[0]
     assert float((o.float().cpu() - r).abs().max()) < 3e-3
 
@@ -86,9 +88,9 @@ def test_processor_fuses_only_plain_linears_and_tracks_weight_updates():
     seen = []
     real = fresco_amd.ops.linear
 
-    def spy(*a, **k):
-        seen.append(a[3] if len(a) > 3 else k.get("nw", 1))
-        return real(*a, **k)
+    def spy(x_, weights, *a, **k):
+        seen.append(len(weights))
+        return real(x_, weights, *a, **k)
 
     fresco_amd.ops.linear = spy
     try:
@@ -98,11 +100,14 @@ def test_processor_fuses_only_plain_linears_and_tracks_weight_updates():
         ref = O.fresco_attention(x.float().cpu(), W[0], W[1], W[2], W[3], attn.to_out[0].bias.detach().float().cpu(), H,
                                  round_dtype=torch.float16)
         assert float((y.float().cpu() - ref).abs().max()) < 3e-3
-        # in-place weight update: the stacked copy must follow
+        # in-place weight updates, also the kind that leaves `_version` and the address alone (EMA copy_to / LoRA
+        # merges write through `.data`): the kernel reads the live weights, there is no stacked copy to go stale
         with torch.no_grad():
             attn.to_k.weight.mul_(-1.0)
+        attn.to_v.weight.data.mul_(0.5)
         y2 = proc(attn, x)
         W[1] = -W[1]
+        W[2] = 0.5 * W[2]
         ref2 = O.fresco_attention(x.float().cpu(), W[0], W[1], W[2], W[3], attn.to_out[0].bias.detach().float().cpu(), H,
                                   round_dtype=torch.float16)
         assert float((y2.float().cpu() - ref2).abs().max()) < 3e-3

@@ -1,7 +1,7 @@
 """Frame-sharded attention path on ONE GPU: every rank of a world of 2 / 4 is emulated by a thread
-whose FrameShard.all_gather is a barrier-synchronised in-process gather, so the sharded kernels
-(remapped key rows out of the fused K|V gather buffer, fresco_temporal_attn_sharded) and the
-processor's sharded branch are exercised exactly as under RCCL.  Result must equal the single-GPU
+whose FrameShard collectives are barrier-synchronised in-process exchanges, so the sharded kernels
+(remapped key rows out of the sparse cross-frame exchange buffer, fresco_temporal_pack / _attn_packed /
+_unpack around the trajectory all-to-all) and the processor's sharded branch are exercised exactly as under RCCL.  Result must equal the single-GPU
 processor's rows for the same global batch."""
 import copy
 import threading
@@ -16,21 +16,45 @@ DEV = "cuda"
 
 
 class ThreadShard:
-    """Drop-in for fresco_amd.dist.FrameShard with an in-process all_gather."""
+    """Drop-in for fresco_amd.dist.FrameShard whose collectives are barrier-synchronised in-process exchanges."""
 
     def __init__(self, base, slots, barrier):
         self.__dict__.update(base.__dict__)
         self._base, self._slots, self._barrier = base, slots, barrier
 
-    def kv_rows(self, *a):
-        return self._base.kv_rows(*a)
+    def _exchange(self, x):
+        self._slots[self.rank] = x
+        self._barrier.wait()
+        got = [self._slots[r] for r in range(self.world)]
+        self._barrier.wait()  # everyone has read the slots before they are reused
+        return got
+
+    def cf_plan(self, *a):
+        return self._base.cf_plan(*a)
 
     def all_gather(self, x, async_op=False):
-        self._slots[self.rank] = x.contiguous()
-        self._barrier.wait()
-        out = torch.stack([self._slots[r] for r in range(self.world)], 0)
-        self._barrier.wait()  # everyone has read the slots before they are reused
-        return out, None
+        return torch.stack([t.contiguous() for t in self._exchange(x.contiguous())], 0), None
+
+    def all_gather_into(self, out, x, async_op=False):
+        out.copy_(torch.cat([t.contiguous() for t in self._exchange(x.contiguous())], 0).view_as(out))
+        return None
+
+    def broadcast(self, x, src, async_op=False):
+        got = self._exchange(x.clone())
+        x.copy_(got[src])
+        return None
+
+    def all_to_all(self, x):
+        got = self._exchange(x.contiguous())
+        return torch.stack([got[s][self.rank] for s in range(self.world)], 0).contiguous()
+
+    def exchange_cf(self, kv_loc, plan):
+        from fresco_amd.dist import FrameShard
+        return FrameShard.exchange_cf(self, kv_loc, plan)
+
+    def temporal(self, *a):
+        from fresco_amd.dist import FrameShard
+        return FrameShard.temporal(self, *a)
 
 
 @pytest.mark.parametrize("world", [2, 4])

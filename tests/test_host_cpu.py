@@ -153,11 +153,13 @@ def test_capi_argument_validation_without_gpu():
     assert attn(wsb=ws - 1) == EWS
     assert attn(D=24, wsb=1 << 30) == EUNSUP    # head dims are instantiated for 8,16,32,40,64,80,96,128
     assert lib.fresco_attn_fwd_ld(p, p, p, None, p, p, ws, 4, 8, 64, 40, 2, 100, 200, 0.1, 0.0, 300, 320, None) == EINVAL
-    # temporal pass: N*H > 256 threads per trajectory, head dim without an instantiation, bad sharding
-    assert lib.fresco_temporal_attn(p, p, p, p, p, p, 2, 40, 64, 8, 40, 0.1, None) == EUNSUP
+    # temporal pass: a trajectory's rows beyond the LDS, head dim without an instantiation, bad sharding
+    assert lib.fresco_temporal_attn(p, p, p, p, p, p, 2, 2000, 64, 8, 40, 0.1, None) == EUNSUP
     assert lib.fresco_temporal_attn(p, p, p, p, p, p, 2, 8, 64, 8, 24, 0.1, None) == EUNSUP
     assert lib.fresco_temporal_attn(p, p, p, None, p, p, 2, 8, 64, 8, 40, 0.1, None) == EINVAL
-    assert lib.fresco_temporal_attn_sharded(p, p, p, p, p, p, 2, 8, 64, 8, 40, 0.1, 3, 0, 0, 0, None) == EINVAL
+    assert lib.fresco_temporal_attn_packed(None, p, p, 2, 8, 64, 8, 40, 0.1, None) == EINVAL
+    assert lib.fresco_temporal_pack(p, p, p, p, p, 2, 4, 0, 64, 320, 3, 320, 320, 320, None) == EINVAL  # 64 % 3
+    assert lib.fresco_temporal_unpack(p, p, None, 2, 4, 0, 64, 320, 2, None) == EINVAL
     # warp chain needs two frames; dilate needs an odd kernel; AdaIN needs >= 2 elements per row and a known dtype
     assert lib.fresco_warp_fuse_chain(p, p, p, p, p, p, p, p, 2, 1, 4, 8, 8, None) == EUNSUP
     assert lib.fresco_dilate(p, p, 1, 8, 8, 4, None) == EINVAL

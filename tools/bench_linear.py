@@ -17,10 +17,9 @@ g = torch.Generator().manual_seed(0)
 for (M, C) in ((16 * 4096, 320), (16 * 1024, 640), (2 * 4096, 320), (2 * 1024, 640)):
     x = torch.randn(M, C, generator=g).half().cuda()
     Ws = [(torch.randn(C, C, generator=g) / C ** 0.5).half().cuda() for _ in range(3)]
-    W3 = torch.cat(Ws, 0).contiguous()
     b = torch.randn(C, generator=g).half().cuda()
     lin3 = t(lambda: [torch.nn.functional.linear(x, w) for w in Ws])
-    fus3 = t(lambda: ops.linear(x, W3, None, 3))
+    fus3 = t(lambda: ops.linear(x, Ws))
     lin1 = t(lambda: torch.nn.functional.linear(x, Ws[0], b))
-    fus1 = t(lambda: ops.linear(x, Ws[0], b, 1))
+    fus1 = t(lambda: ops.linear(x, [Ws[0]], [b]))
     print("M=%d C=%d: q,k,v torch %.1f us  fused %.1f us | out-proj torch %.1f us  ours %.1f us" % (M, C, lin3, fus3, lin1, fus1))
