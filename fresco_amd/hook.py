@@ -131,10 +131,11 @@ def patch_reference(dh=None, pf=None, fu=None):
         dh.flow_warp = _warp.flow_warp
         dh.adaptive_instance_normalization = _warp.adaptive_instance_normalization
     if pf is not None:
-        from . import step as _step
+        # (`from . import step` would fetch the FUNCTION the package re-exports under the submodule's name)
+        from .step import step as _step_fn
 
         pf.warp_tensor = _warp.warp_tensor
-        pf.step = _step.step  # inference() looks `step` up in its module globals (pipe_FRESCO.py:222-228)
+        pf.step = _step_fn  # inference() looks `step` up in its module globals (pipe_FRESCO.py:222-228)
     if fu is not None:
         from . import mapping
 
