@@ -241,6 +241,61 @@ def torch_gpu_baseline(layers, params, N, device, ours):
                                         "(outputs are O(0.3); both sides round to fp16)"))
 
 
+def cfg2b_large_mask(layers, N, R, device, lib):
+    """SURVEY 8d's second mask setting at the up_blocks.3 shapes: Bernoulli(0.5) blocks of 32x32 px occluded in the
+    frames after the first -> M ~ (1 + 0.5 (N-1)) HW cross-frame keys, the regime real clips push towards and where
+    the packed key images stop fitting an XCD's L2.  Returns the flash kernel's mean HIP-event time and fraction."""
+    import fresco_amd.ops as ops
+
+    l = layers[3]
+    side = R // 8
+    HW = side * side
+    gen = torch.Generator().manual_seed(7)
+    nb = max(side // 4, 1)  # 32 px = 4 tokens at 1/8 scale
+    blocks = torch.rand(N, nb, nb, generator=gen) < 0.5
+    mask = blocks.repeat_interleave(side // nb, 1).repeat_interleave(side // nb, 2).reshape(N, HW)
+    mask[0] = True
+    rows = mask.reshape(-1).nonzero().squeeze(1).to(torch.int32).to(device)
+    a = l["attn"]
+    with torch.no_grad():
+        q, k, v = ops.linear(l["hidden"], [a.to_q.weight, a.to_k.weight, a.to_v.weight])
+        M = rows.numel()
+        kw = dict(kv_rows=rows, n_groups=2, M=M, group_rows=N * HW)
+        for _ in range(2):
+            ops.attention(q, k, v, 8, 1.0 / math.sqrt(40), **kw)
+        torch.cuda.synchronize()
+        lib.fresco_prof_enable(64)
+        for _ in range(5):
+            ops.attention(q, k, v, 8, 1.0 / math.sqrt(40), **kw)
+        torch.cuda.synchronize()
+        lib.fresco_prof_disable()
+    t = [ms for tag, d, ms in read_prof(lib, 64) if tag == 1]
+    mean_s = sum(t) / len(t) * 1e-3
+    flop = 4.0 * 2 * N * HW * M * 320
+    return dict(workload="up_blocks.3 cross-frame pass, block-occlusion mask: M = %d keys (%.2f x HW)" % (M, M / HW),
+                flash_avg_us=round(mean_s * 1e6, 1), algorithmic_tflops=round(flop / mean_s / 1e12, 1),
+                frac_of_mfma_peak=round(flop / mean_s / PEAK_F16_DENSE, 4))
+
+
+def collective_bytes_per_step(N, R, world, M_rest):
+    """Fabric bytes one rank RECEIVES per hot-path step of the schedule mix (frame-sharded run, fresco_amd/dist.py):
+    cross-frame exchange on every layer call (broadcast of frame 0's fused K|V rows + all-gather of the other frames'
+    selected rows, padded to the largest rank's count), trajectory all-to-all (q|k|v out, result back) while the
+    temporal pass is on (8 of 15 steps)."""
+    out = {}
+    tot = 0.0
+    for name, C, down in (("L2", 640, 16), ("L3", 320, 8)):
+        HW = (R // down) ** 2
+        n_loc = N // world
+        cf = 2 * HW * 2 * C * 2 * (0 if world == 1 else 1)                       # frame 0, both CFG halves, K|V, fp16
+        cf += 2 * (world - 1) * M_rest[name] * 2 * C * 2                         # padded selected rows of the other ranks
+        a2a = (world - 1) / world * (2 * n_loc * HW) * (3 * C + C) * 2           # q|k|v out + result back
+        out[name] = dict(cross_frame=int(cf), temporal_all_to_all=int(a2a))
+        tot += 3 * (cf + a2a * 8.0 / 15.0)
+    out["per_step_mean"] = int(tot)
+    return out
+
+
 def read_prof(lib, cap):
     tags = (ctypes.c_int * cap)()
     dims = (ctypes.c_int * (4 * cap))()
@@ -370,8 +425,11 @@ def main():
                         frac=round(ach / PEAK_F16_DENSE, 4), traffic=pmc_traffic_bytes("attn_flash_kernelILi40"),
                         algorithmic_bytes_per_launch=int(2 * B_loc * HW3 * 320 * 2 + 2 * 2 * M3 * 320 * 2),
                         launches=len(dom),
-                        note="peak = spec figure; a pure-MFMA micro-kernel sustains 1.6-1.85 PFLOP/s on these boxes "
-                             "(profiles/r01_mfma_peak_ubench.txt)",
+                        executed_flop_per_launch=flop * 1.4,
+                        note="achieved / frac count ALGORITHMIC flop against the 2.5 PFLOP/s dense fp16 spec peak; the kernel "
+                             "executes 1.40 x that (head dim 40 padded to 48 in QK^T and to 64 rows in PV); what bounds it is "
+                             "the SIMD's VALU/issue port (64 exp + 32 cvt + 28 MFMA issues per 64 keys x 64 queries) beside "
+                             "the matrix pipe: profiles/r02_attn_experiments.txt",
                         avg_launch_us=round(mean_s * 1e6, 2), algorithmic_flop_per_launch=flop)
     by_tag = {}
     for tag, d, ms in recs:
@@ -399,11 +457,21 @@ def main():
                             "included), 15-step schedule 1x spatial+cf+temporal / 7x cf+temporal / 7x cf"
                             % (N, R, R, (R // 16) ** 2, HW3),
                 "cross_frame_keys_M": {"L3": M3, "L2": int(params[16][3].sum())},
-                "parallelism": "frame-shard x%d (RCCL all-gather of K|V)" % world if world > 1 else "single GPU",
+                "parallelism": ("frame-shard x%d: broadcast of frame 0's K|V + all-gather of the masked rows, trajectory "
+                                "all-to-all for the temporal pass (RCCL)" % world) if world > 1 else "single GPU",
             },
             "roofline": roofline,
             "kernel_avg_us": kernels_us,
         }
+        if world > 1:
+            M_rest = {}
+            for name, down in (("L2", 16), ("L3", 8)):
+                m = params[down][3]
+                cnt = [int(m[max(r * n_loc, 1):(r + 1) * n_loc].sum()) for r in range(world)]
+                M_rest[name] = max(cnt)
+            res["collective_bytes_received_per_rank"] = collective_bytes_per_step(N, R, world, M_rest)
+        if world == 1:
+            res["cfg2b"] = cfg2b_large_mask(layers, N, R, device, lib)
         if not args.no_cpu_baseline and world == 1:
             def ours(mode, l):
                 set_mode(ctrl, mode, [l["ref_local"]], paras, masks)

@@ -79,12 +79,19 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void
         dma_off[i] = (r < Cfg::TF && dc < Cfg::CPR - 1) ? (uint32_t)(r * K * 2 + dc * 16) : 0u;
     }
     // feature tile ft belongs to projection ft / tiles_per_out: every projection keeps its own (live) weight
-    // matrix, nothing is stacked or cached on the host side
+    // matrix, nothing is stacked or cached on the host side.  The tile's slab address is scalar arithmetic on
+    // values the loop below carries (wave-uniform): no per-lane selects in front of the DMA.
     const int tiles_per_out = N / Cfg::TF;
-    auto stage = [&](int ft, int kc, int buf) __attribute__((always_inline)) {
-        const int jw = ft / tiles_per_out;
-        const char* wbase = reinterpret_cast<const char*>(jw == 0 ? W0 : (jw == 1 ? W1 : W2));
-        const char* src = wbase + ((int64_t)(ft - jw * tiles_per_out) * Cfg::TF * K + kc * Cfg::KC) * 2;  // wave-uniform
+    auto tile_base = [&](int ft) __attribute__((always_inline)) -> const char* {
+        const int jw = __builtin_amdgcn_readfirstlane(ft / tiles_per_out);
+        // (arithmetic instead of a three-way select: the compiler turns the select into a scratch-memory table)
+        const int64_t d1 = reinterpret_cast<const char*>(W1) - reinterpret_cast<const char*>(W0);
+        const int64_t d2 = reinterpret_cast<const char*>(W2) - reinterpret_cast<const char*>(W0);
+        const int64_t dj = (int64_t)(jw == 1) * d1 + (int64_t)(jw == 2) * d2;
+        return reinterpret_cast<const char*>(W0) + dj + (int64_t)(ft - jw * tiles_per_out) * Cfg::TF * K * 2;
+    };
+    auto stage = [&](const char* tbase, int kc, int buf) __attribute__((always_inline)) {
+        const char* src = tbase + kc * Cfg::KC * 2;  // wave-uniform
         char* dst = smem + buf * Cfg::BUFB + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < Cfg::PW; ++i)
@@ -96,10 +103,12 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void
     int j = ft0 / tiles_per_out;
     int col = (ft0 % tiles_per_out) * Cfg::TF;
 
-    stage(ft0, 0, 0);
+    const char* tb_cur = tile_base(ft0);
+    stage(tb_cur, 0, 0);
     __syncthreads();
     int buf = 0;
     for (int ft = ft0; ft < ft1; ++ft) {
+        const char* tb_next = ft + 1 < ft1 ? tile_base(ft + 1) : tb_cur;
         floatx16 acc0, acc1;  // two independent accumulation chains (even / odd k-steps)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -110,9 +119,9 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void
         for (int kc = 0; kc < Cfg::NKC; ++kc) {
             // next slab: the other buffer was released by the barrier that ended the previous step
             if (kc + 1 < Cfg::NKC)
-                stage(ft, kc + 1, buf ^ 1);
+                stage(tb_cur, kc + 1, buf ^ 1);
             else if (ft + 1 < ft1)
-                stage(ft + 1, 0, buf ^ 1);
+                stage(tb_next, 0, buf ^ 1);
             const char* wr = smem + buf * Cfg::BUFB + frow * Cfg::ROWB + hi * Cfg::KC;  // hi * (KC/2) halfs
 #pragma unroll
             for (int ks = 0; ks < Cfg::KS; ks += 2) {
@@ -133,7 +142,9 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void
             for (int half = 0; half < 2; ++half) {
                 half8_t w;
                 float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const half_t* bias = (j == 0) ? b0 : (j == 1 ? b1 : b2);
+                const half_t* bias = b0;  // (same: no pointer table)
+                if (j == 1) bias = b1;
+                if (j == 2) bias = b2;
                 if (bias) {
                     const half8_t b8 = *reinterpret_cast<const half8_t*>(bias + col + half * 16 + hi * 8);
 #pragma unroll
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 ? (K <= 320 ? 3 : 2) : 1)) void
                 *reinterpret_cast<half8_t*>(o + half * 16) = w;
             }
         }
+        tb_cur = tb_next;
         col += Cfg::TF;
         if (col == N) {
             col = 0;

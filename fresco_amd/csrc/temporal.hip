@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(
     half_t* ks = qs + (size_t)R * C;
     half_t* vs = ks + (size_t)R * C;
     int* rows = reinterpret_cast<int*>(vs + (size_t)R * C);  // [PB][N] row of frame g (-1: no such trajectory)
+    uint8_t* msk = reinterpret_cast<uint8_t*>(rows + R);     // [PB][N][N] the trajectories' mask rows
 
     for (int i = tid; i < R; i += 256) {
         const int pl = i / N, g = i % N;
@@ -55,6 +56,12 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(
             if (r < 0 || r >= HW) r = -1;  // (a row table that is not a permutation is the caller's bug; never read out of bounds)
         }
         rows[i] = r;
+    }
+    // the PB*N*N mask bytes of these trajectories are contiguous in memory: staged once (a per-item read from
+    // global memory inside the frame loop costs a memory round trip per frame)
+    for (int i = tid; i < R * N; i += 256) {
+        const int64_t gi = (int64_t)p0 * N * N + i;
+        msk[i] = gi < (int64_t)HW * N * N ? mask[gi] : 0;
     }
     __syncthreads();
 
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = 0.f;
         float m_run = -1e30f, l_run = 0.f;
-        const uint8_t* mrow = mask + ((int64_t)p * N + f) * N;
+        const uint8_t* mrow = msk + (pl * N + f) * N;
         const half_t* kbase = ks + (size_t)pl * N * C + h * D;
         const half_t* vbase = vs + (size_t)pl * N * C + h * D;
         for (int g = 0; g < N; ++g) {
@@ -187,7 +194,7 @@ static int launch_temporal(const half_t* q, const half_t* k, const half_t* v, co
                            int64_t q_ld, int64_t k_ld, int64_t v_ld, hipStream_t st) {
     const int C = H * D;
     // LDS: Q, K and V rows of PB trajectories + the row table; two blocks per CU where that is possible
-    const size_t per_traj = (size_t)N * C * 6 + (size_t)N * 4;
+    const size_t per_traj = (size_t)N * C * 6 + (size_t)N * 4 + (size_t)N * N;
     if (per_traj > 160 * 1024) return FRESCO_EUNSUPPORTED;
     int PB = (int)((76 * 1024) / per_traj);
     if (PB < 1) PB = 1;
