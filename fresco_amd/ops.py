@@ -102,7 +102,7 @@ _default_ws = _PerStreamWorkspace()
 # ---------------------------------------------------------------------------------------------
 def linear_supported(K, N, dtype):
     """shapes / dtype fresco_linear takes (SD-1.5 up_blocks.2/3 attention widths); others keep torch's GEMM"""
-    return dtype == torch.float16 and K in (320, 640) and N % 32 == 0
+    return dtype == torch.float16 and K in (320, 640) and N % 64 == 0
 
 
 def linear(x, weights, biases=None, outs=None):

@@ -103,7 +103,7 @@ size_t fresco_attn_workspace_bytes(int n_groups, int H, int M, int D);
  *   b_j  : (N) half or NULL
  *   out_j: (M, N) half, row stride ld_j (elements); unused outputs NULL
  *   fp32 accumulation, one rounding to half at the end (what the library GEMM behind nn.Linear does).
- *   Supported: K in {320, 640} (SD-1.5 up_blocks.3 / up_blocks.2), N % 32 == 0; anything else returns
+ *   Supported: K in {320, 640} (SD-1.5 up_blocks.3 / up_blocks.2), N % 64 == 0; anything else returns
  *   FRESCO_EUNSUPPORTED and the caller keeps its own GEMM.
  * ------------------------------------------------------------------------------------------ */
 int fresco_linear(const void* x, int64_t x_ld, const void* W0, const void* W1, const void* W2, const void* b0,

@@ -17,7 +17,7 @@ def _ref(x, W, b, nw):
 
 @pytest.mark.parametrize("K,N,nw,M,bias", [(320, 320, 3, 1000, False), (640, 640, 3, 300, False),
                                             (320, 320, 1, 4096, True), (640, 640, 2, 129, True),
-                                            (320, 64, 1, 5, False), (640, 96, 3, 128, True)])
+                                            (320, 64, 1, 5, False), (640, 128, 3, 128, True), (320, 960, 1, 777, True)])
 def test_linear_matches_fp32_matmul(K, N, nw, M, bias):
     import fresco_amd.ops as ops
     g = synth.gen(K + N + nw + M)
