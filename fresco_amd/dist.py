@@ -194,8 +194,9 @@ class FrameShard:
         if HW % self.world != 0:
             raise ValueError("tokens (%d) must divide evenly over %d ranks" % (HW, self.world))
         Pw = HW // self.world
+        owner = fwd_map
         fwd_map, mask = ops._prep_maps(fwd_map, mask, self.N, HW)
-        ops._check_permutations(fwd_map, HW)
+        ops._check_permutations(owner, fwd_map, HW)
         send = ops.temporal_pack(q, k, v, fwd_map, self.chunk, self.n_loc, self.f0, self.world)
         recv = self.all_to_all(send)  # (src, fl, c, pl, 3C) = (frame, c, pl, 3C)
         outp = ops.temporal_attention_packed(recv.view(self.N, self.chunk, Pw, 3 * C),

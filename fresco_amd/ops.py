@@ -239,23 +239,25 @@ def _check_once(key, tensor, fn):
     _checked_tables[key] = weakref.ref(tensor)
 
 
-def _check_permutations(fwd_map, HW):
+def _check_permutations(owner, fwd_map, HW):
     """every row of fwd_map (N, HW) must be a permutation of 0..HW-1: the temporal kernel writes
     out[f][fwd_map[f][p]], so anything else leaves rows of the result unwritten (the reference's
-    get_mapping_ind always produces permutations, src/flow_utils.py:99-101, 134-135)"""
+    get_mapping_ind always produces permutations, src/flow_utils.py:99-101, 134-135).  `owner` is the tensor
+    object the caller holds (the verdict is cached with IT: views made here are new objects every call)."""
     def run():
         srt = torch.sort(fwd_map, dim=1).values
         ok = bool((srt == torch.arange(HW, device=fwd_map.device, dtype=fwd_map.dtype)).all())
         if not ok:
             raise ValueError("fresco_amd.temporal_attention: fwd_mapping rows must be permutations of 0..%d" % (HW - 1))
-    _check_once(("perm", fwd_map.data_ptr(), tuple(fwd_map.shape), fwd_map._version), fwd_map, run)
+    _check_once(("perm", owner.data_ptr(), tuple(owner.shape), owner._version), owner, run)
 
 
 def _prep_maps(fwd_map, mask, N, HW):
-    fwd_map = fwd_map.reshape(N, HW)
-    if fwd_map.dtype != torch.int64:
-        fwd_map = fwd_map.to(torch.int64)
-    fwd_map = fwd_map.contiguous()
+    if fwd_map is not None:
+        fwd_map = fwd_map.reshape(N, HW)
+        if fwd_map.dtype != torch.int64:
+            fwd_map = fwd_map.to(torch.int64)
+        fwd_map = fwd_map.contiguous()
     mask = mask.reshape(-1, N, N)
     if mask.dtype == torch.bool:
         mask = mask.contiguous().view(torch.uint8)
@@ -276,8 +278,9 @@ def temporal_attention(q, k, v, fwd_map, mask, heads, scale, chunk):
     q, q_ld, _ = _rows(q)
     k, k_ld, _ = _rows(k)
     v, v_ld, _ = _rows(v)
+    owner = fwd_map
     fwd_map, mask = _prep_maps(fwd_map, mask, N, HW)
-    _check_permutations(fwd_map, HW)
+    _check_permutations(owner, fwd_map, HW)
     out = torch.empty((Bt, HW, C), dtype=q.dtype, device=q.device)
     rc = _lib.load().fresco_temporal_attn_ld(q.data_ptr(), k.data_ptr(), v.data_ptr(), fwd_map.data_ptr(),
                                              mask.data_ptr(), out.data_ptr(), chunk, N, HW, heads, D,
@@ -310,7 +313,7 @@ def temporal_attention_packed(qkv, mask, heads, scale, chunk):
     D = C // heads
     if ch != chunk or qkv.dtype != torch.float16 or not qkv.is_contiguous():
         raise ValueError("temporal_attention_packed: contiguous fp16 (N, chunk, P, 3C) expected")
-    _, mask = _prep_maps(torch.zeros(N, 1, dtype=torch.int64), mask, N, 1)
+    _, mask = _prep_maps(None, mask, N, 1)
     if mask.shape[0] != P:
         raise ValueError("temporal_attention_packed: mask must cover the %d trajectories of the range" % P)
     out = torch.empty((N, chunk, P, C), dtype=torch.float16, device=qkv.device)
