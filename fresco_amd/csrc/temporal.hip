@@ -28,11 +28,230 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 // q, k, v rows of (batch, row) live at  base + (batch*rows_per_batch + row) * ld ; batch of (half c, frame g):
 //   gather form : c * N + g                 rows_per_batch = HW, row = fwd_map[g][p]
 //   packed form : g * chunk + c             rows_per_batch = P,  row = p        (q | k | v fused per row)
-template <int D, bool PACKED>
+
+// ---------------------------------------------------------------------------------------------------------------
+// N <= 32 frames: the per-pixel N x N attention on the matrix pipe.
+//
+// A block owns PB consecutive trajectories of one CFG half: R = PB*N rows each of Q, K and V.  The rows arrive by
+// LDS-DMA (global_load_lds_dwordx4: one instruction per gathered row and 64 chunks, every load of the block in
+// flight at once, no staging registers) into LDS rows of RS = 16 * (C/8 | 1) bytes: an odd number of 16-byte
+// chunks, so that the 16 rows of an MFMA operand tile start in 16 different bank quads (ds_read_b128 of one
+// chunk per row: conflict-free) and rows 4 apart sit 16 banks apart (the 2-byte reads of the V operand).
+//
+// One wave owns a unit = (16-row query tile, head).  For N <= 16 a tile holds 16/N whole trajectories
+// (block-diagonal: scores between different trajectories are masked off), for N <= 32 a trajectory is KT = 2
+// key tiles.  Per unit:
+//   S^T = K Q^T      v_mfma_f32_16x16x32_f16, A = K rows, B = Q rows (16 B per lane straight from LDS);
+//                    lane (i = l%16, j = l/16) gets S^T[key 4j..4j+3][query i]
+//   P^T              masked softmax down the key axis: 4 values per lane x KT tiles, two cross-lane maxima;
+//                    the fp32 -> fp16 packed P^T registers ARE the B operand of the next product
+//   O^T = V^T P^T    v_mfma_f32_16x16x16_f16, A = V^T (2-byte LDS reads, 4 keys per lane), one extra product
+//                    with A = ones gives the softmax denominator in every lane
+//   O                scaled, fp16, written over the unit's own Q segment (nobody else reads it); the block
+//                    then stores whole rows.
+template <int D, int KT>
+__global__ __launch_bounds__(512) void temporal_mfma_kernel(
+    const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v,
+    const int64_t* __restrict__ fwd_map, const uint8_t* __restrict__ mask, half_t* __restrict__ out,
+    int N, int HW, int H, int PB, int chunk, float scale_log2, int64_t q_ld, int64_t k_ld, int64_t v_ld, int packed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK32 = (D + 31) / 32;  // k-steps of the score product
+    constexpr int NDT = (D + 15) / 16;   // 16-wide output tiles
+    const int C = H * D;
+    const int CC = C / 8;  // 16-byte chunks per row
+    const int RS = 16 * (CC | 1);
+    const int c = blockIdx.y;
+    const int p0 = blockIdx.x * PB;
+    const int tid = threadIdx.x;
+    const int NT = blockDim.x;
+    const int R = PB * N;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = NT >> 6;
+
+    char* qs = smem;
+    const char* ks = qs + (size_t)R * RS;
+    const char* vs = ks + (size_t)R * RS;
+    int* rows = reinterpret_cast<int*>(smem + (size_t)3 * R * RS);  // [PB][N] global row index of frame g (-1: none)
+    uint8_t* msk = reinterpret_cast<uint8_t*>(rows + R);            // [PB][N][N] the trajectories' mask rows
+
+    for (int i = tid; i < R; i += NT) {
+        const int pl = i / N, g = i % N;
+        const int p = p0 + pl;
+        int r = -1;
+        if (p < HW) {
+            const int row = packed ? p : (int)fwd_map[(int64_t)g * HW + p];
+            // (a row table that is not a permutation is the caller's bug; never read out of bounds)
+            if (row >= 0 && row < HW) r = (packed ? g * chunk + c : c * N + g) * HW + row;
+        }
+        rows[i] = r;
+    }
+    for (int i = tid; i < R * N; i += NT) {
+        const int64_t gi = (int64_t)p0 * N * N + i;
+        msk[i] = gi < (int64_t)HW * N * N ? mask[gi] : 0;
+    }
+    __syncthreads();
+
+    // ---- stage Q, K, V rows by DMA: wave w takes rows w, w + nwaves, ...; lane = 16-byte chunk of the row ------
+    const int ppr = (CC + 63) >> 6;  // DMA instructions per row
+    {
+        const uint32_t lds0 =
+            __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+        for (int r = wave; r < R; r += nwaves) {
+            int ro = __builtin_amdgcn_readfirstlane(rows[r]);
+            if (ro < 0) ro = 0;  // rows without a trajectory: load something valid, never stored
+            const half_t* src[3] = {q + (int64_t)ro * q_ld, k + (int64_t)ro * k_ld, v + (int64_t)ro * v_ld};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                for (int part = 0; part < ppr; ++part) {
+                    const int cc = part * 64 + lane;
+                    const uint32_t m0v = lds0 + (uint32_t)((t * R + r) * RS + part * 1024);
+                    if (cc < CC) {
+                        const uint32_t voff = (uint32_t)cc * 16u;
+                        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src[t]),
+                                     "s"(m0v)
+                                     : "memory");
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    // ---- units (query tile, head): per-lane geometry first (nothing of it depends on the head) ----------------
+    // The block's R rows are one key tile set: KT = 1: R = (16/N)*N rows of 16/N whole trajectories, one
+    // query tile; KT = 2: R = N rows of one trajectory, ceil(N/16) query tiles.
+    const int li = lane & 15, lj = lane >> 4;
+    const int ntiles = KT == 1 ? 1 : (N + 15) / 16;
+    const int qtr = KT == 1 ? li / N : 0;  // trajectory of the query slot inside the tile
+    int koff[KT], voff[KT][4], kg[KT][4];
+    bool kok[KT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        koff[kt] = min(kt * 16 + li, R - 1) * RS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rel = kt * 16 + 4 * lj + r;
+            voff[kt][r] = min(rel, R - 1) * RS;
+            kok[kt][r] = rel < R && (KT == 1 ? rel / N == qtr : true);
+            kg[kt][r] = KT == 1 ? rel % N : min(rel, N - 1);
+        }
+    }
+    const half4_t ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+    const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    {
+        for (int tb = 0; tb < ntiles; ++tb) {
+            const int qr = tb * 16 + li;
+            const bool qok = qr < R;
+            const int qrow = qok ? qr : R - 1;
+            bool ok[KT][4];  // msk is [trajectory][f][g] = [row][g]
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ok[kt][r] = qok && kok[kt][r] && msk[qrow * N + kg[kt][r]] != 0;
+            for (int h = wave; h < H; h += nwaves) {
+                char* qseg = qs + (size_t)qrow * RS + h * D * 2;
+                const char* kh = ks + h * D * 2;
+                const char* vh = vs + h * D * 2;
+                // every LDS read of the unit is issued before the first product
+                half8_t bq[NK32], ak[KT][NK32];
+#pragma unroll
+                for (int s = 0; s < NK32; ++s) {
+                    const int ch = s * 4 + lj;  // chunks past the head's D/8: a zero on the Q side is enough
+                    const half8_t tq = *reinterpret_cast<const half8_t*>(qseg + min(ch, D / 8 - 1) * 16);
+                    bq[s] = ch < D / 8 ? tq : zero8;
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        ak[kt][s] = *reinterpret_cast<const half8_t*>(kh + koff[kt] + min(ch, D / 8 - 1) * 16);
+                }
+                half4_t av[NDT][KT];  // V^T: channel d = dt*16 + i (channels past D: any finite row, never stored)
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const int d = min(dt * 16 + li, D - 1);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            av[dt][kt][r] = *reinterpret_cast<const half_t*>(vh + voff[kt][r] + d * 2);
+                }
+                float sc[KT][4];
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < NK32; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[kt][s], bq[s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {  // acc[r] = S^T[key 4j + r][query i]
+                        sc[kt][r] = ok[kt][r] ? acc[r] * scale_log2 : -INFINITY;
+                        m = fmaxf(m, sc[kt][r]);
+                    }
+                }
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                // (a query whose keys are all masked: exp2(-inf - -inf) = NaN, as the reference's softmax of an
+                // all -inf row)
+                half4_t pb[KT];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pb[kt][r] = (half_t)__builtin_amdgcn_exp2f(sc[kt][r] - m);
+                floatx4 den = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    den = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pb[kt], den, 0, 0, 0);
+                floatx4 o[NDT];
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    o[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(av[dt][kt], pb[kt], o[dt], 0, 0, 0);
+                }
+                const float inv = __builtin_amdgcn_rcpf(den[0]);
+                // O^T[d = dt*16 + 4j + r][query i]: 4 consecutive channels of the query's row
+                if (qok) {
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        const int d0 = dt * 16 + 4 * lj;
+                        if (d0 < D) {
+                            half4_t ov;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dt][r] * inv);
+                            *reinterpret_cast<half4_t*>(qseg + d0 * 2) = ov;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- store whole output rows ---------------------------------------------------------------------
+        for (int r = wave; r < R; r += nwaves) {
+            const int ro = __builtin_amdgcn_readfirstlane(rows[r]);
+            if (ro < 0) continue;
+            half_t* dst = out + (int64_t)ro * C;
+            for (int part = 0; part < ppr; ++part) {
+                const int cc = part * 64 + lane;
+                if (cc < CC)
+                    *reinterpret_cast<uint4*>(dst + cc * 8) =
+                        *reinterpret_cast<const uint4*>(qs + (size_t)r * RS + cc * 16);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Longer clips (N > 32): one work item per (trajectory, query frame, head) on the vector ALUs, running-maximum
+// softmax over the frames; same staging of whole rows through LDS.
+template <int D>
 __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v,
     const int64_t* __restrict__ fwd_map, const uint8_t* __restrict__ mask, half_t* __restrict__ out,
-    int N, int HW, int H, int PB, int chunk, float scale_log2, int64_t q_ld, int64_t k_ld, int64_t v_ld) {
+    int N, int HW, int H, int PB, int chunk, float scale_log2, int64_t q_ld, int64_t k_ld, int64_t v_ld, int packed) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = H * D;
     const int CC = C / 8;  // 16-byte chunks per row
@@ -52,20 +271,18 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(
         const int p = p0 + pl;
         int r = -1;
         if (p < HW) {
-            r = PACKED ? p : (int)fwd_map[(int64_t)g * HW + p];
-            if (r < 0 || r >= HW) r = -1;  // (a row table that is not a permutation is the caller's bug; never read out of bounds)
+            r = packed ? p : (int)fwd_map[(int64_t)g * HW + p];
+            if (r < 0 || r >= HW) r = -1;
         }
         rows[i] = r;
     }
-    // the PB*N*N mask bytes of these trajectories are contiguous in memory: staged once (a per-item read from
-    // global memory inside the frame loop costs a memory round trip per frame)
+    // the PB*N*N mask bytes of these trajectories are contiguous in memory: staged once
     for (int i = tid; i < R * N; i += 256) {
         const int64_t gi = (int64_t)p0 * N * N + i;
         msk[i] = gi < (int64_t)HW * N * N ? mask[gi] : 0;
     }
     __syncthreads();
 
-    // ---- stage Q, K, V rows: 16 bytes per lane, whole rows ------------------------------------------
     const int nchunks = R * CC;
     for (int i = tid; i < nchunks; i += 256) {
         const int r = i / CC, cc = i % CC;
@@ -73,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(
         const int row = rows[r];
         uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv;
         if (row >= 0) {
-            const int64_t b = PACKED ? (int64_t)g * chunk + c : (int64_t)c * N + g;
+            const int64_t b = packed ? (int64_t)g * chunk + c : (int64_t)c * N + g;
             const int64_t ro = b * HW + row;
             qv = *reinterpret_cast<const uint4*>(q + ro * q_ld + cc * 8);
             kv = *reinterpret_cast<const uint4*>(k + ro * k_ld + cc * 8);
@@ -85,7 +302,6 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(
     }
     __syncthreads();
 
-    // ---- work items (trajectory pl, query frame f, head h) ------------------------------------------
     const int nwork = R * H;
     for (int w = tid; w < nwork; w += 256) {
         const int h = w % H;
@@ -144,13 +360,12 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(
     }
     __syncthreads();
 
-    // ---- store whole output rows ---------------------------------------------------------------------
     for (int i = tid; i < nchunks; i += 256) {
         const int r = i / CC, cc = i % CC;
         const int g = r % N;
         const int row = rows[r];
         if (row < 0) continue;
-        const int64_t b = PACKED ? (int64_t)g * chunk + c : (int64_t)c * N + g;
+        const int64_t b = packed ? (int64_t)g * chunk + c : (int64_t)c * N + g;
         *reinterpret_cast<uint4*>(out + (b * HW + row) * C + cc * 8) =
             *reinterpret_cast<const uint4*>(qs + (size_t)r * C + cc * 8);
     }
@@ -188,12 +403,40 @@ __global__ __launch_bounds__(256) void temporal_pack_kernel(const half_t* __rest
     }
 }
 
-template <int D, bool PACKED>
+template <int D, int KT>
+static int launch_temporal_mfma(const half_t* q, const half_t* k, const half_t* v, const int64_t* fwd_map,
+                                const uint8_t* mask, half_t* out, int chunk, int N, int HW, int H, float scale,
+                                int64_t q_ld, int64_t k_ld, int64_t v_ld, bool packed, hipStream_t st) {
+    const int C = H * D;
+    const int RS = 16 * ((C / 8) | 1);
+    // N <= 16: one 16-row tile of 16/N trajectories per block, 4 waves share its H heads (31.5 KB of LDS at C = 320:
+    // five blocks per CU, so that the row-table lookup -> DMA -> products -> stores chains of different blocks
+    // overlap); N <= 32: one trajectory (two key tiles), 8 waves
+    const int PB = KT == 1 ? 16 / N : 1;
+    const int NT = KT == 1 ? 256 : 512;
+    if ((int64_t)chunk * N * HW > 0x7fffffff) return FRESCO_EUNSUPPORTED;  // row indices are 32-bit in the kernel
+    const size_t lds = (size_t)PB * N * (3 * RS + 4 + N);
+    if (lds > 160 * 1024) return FRESCO_EUNSUPPORTED;
+    if (lds > 65536)  // (the attribute is per device, and setting it is cheap: no process-global flag)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_mfma_kernel<D, KT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((HW + PB - 1) / PB, chunk);
+    ProfScope ps(FRESCO_PROF_TEMPORAL, chunk * N, HW, H, D, st);
+    hipLaunchKernelGGL((temporal_mfma_kernel<D, KT>), grid, dim3(NT), lds, st, q, k, v, fwd_map, mask, out, N, HW, H,
+                       PB, chunk, scale * 1.4426950408889634f, q_ld, k_ld, v_ld, packed ? 1 : 0);
+    return check_launch();
+}
+
+template <int D>
 static int launch_temporal(const half_t* q, const half_t* k, const half_t* v, const int64_t* fwd_map,
                            const uint8_t* mask, half_t* out, int chunk, int N, int HW, int H, float scale,
-                           int64_t q_ld, int64_t k_ld, int64_t v_ld, hipStream_t st) {
+                           int64_t q_ld, int64_t k_ld, int64_t v_ld, bool packed, hipStream_t st) {
+    if (N <= 16)
+        return launch_temporal_mfma<D, 1>(q, k, v, fwd_map, mask, out, chunk, N, HW, H, scale, q_ld, k_ld, v_ld, packed, st);
+    if (N <= 32)
+        return launch_temporal_mfma<D, 2>(q, k, v, fwd_map, mask, out, chunk, N, HW, H, scale, q_ld, k_ld, v_ld, packed, st);
     const int C = H * D;
-    // LDS: Q, K and V rows of PB trajectories + the row table; two blocks per CU where that is possible
+    // LDS: Q, K and V rows of PB trajectories + the row table + the mask rows; two blocks per CU where that is possible
     const size_t per_traj = (size_t)N * C * 6 + (size_t)N * 4 + (size_t)N * N;
     if (per_traj > 160 * 1024) return FRESCO_EUNSUPPORTED;
     int PB = (int)((76 * 1024) / per_traj);
@@ -201,13 +444,12 @@ static int launch_temporal(const half_t* q, const half_t* k, const half_t* v, co
     const int want = (256 + N * H - 1) / (N * H);  // enough work items for every thread
     if (PB > want) PB = want;
     const size_t lds = (size_t)PB * per_traj;
-    // (the attribute is per device, and setting it is cheap: every launch, no process-global flag)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel<D, PACKED>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel<D>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 65536 ? lds : 65536));
     dim3 grid((HW + PB - 1) / PB, chunk);
     ProfScope ps(FRESCO_PROF_TEMPORAL, chunk * N, HW, H, D, st);
-    hipLaunchKernelGGL((temporal_attn_kernel<D, PACKED>), grid, dim3(256), lds, st, q, k, v, fwd_map, mask, out, N, HW,
-                       H, PB, chunk, scale * 1.4426950408889634f, q_ld, k_ld, v_ld);
+    hipLaunchKernelGGL((temporal_attn_kernel<D>), grid, dim3(256), lds, st, q, k, v, fwd_map, mask, out, N, HW, H, PB,
+                       chunk, scale * 1.4426950408889634f, q_ld, k_ld, v_ld, packed ? 1 : 0);
     return check_launch();
 }
 
@@ -227,12 +469,9 @@ static int temporal_dispatch(const void* q, const void* k, const void* v, const 
     const half_t* kh = static_cast<const half_t*>(k);
     const half_t* vh = static_cast<const half_t*>(v);
     half_t* oh = static_cast<half_t*>(out);
-#define FRESCO_T_CASE(DD)                                                                                          \
-    case DD:                                                                                                       \
-        return packed ? launch_temporal<DD, true>(qh, kh, vh, fwd_map, mask, oh, chunk, N, HW, H, scale, q_ld, k_ld, \
-                                                  v_ld, st)                                                        \
-                      : launch_temporal<DD, false>(qh, kh, vh, fwd_map, mask, oh, chunk, N, HW, H, scale, q_ld,    \
-                                                   k_ld, v_ld, st);
+#define FRESCO_T_CASE(DD) \
+    case DD:              \
+        return launch_temporal<DD>(qh, kh, vh, fwd_map, mask, oh, chunk, N, HW, H, scale, q_ld, k_ld, v_ld, packed, st);
     switch (D) {
         FRESCO_T_CASE(8)
         FRESCO_T_CASE(16)
