@@ -6,26 +6,33 @@
 //                     exact LDS image the MFMA loop consumes (K fragments ‖ V^T fragments, 16-byte chunks
 //                     in ds_read_b128-conflict-free order).  HBM-bound, a few MB.
 //   attn_flash_kernel: flash-style attention on v_mfma_f32_32x32x16_f16.  One wave owns 32*QB query rows, a
-//                     workgroup 4 waves; two workgroups share a CU (two waves per SIMD, 256 registers each).
-//                     S^T = K Q^T is computed "swapped", so every lane holds the scores of ONE query (its
-//                     column of the 32x32 C tile): the softmax needs no cross-lane traffic and the
-//                     exponentiated scores, packed to fp16, already ARE the B operand of O^T = V^T P^T (the
-//                     key order inside each 16-key MFMA step is the C-tile row order; kv_pack writes V^T in it).
+//                     workgroup 8 waves = two per SIMD, 256 registers each.  S^T = K Q^T is computed
+//                     "swapped", so every lane holds the scores of ONE query (its column of the 32x32 C tile):
+//                     the softmax needs no cross-lane traffic and the exponentiated scores, packed to fp16,
+//                     already ARE the B operand of O^T = V^T P^T (the key order inside each 16-key MFMA step is
+//                     the C-tile row order; kv_pack writes V^T in it).
 //
-// What bounds this kernel on gfx950 (tools/ubench_rates.hip, profiles/r02_ubench_rates.txt): not the matrix
+// What bounds this kernel on gfx950 (tools/ubench_rates.hip, profiles/r02_attn_experiments.txt): not the matrix
 // pipe alone but the SIMD's one VALU/issue port, which v_exp_f32 holds for 8.25 cycles, v_cvt_pk_f16_f32 for
 // 4.3 and every MFMA issue for ~7 -- from either of the two waves of the SIMD; MFMA execution (32 cycles per
-// 32x32x16) overlaps with the partner wave's VALU work, but nothing overlaps on the port itself.  Per 64 keys
+// 32x32x16) overlaps with the partner wave's VALU work, but two waves left to themselves run in lockstep
+// (both in their MFMA block, then both in their softmax block: MFMA time + VALU time, no overlap).  Per 64 keys
 // x 64 queries at D = 40: port = 64 exp + 32 cvt + 28 MFMA issues ~ 880 cycles, matrix pipe = 28 x 32 = 896.
 // Hence: as few and as large MFMAs as possible (32x32x16 for both products; a 16x16x32 PV product would save
 // pipe time but costs more issues plus a permlane per P register: measured slower), no per-score VALU besides
 // exp and cvt (the scale is folded into Q, the running max rides in the QK product, the row sum in the PV
-// product, see below), and nothing that stalls BOTH waves of a SIMD at once:
-//   * key tiles arrive by DMA (global_load_lds_dwordx4, a linear 1 KiB copy per wave instruction) into a
-//     3-slot LDS ring, two tiles ahead, behind counted vmcnt waits and ONE workgroup barrier per tile;
-//   * K fragments of tile t+1 are read into registers under the PV MFMAs of tile t, V^T fragments of tile t
-//     under its softmax, so no MFMA waits on an LDS round trip;
-//   * two query blocks per wave at D <= 48: every fragment read feeds two MFMAs.
+// product, see below), and an explicit PING-PONG of the two waves of a SIMD:
+//   * waves 0-3 (group A) and 4-7 (group B) run the same loop body  [ring barrier | V^T reads, softmax(u) |
+//     K reads, PV(u), QK(u+1)], but A passes the workgroup barrier AFTER its softmax and B BEFORE it: the
+//     barrier therefore releases A's matrix block together with B's softmax block and vice versa, and keeps
+//     them half a step apart for the whole key loop (s_setprio raises the matrix block);
+//   * key packs (K of tile u+1 next to V^T of tile u: exactly what one loop body reads) arrive by DMA
+//     (global_load_lds_dwordx4, linear 1 KiB copies) into a 4-slot LDS ring, three steps ahead, behind counted
+//     vmcnt waits and that ONE barrier per step;
+//   * K fragments are read under the PV MFMAs, V^T fragments under the softmax: no MFMA waits on LDS;
+//   * two query blocks per wave at D <= 48: every fragment read feeds two MFMAs;
+//   * the common case (no diagonal bias, scale folded, >= 3 tiles ahead) is an instantiation of its own without
+//     the scalar branches of the rare passes (a taken branch costs an instruction-fetch bubble).
 // The softmax bookkeeping rides in the MFMAs wherever the head dim leaves room: a ones ROW in V^T makes the
 // PV product deliver the row sum, a ones COLUMN in K against -m in Q's spare column makes the QK product
 // subtract the running max.  Per wave, from the key norms kv_pack records (Cauchy-Schwarz bound on the

@@ -122,11 +122,15 @@ def test_attention_logit_ranges(D, qgain):
     _check(out, ref, atol=3e-3, rtol=3e-3, what="qgain %g D=%d" % (qgain, D))
 
 
-@pytest.mark.parametrize("D,H,N", [(8, 8, 4), (40, 8, 8), (80, 8, 5), (40, 8, 16)])
-def test_temporal_attention(D, H, N):
+@pytest.mark.parametrize("D,H,N,HW", [
+    (8, 8, 4, 150), (40, 8, 8, 150), (80, 8, 5, 150), (40, 8, 16, 150),   # one MFMA tile: 4, 2, 3 (15 of 16 slots), 1 trajectories
+    (40, 8, 3, 151), (16, 5, 7, 149), (64, 3, 12, 90), (32, 8, 1, 100),  # ragged last block, odd head counts, N = 1
+    (40, 8, 20, 70), (80, 8, 32, 40), (40, 8, 17, 64),                    # two key tiles (second one partial)
+    (40, 8, 40, 33), (8, 8, 70, 20)])                                     # long clips: vector-ALU path
+def test_temporal_attention(D, H, N, HW):
     import fresco_amd.ops as ops
     g = synth.gen(3 * D + N)
-    chunk, HW = 2, 150
+    chunk = 2
     C, B = H * D, chunk * N
     q = torch.randn(B, HW, C, generator=g).half()
     k = torch.randn(B, HW, C, generator=g).half()
