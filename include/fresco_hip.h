@@ -136,8 +136,11 @@ int fresco_attn_fwd_ld(const void* q, const void* k, const void* v, const int32_
  *                                                 | mask[p,f,g] ) * v[c*N+g,row(g),h,:]
  *   q,k,v,out : (chunk*N, HW, H*D) half;  fwd_map : (N, HW) int64 (a permutation per frame);
  *   mask : (HW, N, N) uint8/bool, non-zero = may attend (diagonal always set, FU:120-131).
- *   Any N with 6*N*H*D + 4*N + N*N bytes <= 160 KiB of LDS per trajectory; D in {8, 16, 32, 40, 64, 80}.  Row-table
- *   entries outside [0, HW) are skipped (nothing is read or written for them).
+ *   D in {8, 16, 32, 40, 64, 80}; chunk*N*HW < 2^31.  N <= 32: MFMA kernel (needs N * (6*(H*D + 8) + 4 + N) bytes
+ *   <= 160 KiB of LDS for 16 < N <= 32: every SD-1.5 shape fits); N > 32: vector-ALU kernel while 6*N*H*D + 4*N + N*N
+ *   bytes <= 160 KiB; otherwise FRESCO_EUNSUPPORTED.  Row-table entries outside [0, HW) are skipped (no row is read or
+ *   written for them; a table that is not a permutation is the caller's bug).  A query whose mask row is all zero
+ *   yields NaN, like the reference's softmax over an all -inf row.
  * ------------------------------------------------------------------------------------------ */
 int fresco_temporal_attn(const void* q, const void* k, const void* v, const int64_t* fwd_map,
                          const uint8_t* mask, void* out,
