@@ -234,7 +234,11 @@ FRESCOAttnProcessor2_0._sharded_self_attention = _sharded_self_attention
 
 def apply_FRESCO_attn(pipe):
     """Install one shared FRESCO processor on the decoder attentions (diffusion_hacked.py:390-403).
-    The other attentions keep diffusers' stock AttnProcessor2_0."""
+    The other attentions keep diffusers' stock AttnProcessor2_0.
+
+    Narrower than the reference on purpose (there is no eager fallback behind the HIP kernels): the processor takes
+    fp16 CUDA hidden states (the dtype run_fresco.py runs the UNet in, :63-80) -- other dtypes raise TypeError -- and
+    no `attention_mask` (the pipeline never passes one to these layers) -- a mask raises NotImplementedError."""
     from diffusers.models.attention_processor import AttnProcessor2_0
 
     frescoProc = FRESCOAttnProcessor2_0(2, AttentionControl())
