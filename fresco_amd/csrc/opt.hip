@@ -13,13 +13,13 @@
 //                  that W^T s is a deterministic gather (rows sorted by source pixel); entry weight
 //                  already carries mask[src]*k.  Built once per optimize_feature call.
 //   temporal_sign  signs of both residuals as int8 (HBM-bound, 4-tap gathers, taps shared by channels)
-//   temporal_grad  assembles dL/dcs of the temporal term from the int8 signs + CSR gathers
+//   (TGradPixel)   dL/dcs of the temporal term from the int8 signs + CSR gathers, evaluated inside adam_update
 //   colnorm        |X[p]| and V^T (C x hw: the NCHW plane layout IS V^T, so both MFMA operands of
 //                  V V^T are read with lanes along consecutive pixels)
 //   gram           128x128 tiles of V V^T on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain);
 //                  epilogue writes sign(G - T) as int8 (or G itself for the Gram target)
 //   sv             dV^T = 2 coef V^T S on the same MFMA (S in {-1,0,1}, exact)
-//   adam_update    norm backward + Adam step, fused, fp32 state
+//   adam_update    temporal gradient + norm backward + Adam step, fused, fp32 state
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -223,44 +223,61 @@ __global__ __launch_bounds__(256) void temporal_sign_kernel(
 // registers (a smooth flow gives ~4 entries per row), longer rows continue from memory.
 constexpr int TG_MAXE = 6;
 
-// grid (ceil(hw/256), ceil(C/OCPT), chunk*n_loc)
-__global__ __launch_bounds__(256) void temporal_grad_kernel(
-    const int8_t* __restrict__ sgn1, const int8_t* __restrict__ sgn2, const float* __restrict__ bwd_occ,
-    const float* __restrict__ fwd_occ, const int* __restrict__ rowptr, const int* __restrict__ src,
-    const float* __restrict__ wgt, float* __restrict__ grad, TLayout L, int C, int hw, float kscale) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= hw) return;
-    const int b = blockIdx.z, ck = b / L.n_loc, fl = b % L.n_loc;
-    const int NP = L.n_pairs;
-    const int jf = L.circular ? fl : fl + 1;
-    const int jp = L.circular ? (fl + L.n_loc - 1) % L.n_loc : fl;
-    const int bf = ck * NP + jf, bp = ck * NP + jp;
-    const int c0 = blockIdx.y * OCPT, cend = min(c0 + OCPT, C);
-    const float a2 = kscale * (1.f - fwd_occ[(int64_t)jf * hw + p]);
-    const float a1 = kscale * (1.f - bwd_occ[(int64_t)jp * hw + p]);
-    const int* rpB = rowptr + (int64_t)(0 * NP + jf) * (hw + 1);
-    const int* rpF = rowptr + (int64_t)(1 * NP + jp) * (hw + 1);
-    const int bB = rpB[p], eB = rpB[p + 1];
-    const int bF = rpF[p], eF = rpF[p + 1];
-    const int* sB = src + (int64_t)(0 * NP + jf) * 4 * hw;
-    const float* wB = wgt + (int64_t)(0 * NP + jf) * 4 * hw;
-    const int* sF = src + (int64_t)(1 * NP + jp) * 4 * hw;
-    const float* wF = wgt + (int64_t)(1 * NP + jp) * 4 * hw;
+// Per-thread state of the temporal gradient of pixel p of local frame (ck, fl): everything that is shared by the
+// channels (pair indices, occlusion factors, the register-cached heads of the two CSR rows).
+struct TGradArgs {
+    const int8_t* sgn1;
+    const int8_t* sgn2;
+    const float* bwd_occ;
+    const float* fwd_occ;
+    const int* rowptr;
+    const int* src;
+    const float* wgt;
+    TLayout L;
+    float kscale;
+};
+
+struct TGradPixel {
+    int bf, bp, bB, eB, bF, eF;
+    float a1, a2;
+    const int *sB, *sF;
+    const float *wB, *wF;
     int iB[TG_MAXE], iF[TG_MAXE];
     float vB[TG_MAXE], vF[TG_MAXE];
+
+    __device__ __forceinline__ void init(const TGradArgs& t, int b, int p, int hw) {
+        const TLayout& L = t.L;
+        const int ck = b / L.n_loc, fl = b % L.n_loc;
+        const int NP = L.n_pairs;
+        const int jf = L.circular ? fl : fl + 1;
+        const int jp = L.circular ? (fl + L.n_loc - 1) % L.n_loc : fl;
+        bf = ck * NP + jf;
+        bp = ck * NP + jp;
+        a2 = t.kscale * (1.f - t.fwd_occ[(int64_t)jf * hw + p]);
+        a1 = t.kscale * (1.f - t.bwd_occ[(int64_t)jp * hw + p]);
+        const int* rpB = t.rowptr + (int64_t)(0 * NP + jf) * (hw + 1);
+        const int* rpF = t.rowptr + (int64_t)(1 * NP + jp) * (hw + 1);
+        bB = rpB[p], eB = rpB[p + 1];
+        bF = rpF[p], eF = rpF[p + 1];
+        sB = t.src + (int64_t)(0 * NP + jf) * 4 * hw;
+        wB = t.wgt + (int64_t)(0 * NP + jf) * 4 * hw;
+        sF = t.src + (int64_t)(1 * NP + jp) * 4 * hw;
+        wF = t.wgt + (int64_t)(1 * NP + jp) * 4 * hw;
 #pragma unroll
-    for (int e = 0; e < TG_MAXE; ++e) {
-        const bool okB = bB + e < eB, okF = bF + e < eF;
-        iB[e] = okB ? sB[bB + e] : 0;  // weight 0 -> the (valid) index 0 contributes nothing
-        vB[e] = okB ? wB[bB + e] : 0.f;
-        iF[e] = okF ? sF[bF + e] : 0;
-        vF[e] = okF ? wF[bF + e] : 0.f;
+        for (int e = 0; e < TG_MAXE; ++e) {
+            const bool okB = bB + e < eB, okF = bF + e < eF;
+            iB[e] = okB ? sB[bB + e] : 0;  // weight 0 -> the (valid) index 0 contributes nothing
+            vB[e] = okB ? wB[bB + e] : 0.f;
+            iF[e] = okF ? sF[bF + e] : 0;
+            vF[e] = okF ? wF[bF + e] : 0.f;
+        }
     }
-    for (int c = c0; c < cend; ++c) {
-        const int8_t* s1f = sgn1 + ((int64_t)bf * C + c) * hw;
-        const int8_t* s2f = sgn2 + ((int64_t)bf * C + c) * hw;
-        const int8_t* s1p = sgn1 + ((int64_t)bp * C + c) * hw;
-        const int8_t* s2p = sgn2 + ((int64_t)bp * C + c) * hw;
+    // gradient of channel c at the pixel
+    __device__ __forceinline__ float value(const TGradArgs& t, int c, int p, int C, int hw) const {
+        const int8_t* s1f = t.sgn1 + ((int64_t)bf * C + c) * hw;
+        const int8_t* s2f = t.sgn2 + ((int64_t)bf * C + c) * hw;
+        const int8_t* s1p = t.sgn1 + ((int64_t)bp * C + c) * hw;
+        const int8_t* s2p = t.sgn2 + ((int64_t)bp * C + c) * hw;
         const float g = a2 * (float)s2f[p] + a1 * (float)s1p[p];
         float adj = 0.f, adj2 = 0.f;
 #pragma unroll
@@ -270,9 +287,9 @@ __global__ __launch_bounds__(256) void temporal_grad_kernel(
         }
         for (int e = bB + TG_MAXE; e < eB; ++e) adj = fmaf(wB[e], (float)s1f[sB[e]], adj);
         for (int e = bF + TG_MAXE; e < eF; ++e) adj2 = fmaf(wF[e], (float)s2p[sF[e]], adj2);
-        grad[((int64_t)b * C + c) * hw + p] = g - adj - adj2;
+        return g - adj - adj2;
     }
-}
+};
 
 // ------------------------------------------------------------------------------------------------
 // Per-pixel reductions over channels, in two deterministic steps so that small planes (8x8 .. 32x32)
@@ -963,8 +980,7 @@ struct AdamArgs {
 };
 
 __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs, float* __restrict__ m,
-                                                           float* __restrict__ v2,
-                                                           const float* __restrict__ grad_t,
+                                                           float* __restrict__ v2, TGradArgs tg,
                                                            const float* __restrict__ vt,
                                                            const float* __restrict__ dvt,
                                                            const float* __restrict__ nrm,
@@ -980,9 +996,12 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
         n = nrm[(int64_t)b * hw + p];
         inv_n = 1.f / n;
     }
+    // the temporal gradient is formed here from the residual signs (no gradient tensor is written and re-read)
+    TGradPixel tp;
+    if (has_t) tp.init(tg, b, p, hw);
     for (int c = c0; c < cend; ++c) {
         const int64_t o = ((int64_t)b * C + c) * hw + p;
-        float g = has_t ? grad_t[o] : 0.f;
+        float g = has_t ? tp.value(tg, c, p, C, hw) : 0.f;
         const float x = cs[o];
         if (has_s) g += (dvt[o] - (vt ? vt[o] : x / n) * dot) * inv_n;  // vt == nullptr: V = X/|X| rebuilt (same quotient)
         if (mode == 1) {
@@ -1019,7 +1038,7 @@ static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int 
     OptWs tmp;
     tmp.m = carve<float>(p, E);
     tmp.v = carve<float>(p, E);
-    tmp.grad = has_t ? carve<float>(p, E) : nullptr;
+    tmp.grad = nullptr;  // (the temporal gradient is formed inside the Adam kernel: no gradient tensor)
     tmp.sgn1 = has_t ? carve<int8_t>(p, EP) : nullptr;
     tmp.sgn2 = has_t ? carve<int8_t>(p, EP) : nullptr;
     tmp.rowptr = has_t ? carve<int>(p, (size_t)2 * NP * (hw + 1)) : nullptr;
@@ -1064,16 +1083,10 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
     }();
     const bool f16_sv = (hw % 16 == 0) && sv_mode == 0;
     if (has_t) {
-        dim3 grid((hw + 255) / 256, (C + OCPT - 1) / OCPT, B);
-        dim3 sgrid(grid.x, grid.y, chunk * L.n_pairs);
-        {
-            ProfScope ps(FRESCO_PROF_OPT_TSIGN, B, C, hw, 0, st);
-            hipLaunchKernelGGL(temporal_sign_kernel, sgrid, dim3(256), 0, st, cs, bwd_flow, fwd_flow, bwd_occ,
-                               fwd_occ, w.sgn1, w.sgn2, loss, L, C, h, wd);
-        }
-        ProfScope ps(FRESCO_PROF_OPT_TGRAD, B, C, hw, 0, st);
-        hipLaunchKernelGGL(temporal_grad_kernel, grid, dim3(256), 0, st, w.sgn1, w.sgn2, bwd_occ, fwd_occ,
-                           w.rowptr, w.src, w.wgt, w.grad, L, C, hw, kscale);
+        dim3 sgrid((hw + 255) / 256, (C + OCPT - 1) / OCPT, chunk * L.n_pairs);
+        ProfScope ps(FRESCO_PROF_OPT_TSIGN, B, C, hw, 0, st);
+        hipLaunchKernelGGL(temporal_sign_kernel, sgrid, dim3(256), 0, st, cs, bwd_flow, fwd_flow, bwd_occ, fwd_occ,
+                           w.sgn1, w.sgn2, loss, L, C, h, wd);
     }
     if (has_s) {
         {
@@ -1118,7 +1131,9 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
             hipLaunchKernelGGL((chan_partial_kernel<2>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, cs, w.dvt,
                                w.part, C, hw, S, w.nrm);
     }
-    hipLaunchKernelGGL(adam_update_kernel, egrid, dim3(256), 0, st, cs, w.m, w.v, w.grad,
+    static_assert(OCPT == ECPT, "the temporal gradient is evaluated on the elementwise grid");
+    const TGradArgs tg = {w.sgn1, w.sgn2, bwd_occ, fwd_occ, w.rowptr, w.src, w.wgt, L, kscale};
+    hipLaunchKernelGGL(adam_update_kernel, egrid, dim3(256), 0, st, cs, w.m, w.v, tg,
                        v_stored ? w.vt : (const float*)nullptr, w.dvt, w.nrm, w.part, gout, C, hw, S, has_t, has_s, mode,
                        a);
 }

@@ -6,7 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-NAMES = {4: "temporal_sign", 5: "temporal_grad", 6: "colnorm", 7: "gram", 8: "sv", 9: "adam_update"}
+NAMES = {4: "temporal_sign", 6: "colnorm", 7: "gram", 8: "sv", 9: "adam_update"}  # (5, the temporal gradient, lives in adam_update)
 LAYERS = ((1280, 8), (1280, 16), (1280, 32), (640, 64))
 
 
