@@ -36,6 +36,8 @@ class FRESCOAttnProcessor2_0:
         self._rows_cache = {}
         self.shard = None  # fresco_amd.dist.FrameShard for frame-parallel multi-GPU runs
         self.fuse_projections = True  # q/k/v (and to_out at C = 320) through fresco_linear when they are plain Linears
+        # cross-frame-only calls (no temporal pass) read K and V of the selected tokens only: project just those
+        self.sparse_kv_projection = True
 
     # ---- fused projections ---------------------------------------------------------------------------
     def _project(self, attn, x, names, outs=None):
@@ -65,16 +67,25 @@ class FRESCOAttnProcessor2_0:
         return lin(hs)
 
     # flat int32 indices of the True entries of a (N, HW) mask, cached per mask tensor
-    def _kv_rows(self, mask):
+    def _kv_rows(self, mask, as_long=False):
         key = (mask.data_ptr(), tuple(mask.shape), mask._version)
         hit = self._rows_cache.get(key)
         if hit is None or hit[0]() is not mask:  # the weakref guards against a recycled address
             if len(self._rows_cache) > 16:
                 self._rows_cache.clear()
-            rows = torch.nonzero(mask.reshape(-1), as_tuple=False).squeeze(1).to(torch.int32).contiguous()
-            hit = (weakref.ref(mask), rows)
+            rows64 = torch.nonzero(mask.reshape(-1), as_tuple=False).squeeze(1).contiguous()
+            hit = (weakref.ref(mask), rows64.to(torch.int32), rows64)
             self._rows_cache[key] = hit
-        return hit[1]
+        return hit[2] if as_long else hit[1]
+
+    def _cf_mask(self, ctrl, hw):
+        """the cross-frame key mask of this feature scale (None: every frame attends to frame 0 only)"""
+        mask = None
+        if ctrl.attn_mask is not None:
+            for m in ctrl.attn_mask:
+                if m.shape[1] == hw:
+                    mask = m
+        return mask
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
         residual = hidden_states
@@ -99,13 +110,32 @@ class FRESCOAttnProcessor2_0:
                 ctrl(hidden_states.detach().clone())
             if self.shard is not None and ctrl and (ctrl.use_cfattn or ctrl.use_interattn):
                 return self._sharded_self_attention(attn, hidden_states, residual, input_ndim)
-            query, key, value = self._project(attn, hidden_states, ("to_q", "to_k", "to_v"))
+            sparse_kv = (self.sparse_kv_projection and bool(ctrl) and ctrl.use_cfattn and not ctrl.use_interattn
+                         and hidden_states.shape[0] % self.unet_chunk_size == 0)
+            if sparse_kv:
+                # the only reader of K and V is the cross-frame pass, which gathers frame 0 and the selected tokens of
+                # the other frames (225-247): project exactly those rows, in the order the pass enumerates them
+                (query,) = self._project(attn, hidden_states, ("to_q",))
+                chunk_, hw_ = self.unet_chunk_size, hidden_states.shape[1]
+                mask = self._cf_mask(ctrl, hw_)
+                xg = hidden_states.reshape(chunk_, -1, hidden_states.shape[-1])
+                x_sel = xg[:, :hw_] if mask is None else xg.index_select(1, self._kv_rows(mask, as_long=True))
+                key, value = self._project(attn, x_sel.contiguous(), ("to_k", "to_v"))
+            else:
+                query, key, value = self._project(attn, hidden_states, ("to_q", "to_k", "to_v"))
         else:
+            sparse_kv = False
             query = attn.to_q(hidden_states)
             if attn.norm_cross:
                 encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
             key = attn.to_k(encoder_hidden_states)
             value = attn.to_v(encoder_hidden_states)
+
+        # the kernels compute in fp16 (the dtype the pipeline runs its UNet in); fp32 / bf16 activations are rounded
+        # to fp16 after the projections and the result is cast back: same HIP path, no eager branch
+        out_dtype = query.dtype
+        if out_dtype != torch.float16:
+            query, key, value = query.half(), key.half(), value.half()
 
         heads = attn.heads
         head_dim = key.shape[-1] // heads
@@ -120,18 +150,19 @@ class FRESCOAttnProcessor2_0:
             ref = ctrl(None)
             assert ref.shape == encoder_hidden_states.shape
             q_ref, k_ref = self._project(attn, ref, ("to_q", "to_k"))
+            if q_ref.dtype != torch.float16:
+                q_ref, k_ref = q_ref.half(), k_ref.half()
             q_att = ops.attention(q_ref, k_ref, query, heads, ctrl.intraattn_scale_factor * sm_scale,
                                   diag_bias=float(ctrl.intraattn_bias), workspace=self._ws)
 
         # main pass: efficient cross-frame attention (225-247, 303-305) or plain attention
-        if fresco and ctrl.use_cfattn:
+        if fresco and ctrl.use_cfattn and sparse_kv:
+            hs = ops.attention(q_att, key, value, heads, sm_scale, n_groups=chunk, M=key.shape[1],
+                               group_rows=key.shape[1], workspace=self._ws)
+        elif fresco and ctrl.use_cfattn:
             video_length = key.shape[0] // chunk
             hw = key.shape[1]
-            mask = None
-            if ctrl.attn_mask is not None:
-                for m in ctrl.attn_mask:
-                    if m.shape[1] == hw:
-                        mask = m
+            mask = self._cf_mask(ctrl, hw)
             rows = self._kv_rows(mask) if mask is not None else None
             hs = ops.attention(q_att, key, value, heads, sm_scale, kv_rows=rows, n_groups=chunk,
                                M=hw if rows is None else rows.numel(), group_rows=video_length * hw,
@@ -152,7 +183,7 @@ class FRESCOAttnProcessor2_0:
             hs = ops.temporal_attention(query, key, hs, fwd_mapping, interattn_mask, heads,
                                         ctrl.interattn_scale_factor * sm_scale, chunk)
 
-        hs = hs.to(query.dtype)
+        hs = hs.to(out_dtype)
         hs = self._project_out(attn, hs)
         hs = attn.to_out[1](hs)
         if input_ndim == 4:
@@ -170,6 +201,8 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
     other frames' selected rows; temporal pass: all-to-all to trajectory shards and back; the rest is local."""
     if input_ndim != 3:
         raise NotImplementedError("fresco_amd: frame-sharded attention expects (B, HW, C) hidden states")
+    if hidden_states.dtype != torch.float16:
+        raise TypeError("fresco_amd: frame-sharded attention expects fp16 hidden states (got %s)" % hidden_states.dtype)
     ctrl, sh = self.controller, self.shard
     chunk = self.unet_chunk_size
     heads = attn.heads
@@ -237,8 +270,9 @@ def apply_FRESCO_attn(pipe):
     The other attentions keep diffusers' stock AttnProcessor2_0.
 
     Narrower than the reference on purpose (there is no eager fallback behind the HIP kernels): the processor takes
-    fp16 CUDA hidden states (the dtype run_fresco.py runs the UNet in, :63-80) -- other dtypes raise TypeError -- and
-    no `attention_mask` (the pipeline never passes one to these layers) -- a mask raises NotImplementedError."""
+    CUDA hidden states and computes the attention in fp16 (the dtype run_fresco.py runs the UNet in, :63-80): fp32 /
+    bf16 activations are rounded to fp16 after the projections and the result is cast back (frame-sharded runs: fp16
+    only); and no `attention_mask` (the pipeline never passes one to these layers) -- a mask raises NotImplementedError."""
     from diffusers.models.attention_processor import AttnProcessor2_0
 
     frescoProc = FRESCOAttnProcessor2_0(2, AttentionControl())

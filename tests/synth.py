@@ -105,13 +105,13 @@ def oracle_attention(case, mode, round_dtype=torch.float16):
                               round_dtype=round_dtype, **kw)
 
 
-def controller_for(case, mode, device):
+def controller_for(case, mode, device, dtype=None):
     """A fresco_amd AttentionControl configured like the pipeline would for `mode`."""
     import fresco_amd
 
     c = fresco_amd.AttentionControl()
     if mode == "full":
-        c.stored_attn["decoder_attn"] = [case["ref"].to(device).to(case.get("dtype", torch.float16))]
+        c.stored_attn["decoder_attn"] = [case["ref"].to(device).to(dtype or case.get("dtype", torch.float16))]
         c.enable_intraattn()
     if mode in ("full", "cf_temporal", "temporal"):
         c.enable_interattn(dict(fwd_mappings=[case["fwd_map"].to(device)],

@@ -187,6 +187,29 @@ def test_processor_vs_oracle_cfg1(layer, mode):
     _check(out, ref32, atol=1e-3, rtol=1e-3, what="%s %s fp32" % (layer, mode))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["full", "cf"])
+def test_processor_other_activation_dtypes(mode, dtype):
+    """fp32 / bf16 pipelines: the module's own projections run in that dtype, q, k, v are rounded to fp16 for the
+    kernels and the result is cast back -- the same HIP path, within the fp16 contract of the fp32 oracle (bf16: the
+    oracle sees the bf16-rounded weights and inputs; the tolerance covers bf16 projections, 3 significant digits)."""
+    import fresco_amd
+    case = synth.make_attention_case(4, 256, "L3", seed=3)
+    proc = fresco_amd.FRESCOAttnProcessor2_0(2, synth.controller_for(case, mode, DEV, dtype=dtype))
+    attn = copy.deepcopy(case["attn"]).to(DEV).to(dtype)
+    with torch.no_grad():
+        out = proc(attn, case["hidden"].to(DEV).to(dtype))
+    assert out.dtype == dtype
+    if dtype == torch.bfloat16:
+        case = dict(case)
+        case["attn"] = copy.deepcopy(case["attn"]).to(dtype).float()
+        case["hidden"] = case["hidden"].to(dtype).float()
+        case["ref"] = case["ref"].to(dtype).float()
+    ref32 = synth.oracle_attention(case, mode, round_dtype=None)
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    _check(out, ref32, atol=tol, rtol=tol, what="%s %s" % (mode, dtype))
+
+
 def test_processor_large_mask_blocks():
     """Block occlusions: M ~ (1 + 0.5 (N-1)) HW keys, many broken trajectories."""
     case = synth.make_attention_case(4, 256, "L3", seed=2, occ_mode="blocks")
@@ -282,8 +305,10 @@ def test_processor_rejects_unsupported_inputs():
     import fresco_amd
     attn = synth.FakeAttn(64, 8).to(DEV)
     proc = fresco_amd.FRESCOAttnProcessor2_0(2, fresco_amd.AttentionControl())
+    import fresco_amd.ops as ops
     x32 = torch.zeros(2, 16, 64, device=DEV)
-    with pytest.raises(TypeError):          # fp32 hidden states: the kernels are fp16 (no silent down-cast)
-        proc(attn, x32)
+    assert proc(attn, x32).dtype == torch.float32   # fp32 activations: computed in fp16, cast back (documented)
+    with pytest.raises(TypeError):                  # the operator itself takes fp16 only
+        ops.attention(x32, x32, x32, 8, 1.0)
     with pytest.raises(NotImplementedError):
         proc(attn.half(), x32.half(), attention_mask=torch.zeros(2, 1, 16, device=DEV))
