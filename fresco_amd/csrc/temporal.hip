@@ -57,8 +57,11 @@ __global__ __launch_bounds__(512) void temporal_mfma_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NK32 = (D + 31) / 32;  // k-steps of the score product
     constexpr int NDT = (D + 15) / 16;   // 16-wide output tiles
+    // gridDim.z blocks share a tile's heads: a block stages (and writes) only the columns of its Hs heads
     const int C = H * D;
-    const int CC = C / 8;  // 16-byte chunks per row
+    const int Hs = H / (int)gridDim.z;
+    const int col0 = blockIdx.z * Hs * D;  // first channel of this block's heads
+    const int CC = Hs * D / 8;             // 16-byte chunks per staged row
     const int RS = 16 * (CC | 1);
     const int c = blockIdx.y;
     const int p0 = blockIdx.x * PB;
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(512) void temporal_mfma_kernel(
         for (int r = wave; r < R; r += nwaves) {
             int ro = __builtin_amdgcn_readfirstlane(rows[r]);
             if (ro < 0) ro = 0;  // rows without a trajectory: load something valid, never stored
-            const half_t* src[3] = {q + (int64_t)ro * q_ld, k + (int64_t)ro * k_ld, v + (int64_t)ro * v_ld};
+            const half_t* src[3] = {q + (int64_t)ro * q_ld + col0, k + (int64_t)ro * k_ld + col0,
+                                    v + (int64_t)ro * v_ld + col0};
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 for (int part = 0; part < ppr; ++part) {
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(512) void temporal_mfma_kernel(
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ok[kt][r] = qok && kok[kt][r] && msk[qrow * N + kg[kt][r]] != 0;
-            for (int h = wave; h < H; h += nwaves) {
+            for (int h = wave; h < Hs; h += nwaves) {
                 char* qseg = qs + (size_t)qrow * RS + h * D * 2;
                 const char* kh = ks + h * D * 2;
                 const char* vh = vs + h * D * 2;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(512) void temporal_mfma_kernel(
         for (int r = wave; r < R; r += nwaves) {
             const int ro = __builtin_amdgcn_readfirstlane(rows[r]);
             if (ro < 0) continue;
-            half_t* dst = out + (int64_t)ro * C;
+            half_t* dst = out + (int64_t)ro * C + col0;
             for (int part = 0; part < ppr; ++part) {
                 const int cc = part * 64 + lane;
                 if (cc < CC)
@@ -408,19 +412,26 @@ static int launch_temporal_mfma(const half_t* q, const half_t* k, const half_t* 
                                 const uint8_t* mask, half_t* out, int chunk, int N, int HW, int H, float scale,
                                 int64_t q_ld, int64_t k_ld, int64_t v_ld, bool packed, hipStream_t st) {
     const int C = H * D;
-    const int RS = 16 * ((C / 8) | 1);
     // N <= 16: one 16-row tile of 16/N trajectories per block, 4 waves share its H heads (31.5 KB of LDS at C = 320:
     // five blocks per CU, so that the row-table lookup -> DMA -> products -> stores chains of different blocks
     // overlap); N <= 32: one trajectory (two key tiles), 8 waves
     const int PB = KT == 1 ? 16 / N : 1;
     const int NT = KT == 1 ? 256 : 512;
     if ((int64_t)chunk * N * HW > 0x7fffffff) return FRESCO_EUNSUPPORTED;  // row indices are 32-bit in the kernel
+    // wide rows (N <= 16): split a tile's heads over 2 or 4 blocks (each stages only its heads' columns) so that a
+    // block's LDS stays near 32 KB and five of them share a CU (C = 640, N = 8: 23 -> 21 us; N = 16: 40 -> 34 us).  Not
+    // for the two-key-tile form: 320-byte row pieces and one unit per wave measured 1.4x slower there.
+    int hsplit = 1;
+    while (KT == 1 && hsplit < 4 && H % (hsplit * 2) == 0 &&
+           (size_t)PB * N * 3 * (16 * ((C / hsplit / 8) | 1)) > 40 * 1024)
+        hsplit *= 2;
+    const int RS = 16 * ((C / hsplit / 8) | 1);
     const size_t lds = (size_t)PB * N * (3 * RS + 4 + N);
     if (lds > 160 * 1024) return FRESCO_EUNSUPPORTED;
     if (lds > 65536)  // (the attribute is per device, and setting it is cheap: no process-global flag)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_mfma_kernel<D, KT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((HW + PB - 1) / PB, chunk);
+    dim3 grid((HW + PB - 1) / PB, chunk, hsplit);
     ProfScope ps(FRESCO_PROF_TEMPORAL, chunk * N, HW, H, D, st);
     hipLaunchKernelGGL((temporal_mfma_kernel<D, KT>), grid, dim3(NT), lds, st, q, k, v, fwd_map, mask, out, N, HW, H,
                        PB, chunk, scale * 1.4426950408889634f, q_ld, k_ld, v_ld, packed ? 1 : 0);
