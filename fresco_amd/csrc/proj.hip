@@ -6,8 +6,7 @@
 // 2.3 TB/s, 360 TFLOP/s).  Here x is read ONCE: a wave keeps its 32 rows of x resident in registers as
 // MFMA B fragments (K/16 fragments of 8 halfs) and streams slabs of 64 weight rows x 160 k through LDS -- the
 // same swapped orientation as the flash kernel (out^T = W_tile x^T: one lane owns one row of x and ends up
-// with 4 x 8 consecutive output features of a 64-feature tile; the two lanes of a row together write one whole
-// 128-byte line).  Weight slabs are DMA'd global -> LDS (global_load_lds_dwordx4, issued as inline asm so that
+// with 4 x 8 consecutive output features of a 64-feature tile).  Weight slabs are DMA'd global -> LDS (global_load_lds_dwordx4, issued as inline asm so that
 // the compiler does not drain vmcnt in front of the fragment reads) into a 3-slot ring, TWO steps ahead, behind
 // a counted s_waitcnt and one barrier per step; rows padded to an odd multiple of 16 B (conflict-free
 // ds_read_b128); the weights (<= 2.4 MB) stay L2-resident.
@@ -16,10 +15,11 @@
 // (splits > 1 only when M/256 alone cannot fill the chip).  What bounds the kernel is the rate at which a CU
 // can stream the weight slabs into LDS (~25 GB/s per CU for LDS-DMA): every workgroup reads all of W, so rows per
 // workgroup, not MFMA or HBM time, set the floor -- 256 rows (one workgroup per CU) halve that traffic vs 128.
-// Measured (MI355X, M = 65536, K = 320, q,k,v in one launch): 58.9 us (round 1: 63.6); tools/proj_abl.hip: x loads +
-// loop 11 us, + LDS fragment reads 10, + weight DMA 6.5, + MFMA 17, + output stores 16 -- the parts ADD UP: with one
+// Measured (MI355X, M = 65536, K = 320, q,k,v in one launch): 56.6 us (round 1: 63.6); tools/proj_abl.hip: x loads +
+// loop 11 us, + LDS fragment reads 10, + weight DMA 6.5, + MFMA 17, + output stores 12 -- the parts ADD UP: with one
 // barrier-coupled workgroup per CU nothing overlaps.  Splitting the features over more workgroups (staggered
-// lifetimes) re-reads x and is slower (2 / 3 / 5 splits: 68 / 78 / 94 us).
+// lifetimes) re-reads x and is slower (2 / 3 / 5 splits: 68 / 78 / 94 us).  Output tiles are transposed through LDS
+// so that a store instruction writes whole 128-byte lines (16-byte pieces of 32 rows each: +4 us).
 #include "common.h"
 
 // Ablation switch for tools/proj_abl.hip (timing experiments only; the product builds 0):
@@ -44,7 +44,12 @@ struct ProjCfg {
     static constexpr int NPW_LO = NP / NWV, NPW_HI = (NP + NWV - 1) / NWV, NREM = NP % NWV;
     static constexpr int SLOT = NPW_HI * NWV * 1024;  // LDS bytes per ring slot
     static constexpr int NBUF = 3;
-    static constexpr int LDS_BYTES = NBUF * SLOT;
+    static constexpr int RING_BYTES = NBUF * SLOT;
+    // epilogue: a wave's 32 x 64 output tile is transposed through LDS so that every store instruction writes whole
+    // 128-byte lines (8 lanes per row); rows padded to 144 B (conflict-free ds_write_b128 of 16 rows)
+    static constexpr int OROW = TF * 2 + 16;
+    static constexpr int OSCR = 32 * OROW;                // per wave
+    static constexpr int BIAS_OFF = RING_BYTES + NWV * OSCR;  // [nw][N] halfs follow
 };
 
 template <int N_>
@@ -137,6 +142,18 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
 
     stage(0, 0);
     if (nsteps > 1) stage(1, 1);
+    // biases -> LDS once (a global load inside the tile loop would make the compiler drain vmcnt there, DMA included)
+    half_t* bias_s = reinterpret_cast<half_t*>(smem + Cfg::BIAS_OFF);
+    const bool has_bias = b0 || b1 || b2;
+    if (has_bias) {
+        const int nwN = (nF / tiles_per_out) * N;
+        for (int i = tid; i < nwN; i += NWV * 64) {
+            const int jb = i / N;
+            const half_t* bp = jb == 0 ? b0 : (jb == 1 ? b1 : b2);
+            bias_s[i] = bp ? bp[i - jb * N] : (half_t)0.f;
+        }
+    }
+    char* scr = smem + Cfg::RING_BYTES + wave * Cfg::OSCR;
     wait_barrier(nsteps > 1 ? 1 : 0);
     int slot = 0, s = 0;
     for (int ft = ft0; ft < ft1; ++ft) {
@@ -168,29 +185,35 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
             }
             slot = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
         }
-        // epilogue of the feature tile: + bias, fp16; the two lanes of a row write one whole 128-byte line
+        // epilogue of the feature tile: + bias, fp16, transposed through the wave's LDS scratch: lane (row, hi) holds
+        // the 16-byte chunks 2*c4 + hi of its row; store instruction i then writes rows 8i .. 8i+7 as whole lines
         half_t* op = out0;
         int64_t ld = ld0;
-        const half_t* bias = b0;
-        if (j == 1) { op = out1; ld = ld1; bias = b1; }
-        if (j == 2) { op = out2; ld = ld2; bias = b2; }
-        if (row < M && (!(FRESCO_PROJ_ABL & 1) || acc[0][0][0] == 12345.f)) {
-            half_t* o = op + (int64_t)row * ld + col + hi * 8;
+        if (j == 1) { op = out1; ld = ld1; }
+        if (j == 2) { op = out2; ld = ld2; }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    half8_t w;
-                    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    if (bias) {
-                        const half8_t b8 = *reinterpret_cast<const half8_t*>(bias + col + t * 32 + half * 16 + hi * 8);
+            for (int half = 0; half < 2; ++half) {
+                half8_t w;
+                float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (has_bias) {
+                    const half8_t b8 = *reinterpret_cast<const half8_t*>(bias_s + j * N + col + t * 32 + half * 16 + hi * 8);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) bv[e] = (float)b8[e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) w[e] = (half_t)(acc[t][0][half * 8 + e] + acc[t][1][half * 8 + e] + bv[e]);
-                    *reinterpret_cast<half8_t*>(o + t * 32 + half * 16) = w;
+                    for (int e = 0; e < 8; ++e) bv[e] = (float)b8[e];
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (half_t)(acc[t][0][half * 8 + e] + acc[t][1][half * 8 + e] + bv[e]);
+                *reinterpret_cast<half8_t*>(scr + l31 * Cfg::OROW + ((t * 2 + half) * 2 + hi) * 16) = w;
+            }
+        if (!(FRESCO_PROJ_ABL & 1) || acc[0][0][0] == 12345.f) {
+            const int row0 = blockIdx.x * (NWV * 32) + wave * 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 8 + (lane >> 3), ch = lane & 7;
+                const half8_t w = *reinterpret_cast<const half8_t*>(scr + r * Cfg::OROW + ch * 16);
+                if (row0 + r < M) *reinterpret_cast<half8_t*>(op + (int64_t)(row0 + r) * ld + col + ch * 8) = w;
+            }
         }
         col += Cfg::TF;
         if (col == N) {
@@ -206,8 +229,10 @@ static int launch_linear(const half_t* x, int64_t x_ld, const half_t* const* W, 
                          int N, hipStream_t st) {
     using Cfg = ProjCfg<K, NWV>;
     // (per device and cheap: set on every launch rather than cached in a process-global flag)
+    const int lds_bytes = Cfg::BIAS_OFF + nw * N * 2;
+    if (lds_bytes > 160 * 1024) return FRESCO_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<K, NWV>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     const int nF = nw * N / Cfg::TF;
     const int row_blocks = (M + NWV * 32 - 1) / (NWV * 32);
     // enough workgroups for two rounds of the 256 CUs; every extra split re-reads x once
@@ -217,7 +242,7 @@ static int launch_linear(const half_t* x, int64_t x_ld, const half_t* const* W, 
     const int tiles_per_split = (nF + splits - 1) / splits;
     splits = (nF + tiles_per_split - 1) / tiles_per_split;
     ProfScope ps(FRESCO_PROF_LINEAR, M, N, K, nw, st);
-    hipLaunchKernelGGL((linear_kernel<K, NWV>), dim3(row_blocks, splits), dim3(NWV * 64), Cfg::LDS_BYTES, st, x, x_ld, W[0], W[1],
+    hipLaunchKernelGGL((linear_kernel<K, NWV>), dim3(row_blocks, splits), dim3(NWV * 64), lds_bytes, st, x, x_ld, W[0], W[1],
                        W[2], bias[0], bias[1], bias[2], out0, out1, out2, ld0, ld1, ld2, M, N, nF, tiles_per_split);
     return check_launch();
 }
