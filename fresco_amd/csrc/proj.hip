@@ -43,7 +43,10 @@ struct ProjCfg {
     static constexpr int NP = (TF * CPR + 63) / 64;  // 1 KiB DMA pieces per slab (the last one is partly pad)
     static constexpr int NPW_LO = NP / NWV, NPW_HI = (NP + NWV - 1) / NWV, NREM = NP % NWV;
     static constexpr int SLOT = NPW_HI * NWV * 1024;  // LDS bytes per ring slot
-    static constexpr int NBUF = 3;
+#ifndef FRESCO_PROJ_NBUF
+#define FRESCO_PROJ_NBUF 3
+#endif
+    static constexpr int NBUF = FRESCO_PROJ_NBUF;  // ring slots: slabs are staged NBUF - 1 steps ahead
     static constexpr int RING_BYTES = NBUF * SLOT;
     // epilogue: a wave's 32 x 64 output tile is transposed through LDS so that every store instruction writes whole
     // 128-byte lines (8 lanes per row); rows padded to 144 B (conflict-free ds_write_b128 of 16 rows)
@@ -127,14 +130,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
     };
     // the slab of step s+1 has landed for everyone (own pieces: counted vmcnt, at most the newest slab's still in
     // flight -- output stores only make the wait stricter), and every wave is done with the slab of step s-1
-    auto wait_barrier = [&](int keep) __attribute__((always_inline)) {
+    auto wait_barrier = [&](int keep) __attribute__((always_inline)) {  // keep = newer slabs that may stay in flight
         if (keep == 0)
             proj_wait_barrier<0>();
-        else if (many)
+        else if (keep == 1 && many)
             proj_wait_barrier<Cfg::NPW_HI>();
-        else
+        else if (keep == 1)
             proj_wait_barrier<Cfg::NPW_LO>();
+        else if (many)
+            proj_wait_barrier<2 * Cfg::NPW_HI>();
+        else
+            proj_wait_barrier<2 * Cfg::NPW_LO>();
     };
+    constexpr int AHEAD = Cfg::NBUF - 1;
 
     // output cursor of this split: which tensor, which column
     int j = ft0 / tiles_per_out;
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
 
     stage(0, 0);
     if (nsteps > 1) stage(1, 1);
+    if (AHEAD > 2 && nsteps > 2) stage(2, 2);
     // biases -> LDS once (a global load inside the tile loop would make the compiler drain vmcnt there, DMA included)
     half_t* bias_s = reinterpret_cast<half_t*>(smem + Cfg::BIAS_OFF);
     const bool has_bias = b0 || b1 || b2;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
         }
     }
     char* scr = smem + Cfg::RING_BYTES + wave * Cfg::OSCR;
-    wait_barrier(nsteps > 1 ? 1 : 0);
+    wait_barrier(min(nsteps - 1, AHEAD - 1));
     int slot = 0, s = 0;
     for (int ft = ft0; ft < ft1; ++ft) {
         floatx16 acc[2][2];  // [32-row half of the tile][two accumulation chains (even / odd k-steps)]
@@ -164,8 +173,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
             for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
 #pragma unroll
         for (int kc = 0; kc < Cfg::NKC; ++kc, ++s) {
-            const int slot2 = slot >= 1 ? slot - 1 : Cfg::NBUF - 1;  // = (slot + 2) % 3: the slab of step s-1
-            if (!(FRESCO_PROJ_ABL & 2) && s + 2 < nsteps) stage(s + 2, slot2);
+            const int slot2 = slot >= 1 ? slot - 1 : Cfg::NBUF - 1;  // the slot of step s-1 takes the slab of step s+AHEAD
+            if (!(FRESCO_PROJ_ABL & 2) && s + AHEAD < nsteps) stage(s + AHEAD, slot2);
             const char* wr = smem + slot * Cfg::SLOT + frow * Cfg::ROWB + hi * Cfg::KC;  // hi * (KC/2) halfs
 #pragma unroll
             for (int ks = 0; ks < Cfg::KS; ++ks)
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
             if (FRESCO_PROJ_ABL & 2) {
                 asm volatile("s_barrier" ::: "memory");
             } else if (s + 1 < nsteps) {
-                wait_barrier(s + 2 < nsteps ? 1 : 0);
+                wait_barrier(min(nsteps - 2 - s, AHEAD - 1));  // slabs newer than s+1 that exist
             }
             slot = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
         }
