@@ -341,6 +341,9 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true",
+                    help="skip the auxiliary legs (cfg2b, cfg2c): only the timed steps and their instrumented replay "
+                         "run, so that a rocprofv3 --stats average of the flash kernel is over the bench's own launches")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -499,7 +502,7 @@ def main():
                 cnt = [int(m[max(r * n_loc, 1):(r + 1) * n_loc].sum()) for r in range(world)]
                 M_rest[name] = max(cnt)
             res["collective_bytes_received_per_rank"] = collective_bytes_per_step(N, R, world, M_rest)
-        if world == 1:
+        if world == 1 and not args.no_aux:
             res["cfg2b"] = cfg2b_large_mask(layers, N, R, device, lib)
             rows3 = params[8][3].reshape(-1).nonzero().squeeze(1).to(torch.int32).to(device)
             res["cfg2c_large_logits"] = cfg2c_large_logits(layers, N, R, device, lib, rows3)

@@ -10,7 +10,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; t
 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; cat $OUT/bench_$TAG.json; tail -3 $OUT/bench_$TAG.err
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python $REPO/bench.py --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python $REPO/bench.py --no-cpu-baseline --no-aux > $OUT/prof_$TAG.log 2>&1
 cd $REPO
 find $OUT/prof_$TAG -name "*kernel_stats*" | head -3
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)

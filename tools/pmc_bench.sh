@@ -13,7 +13,7 @@ P4="GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python $REPO/bench.py --no-cpu-baseline --steps 15 --warmup 1 > $OUT/pass$i.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python $REPO/bench.py --no-cpu-baseline --no-aux --steps 15 --warmup 1 > $OUT/pass$i.log 2>&1
 done
 cd $REPO
 TAG=$TAG python - <<'PY'
