@@ -174,3 +174,27 @@ def test_capi_argument_validation_without_gpu():
     assert run(fwd_flow=None, bwd_flow=None, fwd_occ=None, bwd_occ=None, target=None) == EINVAL
     assert run(fwd_flow=None, bwd_flow=None, fwd_occ=None, bwd_occ=None, iw=0.0) == EINVAL
     assert run(wsb=need - 1) == EWS
+
+
+def test_standin_unet_has_the_sd15_shapes():
+    """tools/standin_unet.py (full-step measurement only): parameter counts and the tensors entering the four
+    up-blocks must be SD-1.5's, and the hook of apply_FRESCO_opt must see them."""
+    import sys
+    import types
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from standin_unet import ControlNet, UNet
+    import fresco_amd
+
+    unet = UNet().eval()
+    assert round(sum(p.numel() for p in unet.parameters()) / 1e6, 1) == 859.5
+    assert round(sum(p.numel() for p in ControlNet().parameters()) / 1e6, 1) == 361.3
+    assert len(unet.fresco_self_attentions()) == 6
+    assert [a.to_q.in_features for a in unet.fresco_self_attentions()] == [640] * 3 + [320] * 3
+    pipe = types.SimpleNamespace(unet=unet)
+    fresco_amd.apply_FRESCO_opt(pipe)  # = disable_FRESCO_opt: collects the decoder features, never optimises
+    x, ctx = torch.randn(2, 4, 8, 8), torch.randn(2, 77, 768)
+    with torch.no_grad():
+        out = unet(x, 900, ctx, return_dict=False)
+    assert tuple(out[0].shape) == (2, 4, 8, 8)
+    assert [tuple(t.shape[1:]) for t in out[1:]] == [(1280, 1, 1), (1280, 2, 2), (1280, 4, 4), (640, 8, 8)]
