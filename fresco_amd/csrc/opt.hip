@@ -758,14 +758,19 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
     }
 }
 
-constexpr int GK16 = 32;              // K chunk (channels): 64-byte row segments
-constexpr int GROW = GK16 * 2 + 16;   // LDS bytes per tile row (80: odd multiple of 16)
-
+// K chunk (channels) per staging step, template parameter GK16: 32 (64-byte row segments, 40 KB of LDS: four
+// workgroups per CU) for the big planes; 64 for hw <= 1024, where a launch is a few hundred workgroups of 10-20 chunks
+// and half as many barrier pairs matter more than occupancy (gram at 8^2 / 16^2 / 32^2: 49 / 55 / 162 -> 44 / 46 / 140 us;
+// at 64^2 the 74 KB variant is slower, 737 -> 896 us).  LDS rows of GK16*2 + 16 bytes: an odd multiple of 16.
 // grid (nt*(nt+1)/2, 1, B)
+template <int GK16>
 __global__ __launch_bounds__(256) void gram16_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
                                                       const float* __restrict__ target,
                                                       int8_t* __restrict__ sgn_out, float* __restrict__ loss,
                                                       int C, int hw) {
+    constexpr int GCPR = GK16 / 8;         // 16-byte chunks per staged row
+    constexpr int GNLD = GT * GCPR / 256;  // chunks per thread and array
+    constexpr int GROW = GK16 * 2 + 16;    // LDS bytes per tile row
     __shared__ __attribute__((aligned(16))) char lds[4][GT * GROW];  // [Ah, Al, Bh, Bl][pixel row]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -782,12 +787,12 @@ __global__ __launch_bounds__(256) void gram16_kernel(const half_t* __restrict__ 
     // staging: 4 arrays x 128 rows x 4 chunks of 8 halfs = 2 chunks per thread and array (native vector
     // type: arrays of HIP's uint4 struct are not promoted to registers).  A second register set (two K
     // chunks in flight) was measured: no gain.
-    u32x4 rgA[2][4];
-    auto load = [&](int k0, u32x4 (&rg)[2][4]) {
+    u32x4 rgA[GNLD][4];
+    auto load = [&](int k0, u32x4 (&rg)[GNLD][4]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < GNLD; ++i) {
             const int ch = tid + i * 256;
-            const int srow = ch >> 2, skc = ch & 3;
+            const int srow = ch / GCPR, skc = ch % GCPR;
             const int k = k0 + skc * 8;
             const int pa = p0 + srow, pb = q0 + srow;
             const u32x4 z = {0u, 0u, 0u, 0u};
@@ -798,11 +803,11 @@ __global__ __launch_bounds__(256) void gram16_kernel(const half_t* __restrict__ 
             rg[i][3] = (ka && pb < hw) ? *reinterpret_cast<const u32x4*>(lb + (int64_t)pb * C + k) : z;
         }
     };
-    auto store = [&](const u32x4 (&rg)[2][4]) {
+    auto store = [&](const u32x4 (&rg)[GNLD][4]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < GNLD; ++i) {
             const int ch = tid + i * 256;
-            const int srow = ch >> 2, skc = ch & 3;
+            const int srow = ch / GCPR, skc = ch % GCPR;
 #pragma unroll
             for (int a = 0; a < 4; ++a) *reinterpret_cast<u32x4*>(&lds[a][srow * GROW + skc * 16]) = rg[i][a];
         }
@@ -1104,8 +1109,12 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         {
             ProfScope ps(FRESCO_PROF_OPT_GRAM, B, C, hw, 0, st);
             if (f16_sv && C % 8 == 0) {
-                hipLaunchKernelGGL(gram16_kernel, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vph, w.vpl, target,
-                                   w.ssign, loss ? loss + 1 : nullptr, C, hw);
+                if (hw <= 1024)
+                    hipLaunchKernelGGL(gram16_kernel<64>, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vph, w.vpl,
+                                       target, w.ssign, loss ? loss + 1 : nullptr, C, hw);
+                else
+                    hipLaunchKernelGGL(gram16_kernel<32>, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vph, w.vpl,
+                                       target, w.ssign, loss ? loss + 1 : nullptr, C, hw);
             } else
                 hipLaunchKernelGGL((gram_kernel<0>), dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vt, target,
                                    w.ssign, (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
