@@ -840,12 +840,15 @@ __global__ __launch_bounds__(256) void gram16_kernel(const half_t* __restrict__ 
     };
     const int nk = (C + GK16 - 1) / GK16;
     load(0, rgA);
+#ifndef FRESCO_GRAM_ABL
+#define FRESCO_GRAM_ABL 0
+#endif
     for (int kc = 0; kc + 1 < nk; ++kc) {
-        store(rgA);  // the previous chunk's LDS reads are behind the barrier that ended the last iteration
-        __syncthreads();
-        load((kc + 1) * GK16, rgA);
+        if (!(FRESCO_GRAM_ABL & 1)) store(rgA);  // the previous chunk's LDS reads are behind the barrier that ended the last iteration
+        if (!(FRESCO_GRAM_ABL & 2)) __syncthreads();
+        if (!(FRESCO_GRAM_ABL & 1)) load((kc + 1) * GK16, rgA);
         compute();
-        __syncthreads();
+        if (!(FRESCO_GRAM_ABL & 2)) __syncthreads();
     }
     store(rgA);
     __syncthreads();
