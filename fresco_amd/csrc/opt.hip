@@ -456,6 +456,14 @@ __device__ __forceinline__ void tile_prefetch(TilePre& t, const float* __restric
 // Epilogue shared by the fp32 and the fp16-split Gram kernels: MODE 0 writes sign(G - T) (and, for an
 // off-diagonal tile, the transposed tile to the mirror position, staged through `tr` = >= 18 KB of LDS
 // that is free once the main loop is done); MODE 1 writes G.
+// sign(G - T) is stored as ONE BYTE = the high byte of the fp16 value of the sign (0x3C: +1, 0xBC: -1, 0x00: 0), so
+// that the fp16-MFMA kernel expands four of them to packed halfs with two v_perm_b32 (a plain int8 sign costs ~4 VALU
+// operations per value there, enough to make the S V kernel issue-bound next to its MFMAs).
+__device__ __forceinline__ int8_t sign_byte(float d) { return (int8_t)(d > 0.f ? 0x3C : (d < 0.f ? 0xBC : 0)); }
+__device__ __forceinline__ float sign_from_byte(uint32_t b) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)((b & 0xffu) << 8));
+}
+
 template <int MODE, bool PRE>
 __device__ __forceinline__ void gram_epilogue(const GemmAcc& acc, int8_t* tr, const float* __restrict__ target,
                                               int8_t* __restrict__ sgn_out, float* __restrict__ g_out,
@@ -484,7 +492,7 @@ __device__ __forceinline__ void gram_epilogue(const GemmAcc& acc, int8_t* tr, co
                     const float gval = acc.a[mi][ni][r];
                     if (MODE == 0) {
                         const float d = gval - (PRE ? pre.v[mi][ni][r] : target[o]);
-                        v8 = (int8_t)sgn(d);
+                        v8 = sign_byte(d);
                         lsum += fabsf(d);
                     } else {
                         g_out[o] = gval;
@@ -650,13 +658,13 @@ __global__ __launch_bounds__(256) void sv_kernel(const float* __restrict__ vt,
                 const int2 raw = *reinterpret_cast<const int2*>(sp);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    rb[j] = (float)(int8_t)((raw.x >> (8 * j)) & 0xff);
-                    rb[4 + j] = (float)(int8_t)((raw.y >> (8 * j)) & 0xff);
+                    rb[j] = sign_from_byte((uint32_t)raw.x >> (8 * j));
+                    rb[4 + j] = sign_from_byte((uint32_t)raw.y >> (8 * j));
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (p + j < hw) rb[j] = (float)sp[j];
+                    if (p + j < hw) rb[j] = sign_from_byte((uint8_t)sp[j]);
             }
         }
     };
@@ -915,15 +923,18 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
             *reinterpret_cast<uint4*>(&lds[st][1][row * SROW + kc * 16]) = rvl[i];
         }
         const int row = tid >> 1, kc = tid & 1;
+        // 16 sign bytes -> 16 halfs: each byte IS the high byte of its fp16 value (sign_byte): two v_perm_b32 per dword
         const unsigned w4[4] = {rs.x, rs.y, rs.z, rs.w};
-        half8_t h0, h1;
+        u32x4 h0, h1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            h0[e] = (half_t)(float)(int8_t)((w4[e >> 2] >> (8 * (e & 3))) & 0xff);
-            h1[e] = (half_t)(float)(int8_t)((w4[2 + (e >> 2)] >> (8 * (e & 3))) & 0xff);
+        for (int e = 0; e < 2; ++e) {
+            h0[2 * e] = __builtin_amdgcn_perm(0u, w4[e], 0x010c000cu);          // [b1 0 b0 0]
+            h0[2 * e + 1] = __builtin_amdgcn_perm(0u, w4[e], 0x030c020cu);      // [b3 0 b2 0]
+            h1[2 * e] = __builtin_amdgcn_perm(0u, w4[2 + e], 0x010c000cu);
+            h1[2 * e + 1] = __builtin_amdgcn_perm(0u, w4[2 + e], 0x030c020cu);
         }
-        *reinterpret_cast<half8_t*>(&lds[st][2][row * SROW + kc * 32]) = h0;
-        *reinterpret_cast<half8_t*>(&lds[st][2][row * SROW + kc * 32 + 16]) = h1;
+        *reinterpret_cast<u32x4*>(&lds[st][2][row * SROW + kc * 32]) = h0;
+        *reinterpret_cast<u32x4*>(&lds[st][2][row * SROW + kc * 32 + 16]) = h1;
     };
 
     floatx16 acc[2][2];
