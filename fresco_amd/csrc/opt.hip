@@ -949,9 +949,12 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
     load(0);
     store(0);
     __syncthreads();
+#ifndef FRESCO_SV_ABL
+#define FRESCO_SV_ABL 0  // timing experiments only: 1 = no staging of the next chunk, 2 = no barriers
+#endif
     for (int kc = 0; kc < nk; ++kc) {
-        const int st = kc & 1;
-        if (kc + 1 < nk) load((kc + 1) * SK);
+        const int st = (FRESCO_SV_ABL & 1) ? 0 : (kc & 1);
+        if (!(FRESCO_SV_ABL & 1) && kc + 1 < nk) load((kc + 1) * SK);
         const char* ah = &lds[st][0][0];
         const char* al = &lds[st][1][0];
         const char* bs = &lds[st][2][0];
@@ -973,8 +976,8 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (kc + 1 < nk) store(st ^ 1);
-        __syncthreads();
+        if (!(FRESCO_SV_ABL & 1) && kc + 1 < nk) store(st ^ 1);
+        if (!(FRESCO_SV_ABL & 2)) __syncthreads();
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
