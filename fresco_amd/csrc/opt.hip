@@ -27,6 +27,7 @@
 namespace fresco {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
 // shared bilinear tap helper (same arithmetic as warp.hip: geometry.py:50-55,65-72)
@@ -993,6 +994,149 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same product for the big planes (hw % 512 == 0, C % 128 == 0): 128 (c) x 512 (p) workgroup tiles, 8 waves of
+// 64 x 128.  tools ablation of sv16_kernel (profiles/r02_attn_experiments.txt section 5): 45 % of its time is the
+// staging work itself -- on a 128 x 128 tile with 2 x 2 waves every staged byte is read from LDS only twice, and each
+// thread pays 5 global loads + 6 ds_write_b128 per 16 MFMAs.  Here
+//   * operands arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no VALU) into a 3-slot ring, two K
+//     chunks ahead, behind counted vmcnt waits and one barrier per chunk (the protocol of proj.hip / attn.hip);
+//   * S stays ONE BYTE per sign in LDS (the fp16 high byte, sign_byte): half the LDS bytes of the widened form, expanded
+//     to packed halfs after the ds_read_b64 with two v_perm_b32 per dword;
+//   * a wave reads 4 V fragments + 4 S fragments per 16 MFMAs (0.5 LDS reads per MFMA instead of 0.75) and a staged
+//     byte is reused by 4 (V) / 2 (S) waves.
+// LDS rows: V 64 B + 16 B pad, S 32 B + 16 B pad (odd multiples of 16: conflict-free fragment reads); the pad chunks
+// are DMA'd too (they re-read chunk 0) so that a slot is a linear sequence of 1 KiB pieces.
+// ------------------------------------------------------------------------------------------------
+constexpr int SB_TC = 128, SB_TP = 512, SB_K = 32;
+constexpr int SB_VROW = SB_K * 2 + 16, SB_SROW = SB_K + 16;
+constexpr int SB_VARR = SB_TC * SB_VROW;          // one V array (hi or lo) of a slot: 10 pieces
+constexpr int SB_SARR = SB_TP * SB_SROW;          // the S rows of a slot: 24 pieces
+constexpr int SB_SLOT = 2 * SB_VARR + SB_SARR;    // 44 KiB
+constexpr int SB_NP = SB_SLOT / 1024;             // 44 pieces per slot
+constexpr int SB_NSLOT = 3;
+constexpr int SB_NPW = (SB_NP + 7) / 8;           // pieces per wave and slot: 6 for waves 0-3, 5 for waves 4-7
+
+template <int N_>
+__device__ __forceinline__ void sb_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
+                                                       const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
+                                                       int C, int hw, float alpha) {
+    extern __shared__ __attribute__((aligned(16))) char sb_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * SB_TC, p0 = blockIdx.x * SB_TP;
+    const char* vhb = reinterpret_cast<const char*>(vh + ((int64_t)b * C + c0) * hw);
+    const char* vlb = reinterpret_cast<const char*>(vl + ((int64_t)b * C + c0) * hw);
+    const char* sbp = reinterpret_cast<const char*>(sgn_in + ((int64_t)b * hw + p0) * hw);
+    const uint32_t lds0 =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sb_smem);
+
+    // DMA: wave w issues pieces w, w + 8, ... of a slot; per-lane source offset inside its array, computed once
+    uint32_t doff[SB_NPW];
+#pragma unroll
+    for (int i = 0; i < SB_NPW; ++i) {
+        const int pc = wave + 8 * i;
+        if (pc < 2 * (SB_VARR / 1024)) {  // a V array: rows of 5 chunks (4 data + pad)
+            const int o = (pc % (SB_VARR / 1024)) * 1024 + lane * 16;
+            const int row = o / SB_VROW, cc = (o % SB_VROW) / 16;
+            doff[i] = (uint32_t)(row * hw * 2 + (cc < 4 ? cc * 16 : 0));
+        } else {  // S: rows of 3 chunks (2 data + pad)
+            const int o = (pc - 2 * (SB_VARR / 1024)) * 1024 + lane * 16;
+            const int row = o / SB_SROW, cc = (o % SB_SROW) / 16;
+            doff[i] = (uint32_t)(row * hw + (cc < 2 ? cc * 16 : 0));
+        }
+    }
+    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
+        const int k0 = kc * SB_K;
+#pragma unroll
+        for (int i = 0; i < SB_NPW; ++i) {
+            const int pc = wave + 8 * i;
+            if (pc < SB_NP) {
+                const int arr = pc / (SB_VARR / 1024);  // 0: Vh, 1: Vl, >= 2: S
+                const char* src = arr == 0 ? vhb + (int64_t)k0 * 2 : (arr == 1 ? vlb + (int64_t)k0 * 2 : sbp + k0);
+                const uint32_t m0v = lds0 + (uint32_t)(slot * SB_SLOT + pc * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(doff[i]), "s"(src), "s"(m0v)
+                             : "memory");
+            }
+        }
+    };
+    const int many = wave < SB_NP - 8 * (SB_NPW - 1) ? 1 : 0;  // this wave issues SB_NPW pieces per slot (else one fewer)
+    auto wait_barrier = [&](int keep) __attribute__((always_inline)) {  // keep = newer slots that may stay in flight
+        if (keep == 0)
+            sb_wait_barrier<0>();
+        else if (many)
+            sb_wait_barrier<SB_NPW>();
+        else
+            sb_wait_barrier<SB_NPW - 1>();
+    };
+
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = hw / SB_K;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    wait_barrier(nk > 1 ? 1 : 0);
+    int slot = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : SB_NSLOT - 1);  // the slot of chunk kc - 1
+        const char* base = sb_smem + slot * SB_SLOT;
+#pragma unroll
+        for (int ks = 0; ks < SB_K / 16; ++ks) {
+            half8_t fa[2][2], fb[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + l31) * SB_VROW + ks * 32 + hi * 16;
+                fa[i][0] = *reinterpret_cast<const half8_t*>(base + off);
+                fa[i][1] = *reinterpret_cast<const half8_t*>(base + SB_VARR + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(base + 2 * SB_VARR +
+                                                                  (wn * 128 + j * 32 + l31) * SB_SROW + ks * 16 + hi * 8);
+                u32x4 w;
+                w[0] = __builtin_amdgcn_perm(0u, raw[0], 0x010c000cu);
+                w[1] = __builtin_amdgcn_perm(0u, raw[0], 0x030c020cu);
+                w[2] = __builtin_amdgcn_perm(0u, raw[1], 0x010c000cu);
+                w[3] = __builtin_amdgcn_perm(0u, raw[1], 0x030c020cu);
+                fb[j] = __builtin_bit_cast(half8_t, w);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < nk) wait_barrier(kc + 2 < nk ? 1 : 0);
+        slot = slot == SB_NSLOT - 1 ? 0 : slot + 1;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int col = p0 + wn * 128 + ni * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                dvt[((int64_t)b * C + row) * hw + col] = acc[mi][ni][r] * alpha;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // norm backward + Adam, elementwise.  grid (ceil(hw/256), ceil(C/ECPT), B)
 //   g = grad_t (if has_t) + (dV - V <V,dV>)/|X| (if has_s);  <V,dV>[b][p] = sum of the S partials
 // mode 0: Adam update of cs, m, v;  mode 1: write g to gout (loss_grad entry)
@@ -1139,7 +1283,12 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         const float coef = intra_weight / ((float)Bg * (float)hw * (float)hw);
         {
             ProfScope ps(FRESCO_PROF_OPT_SV, B, C, hw, 0, st);
-            if (f16_sv)
+            if (f16_sv && hw % SB_TP == 0 && C % SB_TC == 0) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, SB_NSLOT * SB_SLOT);
+                hipLaunchKernelGGL(sv16b_kernel, dim3(hw / SB_TP, C / SB_TC, B), dim3(512), SB_NSLOT * SB_SLOT, st, w.vh,
+                                   w.vl, w.ssign, w.dvt, C, hw, 2.f * coef);
+            } else if (f16_sv)
                 hipLaunchKernelGGL(sv16_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vh, w.vl,
                                    w.ssign, w.dvt, C, hw, 2.f * coef);
             else
