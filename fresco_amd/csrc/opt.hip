@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(512, 2) void sv16b_kernel(const half_t* __restrict_
     wait_barrier(nk > 1 ? 1 : 0);
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : SB_NSLOT - 1);  // the slot of chunk kc - 1
+        if ((!(FRESCO_SV_ABL & 1) || kc == 0) && kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : SB_NSLOT - 1);  // the slot of chunk kc - 1
         const char* base = sb_smem + slot * SB_SLOT;
 #pragma unroll
         for (int ks = 0; ks < SB_K / 16; ++ks) {
@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(512, 2) void sv16b_kernel(const half_t* __restrict_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (kc + 1 < nk) wait_barrier(kc + 2 < nk ? 1 : 0);
+        if ((!(FRESCO_SV_ABL & 2) || kc < 2) && kc + 1 < nk) wait_barrier(((FRESCO_SV_ABL & 1) && kc > 0) ? 0 : (kc + 2 < nk ? 1 : 0));
         slot = slot == SB_NSLOT - 1 ? 0 : slot + 1;
     }
 #pragma unroll
