@@ -468,7 +468,12 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
                 float mt = fmaxf(s[j][0][0], s[j][1][0]);
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[j][0][r]), s[j][1][r]);  // v_max3_f32
-                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                {   // the other half of the wave holds the query's other 32 keys of the tile: v_permlane32_swap (VALU) instead
+                    // of a ds_bpermute through the LDS pipe (the builtin inserts the wait state the swap needs)
+                    const unsigned mb = __builtin_bit_cast(unsigned, mt);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                    mt = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+                }
                 if (u == 0 || __builtin_amdgcn_readfirstlane((int)__any(mt > resc_thr)) != 0) {
                     float delta = (u == 0) ? mt : fmaxf(mt, 0.f);
                     if (Cfg::MCOL) {
