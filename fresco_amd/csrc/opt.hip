@@ -994,36 +994,43 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same product for the big planes (hw % 512 == 0, C % 128 == 0): 128 (c) x 512 (p) workgroup tiles, 8 waves of
-// 64 x 128.  tools ablation of sv16_kernel (profiles/r02_attn_experiments.txt section 5): 45 % of its time is the
-// staging work itself -- on a 128 x 128 tile with 2 x 2 waves every staged byte is read from LDS only twice, and each
-// thread pays 5 global loads + 6 ds_write_b128 per 16 MFMAs.  Here
-//   * operands arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no VALU) into a 3-slot ring, two K
-//     chunks ahead, behind counted vmcnt waits and one barrier per chunk (the protocol of proj.hip / attn.hip);
+// The same product for the big planes (hw % 256 == 0, C % 128 == 0): 128 (c) x 256 (p) workgroup tiles, 8 waves of
+// 64 x 64, two workgroups per CU.  Ablation of sv16_kernel (profiles/r02_attn_experiments.txt section 5): 45 % of its
+// time is the staging work itself -- each thread pays 5 global loads + 6 ds_write_b128 (with the sign expansion) per 16
+// MFMAs, and two chunks of register look-ahead do not help.  Here
+//   * operands arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no VALU) into a ring of slots behind
+//     counted vmcnt waits and one barrier per chunk (the protocol of proj.hip / attn.hip); with the registers that
+//     frees (108) two workgroups share a CU, so a 2-slot ring (one chunk ahead) is enough: while one workgroup waits
+//     for its chunk the other multiplies;
 //   * S stays ONE BYTE per sign in LDS (the fp16 high byte, sign_byte): half the LDS bytes of the widened form, expanded
-//     to packed halfs after the ds_read_b64 with two v_perm_b32 per dword;
-//   * a wave reads 4 V fragments + 4 S fragments per 16 MFMAs (0.5 LDS reads per MFMA instead of 0.75) and a staged
-//     byte is reused by 4 (V) / 2 (S) waves.
+//     to packed halfs after the ds_read_b64 with two v_perm_b32 per dword.
 // LDS rows: V 64 B + 16 B pad, S 32 B + 16 B pad (odd multiples of 16: conflict-free fragment reads); the pad chunks
 // are DMA'd too (they re-read chunk 0) so that a slot is a linear sequence of 1 KiB pieces.
 // ------------------------------------------------------------------------------------------------
-constexpr int SB_TC = 128, SB_TP = 512, SB_K = 32;
+constexpr int SB_TC = 128, SB_K = 32;
 constexpr int SB_VROW = SB_K * 2 + 16, SB_SROW = SB_K + 16;
 constexpr int SB_VARR = SB_TC * SB_VROW;          // one V array (hi or lo) of a slot: 10 pieces
-constexpr int SB_SARR = SB_TP * SB_SROW;          // the S rows of a slot: 24 pieces
-constexpr int SB_SLOT = 2 * SB_VARR + SB_SARR;    // 44 KiB
-constexpr int SB_NP = SB_SLOT / 1024;             // 44 pieces per slot
-constexpr int SB_NSLOT = 3;
-constexpr int SB_NPW = (SB_NP + 7) / 8;           // pieces per wave and slot: 6 for waves 0-3, 5 for waves 4-7
+constexpr int SB_NSLOT = 2;
+template <int TP>                                 // pixels per workgroup tile (waves of 64 x TP/4)
+struct SbCfg {
+    static constexpr int NJ = TP / 128;               // 32-column blocks per wave
+    static constexpr int SARR = TP * SB_SROW;         // the S rows of a slot
+    static constexpr int SLOT = 2 * SB_VARR + SARR;   // 44 KiB (TP = 512) / 32 KiB
+    static constexpr int NP = SLOT / 1024;            // 1 KiB pieces per slot
+    static constexpr int NPW = (NP + 7) / 8;          // pieces per wave and slot (the last waves one fewer)
+};
 
 template <int N_>
 __device__ __forceinline__ void sb_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
 }
 
-__global__ __launch_bounds__(512, 2) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
+template <int TP, int NS>
+__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
                                                        const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
                                                        int C, int hw, float alpha) {
+    using Cfg = SbCfg<TP>;
+    constexpr int SB_TP = TP, SB_SLOT = Cfg::SLOT, SB_NP = Cfg::NP, SB_NPW = Cfg::NPW, NJ = Cfg::NJ;
     extern __shared__ __attribute__((aligned(16))) char sb_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1076,25 +1083,26 @@ __global__ __launch_bounds__(512, 2) void sv16b_kernel(const half_t* __restrict_
             sb_wait_barrier<SB_NPW - 1>();
     };
 
-    floatx16 acc[2][4];
+    floatx16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = hw / SB_K;
     stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    wait_barrier(nk > 1 ? 1 : 0);
+    if (NS > 2 && nk > 1) stage(1, 1);
+    wait_barrier(NS > 2 && nk > 1 ? 1 : 0);
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        if ((!(FRESCO_SV_ABL & 1) || kc == 0) && kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : SB_NSLOT - 1);  // the slot of chunk kc - 1
+        // the slot of chunk kc - 1 takes chunk kc + NS - 1
+        if ((!(FRESCO_SV_ABL & 1) || kc == 0) && kc + NS - 1 < nk) stage(kc + NS - 1, slot >= 1 ? slot - 1 : NS - 1);
         const char* base = sb_smem + slot * SB_SLOT;
 #pragma unroll
         for (int ks = 0; ks < SB_K / 16; ++ks) {
-            half8_t fa[2][2], fb[4];
+            half8_t fa[2][2], fb[NJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int off = (wm * 64 + i * 32 + l31) * SB_VROW + ks * 32 + hi * 16;
@@ -1102,9 +1110,9 @@ __global__ __launch_bounds__(512, 2) void sv16b_kernel(const half_t* __restrict_
                 fa[i][1] = *reinterpret_cast<const half8_t*>(base + SB_VARR + off);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const u32x2 raw = *reinterpret_cast<const u32x2*>(base + 2 * SB_VARR +
-                                                                  (wn * 128 + j * 32 + l31) * SB_SROW + ks * 16 + hi * 8);
+                                                                  (wn * (32 * NJ) + j * 32 + l31) * SB_SROW + ks * 16 + hi * 8);
                 u32x4 w;
                 w[0] = __builtin_amdgcn_perm(0u, raw[0], 0x010c000cu);
                 w[1] = __builtin_amdgcn_perm(0u, raw[0], 0x030c020cu);
@@ -1115,19 +1123,20 @@ __global__ __launch_bounds__(512, 2) void sv16b_kernel(const half_t* __restrict_
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if ((!(FRESCO_SV_ABL & 2) || kc < 2) && kc + 1 < nk) wait_barrier(((FRESCO_SV_ABL & 1) && kc > 0) ? 0 : (kc + 2 < nk ? 1 : 0));
-        slot = slot == SB_NSLOT - 1 ? 0 : slot + 1;
+        if ((!(FRESCO_SV_ABL & 2) || kc < 2) && kc + 1 < nk)
+            wait_barrier(((FRESCO_SV_ABL & 1) && kc > 0) || NS == 2 ? 0 : (kc + 2 < nk ? 1 : 0));
+        slot = slot == NS - 1 ? 0 : slot + 1;
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int col = p0 + wn * 128 + ni * 32 + l31;
+        for (int ni = 0; ni < NJ; ++ni) {
+            const int col = p0 + wn * (32 * NJ) + ni * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = c0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -1283,10 +1292,13 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         const float coef = intra_weight / ((float)Bg * (float)hw * (float)hw);
         {
             ProfScope ps(FRESCO_PROF_OPT_SV, B, C, hw, 0, st);
-            if (f16_sv && hw % SB_TP == 0 && C % SB_TC == 0) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, SB_NSLOT * SB_SLOT);
-                hipLaunchKernelGGL(sv16b_kernel, dim3(hw / SB_TP, C / SB_TC, B), dim3(512), SB_NSLOT * SB_SLOT, st, w.vh,
+            if (f16_sv && hw % 256 == 0 && C % SB_TC == 0) {
+                // measured at (640, 64^2): 128 x 512 tiles / 3-slot ring / one workgroup per CU 617-629 us;
+                // 128 x 256 / 3 slots 619; 128 x 256 / 2 slots / two workgroups per CU (108 registers) 532
+                constexpr int lds = SB_NSLOT * SbCfg<256>::SLOT;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<256, SB_NSLOT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL((sv16b_kernel<256, SB_NSLOT>), dim3(hw / 256, C / SB_TC, B), dim3(512), lds, st, w.vh,
                                    w.vl, w.ssign, w.dvt, C, hw, 2.f * coef);
             } else if (f16_sv)
                 hipLaunchKernelGGL(sv16_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vh, w.vl,
