@@ -1,5 +1,5 @@
-"""Time fresco_temporal_attn alone (HIP events around batches of launches) at the bench's layer shapes.
-   python tools/bench_temporal.py [N] [res]      env FRESCO_TEMPORAL_NT = 64 | 128 | 256 picks the block size"""
+"""Time fresco_temporal_attn alone (the library's HIP events around each launch) at the bench's layer shapes.
+   python tools/bench_temporal.py [N] [res]"""
 import math
 import os
 import sys
@@ -40,5 +40,5 @@ for layer, C, down in (("L3", 320, 8), ("L2", 640, 16)):
     t = sorted(ms[i] for i in range(n))
     best = t[len(t) // 2] * 1e3  # median, us (HIP events on the launch stream)
     byts = 4 * 2 * N * HW * C * 2
-    print("temporal %s N=%d HW=%d C=%d NT=%s: %.1f us/launch (median of 20, events around the kernel)  %.2f TB/s algorithmic"
-          % (layer, N, HW, C, os.environ.get("FRESCO_TEMPORAL_NT", "default") + "/abl" + os.environ.get("FRESCO_TEMPORAL_ABL", "0"), best, byts / best / 1e6))
+    print("temporal %s N=%d HW=%d C=%d: %.1f us/launch (median of 20, events around the kernel)  %.2f TB/s algorithmic"
+          % (layer, N, HW, C, best, byts / best / 1e6))
