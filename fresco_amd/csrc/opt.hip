@@ -869,6 +869,147 @@ __global__ __launch_bounds__(256) void gram16_kernel(const half_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same Gram step for the big planes (hw % 128 == 0, hw > 1024, C % 32 == 0) with 16 resident waves per CU:
+// 8 waves per 128 x 128 tile (wave tile 64 x 32: 32 accumulators + 32 prefetched target values per lane, ~120
+// registers), operands by LDS-DMA into a 2-slot ring (no staging registers / ds_write / VALU), two workgroups per CU.
+// The register-staged 4-wave kernel above sits at 8 waves per CU (64 + 64 values per lane) and loses 43 % of its
+// time to the staging chain (profiles/r02_attn_experiments.txt section 5); what helped the S V kernel -- DMA AND
+// twice the resident waves -- is applied here.  A slot is 4 arrays (Ah, Al, Bh, Bl) x 128 rows x 80 B = 40 pieces of
+// 1 KiB; wave w issues pieces w, w + 8, ...; rows of 5 chunks (4 data + the pad chunk, which re-reads chunk 0).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
+                                                         const float* __restrict__ target,
+                                                         int8_t* __restrict__ sgn_out, float* __restrict__ loss,
+                                                         int C, int hw) {
+    constexpr int GK16 = 32, GROW = GK16 * 2 + 16, ARR = GT * GROW, SLOT = 4 * ARR, NPA = ARR / 1024, NPW = 4 * NPA / 8;
+    constexpr int TRS = GT + 16;
+    __shared__ __attribute__((aligned(16))) char lds2[2][SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z;
+    int ti, tj;
+    tri_tile(blockIdx.x, hw / GT, ti, tj);
+    const int p0 = ti * GT, q0 = tj * GT;
+    const char* srcA_h = reinterpret_cast<const char*>(vph + ((int64_t)b * hw + p0) * C);
+    const char* srcA_l = reinterpret_cast<const char*>(vpl + ((int64_t)b * hw + p0) * C);
+    const int64_t dB = ((int64_t)q0 - p0) * C * 2;  // B rows relative to the A rows
+    const uint32_t lds0 =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)&lds2[0][0]);
+
+    // this lane's 32 target values in accumulator order (half at the top, half before the last chunk)
+    float pre[2][16];
+    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 32 + l31;
+    auto prefetch = [&](int mi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pre[mi][r] = tgt[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * hw];
+    };
+    prefetch(0);
+
+    uint32_t doff[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int o = ((wave + 8 * i) % NPA) * 1024 + lane * 16;
+        const int row = o / GROW, cc = (o % GROW) / 16;
+        doff[i] = (uint32_t)(row * C * 2 + (cc < GK16 / 8 ? cc * 16 : 0));
+    }
+    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int pc = wave + 8 * i;  // 0 .. 39
+            const int arr = pc / NPA;     // Ah, Al, Bh, Bl
+            const char* src = ((arr & 1) ? srcA_l : srcA_h) + (int64_t)(arr >> 1) * dB + (int64_t)kc * GK16 * 2;
+            const uint32_t m0v = lds0 + (uint32_t)(slot * SLOT + pc * 1024);
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(doff[i]), "s"(src), "s"(m0v)
+                         : "memory");
+        }
+    };
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int nk = C / GK16;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 1 < nk) stage(kc + 1, (kc + 1) & 1);
+        const char* L = &lds2[kc & 1][0];
+#pragma unroll
+        for (int ks = 0; ks < GK16 / 16; ++ks) {
+            half8_t ah[2], al[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oa = (wm * 64 + i * 32 + l31) * GROW + ks * 32 + hi * 16;
+                ah[i] = *reinterpret_cast<const half8_t*>(L + oa);
+                al[i] = *reinterpret_cast<const half8_t*>(L + ARR + oa);
+            }
+            const int ob = (wn * 32 + l31) * GROW + ks * 32 + hi * 16;
+            const half8_t bh = *reinterpret_cast<const half8_t*>(L + 2 * ARR + ob);
+            const half8_t bl = *reinterpret_cast<const half8_t*>(L + 3 * ARR + ob);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i], 0, 0, 0);
+            }
+        }
+        // (the wait also covers the target prefetch issued before the last chunk: it is consumed right after the loop)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kc + 2 == nk) prefetch(1);
+    }
+
+    // ---- epilogue: sign(G - T) bytes, tile and (off the diagonal) mirrored tile as 16-byte rows through LDS ----
+    int8_t* tr = reinterpret_cast<int8_t*>(&lds2[0][0]);
+    const bool mirror = ti != tj;
+    float lsum = 0.f;
+    int8_t sg[2][16];
+    const int cl = wn * 32 + l31;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float d = acc[mi][r] - pre[mi][r];
+            const int8_t v8 = sign_byte(d);
+            lsum += fabsf(d);
+            sg[mi][r] = v8;
+            tr[rl * TRS + cl] = v8;
+        }
+    auto flush = [&](int r0, int c0) {
+        __syncthreads();
+        for (int i = tid; i < GT * (GT / 16); i += 512) {
+            const int rl = i / (GT / 16), ch = i % (GT / 16);
+            *reinterpret_cast<uint4*>(sgn_out + ((int64_t)b * hw + r0 + rl) * hw + c0 + ch * 16) =
+                *reinterpret_cast<const uint4*>(tr + rl * TRS + ch * 16);
+        }
+    };
+    flush(p0, q0);
+    if (mirror) {
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                tr[cl * TRS + rl] = sg[mi][r];
+            }
+        flush(q0, p0);
+    }
+    if (loss) {
+        float* red = reinterpret_cast<float*>(tr + GT * TRS);  // behind the sign tile
+        const float tot = wave_sum(mirror ? 2.f * lsum : lsum);
+        __syncthreads();
+        if (lane == 0) red[wave] = tot;
+        __syncthreads();
+        if (tid == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dV^T = alpha * V^T S on fp16 MFMA with V split into two halfs:  V = Vh + Vl,  |V| <= 1, so the pair
 // carries V to an absolute 2^-25 -- fp32 class -- and S in {-1,0,1} is exact in fp16; every product
 // is exact in the fp32 accumulator.  2 x v_mfma_f32_32x32x16_f16 replace 8 x v_mfma_f32_32x32x2_f32:
@@ -1281,6 +1422,9 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
             if (f16_sv && C % 8 == 0) {
                 if (hw <= 1024)
                     hipLaunchKernelGGL(gram16_kernel<64>, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vph, w.vpl,
+                                       target, w.ssign, loss ? loss + 1 : nullptr, C, hw);
+                else if (hw % GT == 0 && C % 32 == 0 && C >= 64)
+                    hipLaunchKernelGGL(gram16w_kernel, dim3(nt * (nt + 1) / 2, 1, B), dim3(512), 0, st, w.vph, w.vpl,
                                        target, w.ssign, loss ? loss + 1 : nullptr, C, hw);
                 else
                     hipLaunchKernelGGL(gram16_kernel<32>, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vph, w.vpl,
