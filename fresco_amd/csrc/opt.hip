@@ -888,9 +888,14 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z;
+    // XCD-aware order (see sv16b_kernel): every XCD works through a contiguous range of the (plane, tile) list, so
+    // that the A rows shared by the tiles of one tile row stay in ONE L2
+    int lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const int total = gridDim.x * gridDim.z;
+    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
+    const int b = lin / gridDim.x;
     int ti, tj;
-    tri_tile(blockIdx.x, hw / GT, ti, tj);
+    tri_tile(lin % gridDim.x, hw / GT, ti, tj);
     const int p0 = ti * GT, q0 = tj * GT;
     const char* srcA_h = reinterpret_cast<const char*>(vph + ((int64_t)b * hw + p0) * C);
     const char* srcA_l = reinterpret_cast<const char*>(vpl + ((int64_t)b * hw + p0) * C);
@@ -936,7 +941,7 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 1 < nk) stage(kc + 1, (kc + 1) & 1);
+        if ((!(FRESCO_GRAM_ABL & 1) || kc == 0) && kc + 1 < nk) stage(kc + 1, (kc + 1) & 1);
         const char* L = &lds2[kc & 1][0];
 #pragma unroll
         for (int ks = 0; ks < GK16 / 16; ++ks) {
@@ -987,8 +992,8 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
                 *reinterpret_cast<const uint4*>(tr + rl * TRS + ch * 16);
         }
     };
-    flush(p0, q0);
-    if (mirror) {
+    if (!(FRESCO_GRAM_ABL & 4) || lsum == 12345.f) flush(p0, q0);
+    if (mirror && (!(FRESCO_GRAM_ABL & 4) || lsum == 12345.f)) {
         __syncthreads();
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -1177,8 +1182,14 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z;
-    const int c0 = blockIdx.y * SB_TC, p0 = blockIdx.x * SB_TP;
+    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8), each with its own L2.  The 2 MB V
+    // tile of a (plane, channel block) is shared by all its pixel tiles: give every XCD a CONTIGUOUS range of the
+    // (plane, channel block, pixel tile) list, so that the V tile is fetched into one L2 once instead of into all eight.
+    int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
+    const int b = lin / (gridDim.x * gridDim.y);
+    const int c0 = ((lin / gridDim.x) % gridDim.y) * SB_TC, p0 = (lin % gridDim.x) * SB_TP;
     const char* vhb = reinterpret_cast<const char*>(vh + ((int64_t)b * C + c0) * hw);
     const char* vlb = reinterpret_cast<const char*>(vl + ((int64_t)b * C + c0) * hw);
     const char* sbp = reinterpret_cast<const char*>(sgn_in + ((int64_t)b * hw + p0) * hw);
