@@ -895,7 +895,38 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
     if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
     const int b = lin / gridDim.x;
     int ti, tj;
-    tri_tile(lin % gridDim.x, hw / GT, ti, tj);
+    {
+        // ... and inside a plane the upper triangle is walked in 8 x 8 super-tiles (when the tile count allows): the ~64
+        // tiles an XCD has in flight then share 8 + 8 operand row blocks (5 MB) instead of streaming ~32 of them
+        const int nt = hw / GT;
+        int idx = lin % gridDim.x;
+        if (nt % 8 == 0) {
+            const int ns = nt / 8;
+            int si = 0, sj = 0;
+            for (;; ++si) {  // super-row si: its diagonal block (36 tiles), then ns - 1 - si full blocks (64 tiles)
+                const int row_tiles = 36 + 64 * (ns - 1 - si);
+                if (idx < row_tiles) break;
+                idx -= row_tiles;
+            }
+            if (idx < 36) {
+                sj = si;
+                int r = 0;
+                while (idx >= 8 - r) {
+                    idx -= 8 - r;
+                    ++r;
+                }
+                ti = si * 8 + r;
+                tj = sj * 8 + r + idx;
+            } else {
+                idx -= 36;
+                sj = si + 1 + idx / 64;
+                ti = si * 8 + (idx % 64) / 8;
+                tj = sj * 8 + idx % 8;
+            }
+        } else {
+            tri_tile(idx, nt, ti, tj);
+        }
+    }
     const int p0 = ti * GT, q0 = tj * GT;
     const char* srcA_h = reinterpret_cast<const char*>(vph + ((int64_t)b * hw + p0) * C);
     const char* srcA_l = reinterpret_cast<const char*>(vpl + ((int64_t)b * hw + p0) * C);
