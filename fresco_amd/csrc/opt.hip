@@ -199,16 +199,21 @@ __global__ __launch_bounds__(256) void temporal_sign_kernel(
         const OTaps tf = otaps(ff[p], ff[hw + p], p % w, p / w, h, w);
         const float mb = 1.f - bwd_occ[(int64_t)j * hw + p];
         const float mf = 1.f - fwd_occ[(int64_t)j * hw + p];
+        // the 8 signs of this thread's channel octet are ONE 8-byte word: signs live as [pair][C/8][hw][8] bytes, so a
+        // thread writes (and the gradient code reads, per CSR entry) 8 bytes at once and lanes along p stay coalesced
+        uint64_t w1 = 0, w2 = 0;
         for (int c = c0; c < cend; ++c) {
             const float* c1 = frame_plane(cs, L, ck, sa, c, C, hw);
             const float* c2 = frame_plane(cs, L, ck, sb, c, C, hw);
             const float r1 = (c2[p] - osample(c1, tb)) * mb;
             const float r2 = (c1[p] - osample(c2, tf)) * mf;
-            const int64_t o = ((int64_t)b * C + c) * hw + p;
-            sgn1[o] = (int8_t)sgn(r1);
-            sgn2[o] = (int8_t)sgn(r2);
+            w1 |= (uint64_t)(uint8_t)(int8_t)sgn(r1) << (8 * (c - c0));
+            w2 |= (uint64_t)(uint8_t)(int8_t)sgn(r2) << (8 * (c - c0));
             lsum += fabsf(r1) + fabsf(r2);
         }
+        const int64_t o = ((int64_t)b * gridDim.y + blockIdx.y) * hw + p;
+        reinterpret_cast<uint64_t*>(sgn1)[o] = w1;
+        reinterpret_cast<uint64_t*>(sgn2)[o] = w2;
     }
     if (loss) {
         __shared__ float red[4];
@@ -273,22 +278,40 @@ struct TGradPixel {
             vF[e] = okF ? wF[bF + e] : 0.f;
         }
     }
-    // gradient of channel c at the pixel
-    __device__ __forceinline__ float value(const TGradArgs& t, int c, int p, int C, int hw) const {
-        const int8_t* s1f = t.sgn1 + ((int64_t)bf * C + c) * hw;
-        const int8_t* s2f = t.sgn2 + ((int64_t)bf * C + c) * hw;
-        const int8_t* s1p = t.sgn1 + ((int64_t)bp * C + c) * hw;
-        const int8_t* s2p = t.sgn2 + ((int64_t)bp * C + c) * hw;
-        const float g = a2 * (float)s2f[p] + a1 * (float)s1p[p];
-        float adj = 0.f, adj2 = 0.f;
+    // gradients of the 8 channels of octet c8 at the pixel (signs: [pair][C/8][hw][8] bytes, one 8-byte word per load)
+    __device__ __forceinline__ void values(const TGradArgs& t, int c8, int p, int C8, int hw, float (&out)[8]) const {
+        const uint64_t* s1f = reinterpret_cast<const uint64_t*>(t.sgn1) + ((int64_t)bf * C8 + c8) * hw;
+        const uint64_t* s2f = reinterpret_cast<const uint64_t*>(t.sgn2) + ((int64_t)bf * C8 + c8) * hw;
+        const uint64_t* s1p = reinterpret_cast<const uint64_t*>(t.sgn1) + ((int64_t)bp * C8 + c8) * hw;
+        const uint64_t* s2p = reinterpret_cast<const uint64_t*>(t.sgn2) + ((int64_t)bp * C8 + c8) * hw;
+        auto sg = [](uint64_t w, int k) { return (float)(int8_t)(uint8_t)(w >> (8 * k)); };
+        const uint64_t d2 = s2f[p], d1 = s1p[p];
+        uint64_t gB[TG_MAXE], gF[TG_MAXE];
 #pragma unroll
         for (int e = 0; e < TG_MAXE; ++e) {
-            adj = fmaf(vB[e], (float)s1f[iB[e]], adj);
-            adj2 = fmaf(vF[e], (float)s2p[iF[e]], adj2);
+            gB[e] = s1f[iB[e]];
+            gF[e] = s2p[iF[e]];
         }
-        for (int e = bB + TG_MAXE; e < eB; ++e) adj = fmaf(wB[e], (float)s1f[sB[e]], adj);
-        for (int e = bF + TG_MAXE; e < eF; ++e) adj2 = fmaf(wF[e], (float)s2p[sF[e]], adj2);
-        return g - adj - adj2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float adj = 0.f, adj2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < TG_MAXE; ++e) {
+                adj = fmaf(vB[e], sg(gB[e], k), adj);
+                adj2 = fmaf(vF[e], sg(gF[e], k), adj2);
+            }
+            out[k] = a2 * sg(d2, k) + a1 * sg(d1, k) - adj - adj2;
+        }
+        for (int e = bB + TG_MAXE; e < eB; ++e) {  // rows longer than the register cache (rare)
+            const uint64_t g = s1f[sB[e]];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out[k] -= wB[e] * sg(g, k);
+        }
+        for (int e = bF + TG_MAXE; e < eF; ++e) {
+            const uint64_t g = s2p[sF[e]];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out[k] -= wF[e] * sg(g, k);
+        }
     }
 };
 
@@ -1357,11 +1380,15 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
         inv_n = 1.f / n;
     }
     // the temporal gradient is formed here from the residual signs (no gradient tensor is written and re-read)
-    TGradPixel tp;
-    if (has_t) tp.init(tg, b, p, hw);
+    float tgv[ECPT] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (has_t) {
+        TGradPixel tp;
+        tp.init(tg, b, p, hw);
+        tp.values(tg, blockIdx.y, p, gridDim.y, hw, tgv);
+    }
     for (int c = c0; c < cend; ++c) {
         const int64_t o = ((int64_t)b * C + c) * hw + p;
-        float g = has_t ? tp.value(tg, c, p, C, hw) : 0.f;
+        float g = tgv[c - c0];
         const float x = cs[o];
         if (has_s) g += (dvt[o] - (vt ? vt[o] : x / n) * dot) * inv_n;  // vt == nullptr: V = X/|X| rebuilt (same quotient)
         if (mode == 1) {
@@ -1399,8 +1426,9 @@ static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int 
     tmp.m = carve<float>(p, E);
     tmp.v = carve<float>(p, E);
     tmp.grad = nullptr;  // (the temporal gradient is formed inside the Adam kernel: no gradient tensor)
-    tmp.sgn1 = has_t ? carve<int8_t>(p, EP) : nullptr;
-    tmp.sgn2 = has_t ? carve<int8_t>(p, EP) : nullptr;
+    const size_t EP8 = (size_t)chunk * NP * ((C + 7) / 8) * 8 * hw;  // signs: [pair][C/8][hw][8] bytes
+    tmp.sgn1 = has_t ? carve<int8_t>(p, EP8) : nullptr;
+    tmp.sgn2 = has_t ? carve<int8_t>(p, EP8) : nullptr;
     tmp.rowptr = has_t ? carve<int>(p, (size_t)2 * NP * (hw + 1)) : nullptr;
     tmp.cursor = has_t ? carve<int>(p, (size_t)2 * NP * hw) : nullptr;
     tmp.src = has_t ? carve<int>(p, (size_t)2 * NP * 4 * hw) : nullptr;
