@@ -101,6 +101,28 @@ def test_closure_odd_plane_sizes(h, w):
     _grad_agree(gr, go, float(go.abs().max()), max_bad=int(2e-4 * go.numel()) + 4)
 
 
+@pytest.mark.parametrize("C,h,w", [(128, 16, 16), (128, 16, 32), (96, 16, 24)])
+def test_closure_whole_tile_planes(C, h, w):
+    """planes made of whole 128-pixel Gram tiles with C % 32 == 0: the 8-wave DMA-staged Gram kernel on 2 x 2 / 4 x 4 /
+    3 x 3 tile triangles (the super-tile walk needs a multiple of 8 tiles per side: covered at the shipping shapes), the
+    128 x 256 S V kernel when C % 128 == 0 and hw % 256 == 0 (first two cases), the 128 x 128 one otherwise"""
+    import fresco_amd.ops as ops
+    from fresco_amd.warp import _prep_flow_occ
+    g = synth.gen(C + h * 100 + w)
+    N = 3
+    x = torch.randn(2 * N, C, h, w, generator=g)
+    bwd = torch.tensor([1.5, -1.0]).view(1, 2, 1, 1) + 0.3 * torch.randn(N, 2, 4 * h, 4 * w, generator=g)
+    flows = [-bwd, bwd]
+    occs = [(torch.rand(N, 4 * h, 4 * w, generator=g) < 0.1).float() for _ in range(2)]
+    target = O.gram_target(torch.randn(2 * N, C, h, w, generator=g))
+    prep = _prep_flow_occ(h, [f.to(DEV) for f in flows], [o.to(DEV) for o in occs], with_dilate=False)
+    loss, gr = ops.opt_loss_grad(x.to(DEV), prep, target.to(DEV), 100.0, 2)
+    prep64 = O.opt_prepare(h, flows, occs, 2, torch.float64)
+    lo, go = O.opt_loss_and_grad(x.double(), prep64, target.double(), 100.0)
+    assert abs(float(loss.sum()) - float(lo)) < 1e-5 * float(lo)
+    _grad_agree(gr, go, float(go.abs().max()), max_bad=int(2e-4 * go.numel()) + 4)
+
+
 def test_single_adam_step_and_kat6(kat6, golden):
     import fresco_amd
     import fresco_amd.ops as ops
