@@ -742,6 +742,9 @@ __global__ __launch_bounds__(256) void sv_kernel(const float* __restrict__ vt,
 // waits in registers), rows of 64 B + 16 B pad (conflict-free ds_read_b128).
 // Upper-triangular tiles + mirrored sign tile (gram_epilogue<0>).  Requires C % 8 == 0.
 // ------------------------------------------------------------------------------------------------
+// (the condition under which the 8-wave Gram kernel runs and the pixel-major operand copies are stored pre-tiled)
+__host__ __device__ __forceinline__ bool gram_tiled_layout(int hw, int C) { return hw % 128 == 0 && C % 32 == 0 && C >= 64; }
+
 // Normalisation for the fp16-split GEMMs, one pass over x (same arithmetic and summation order as normalize_kernel): the 64 x 64
 // tile of normalised values is written channel-major (vt fp32, vh / vl halfs: operands of S V) straight from the
 // registers and pixel-major (vph / vpl: operands of the Gram product) through the LDS transpose.
@@ -754,6 +757,11 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
     __shared__ float tile[64][65];
     __shared__ float nn[64];
     const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    // pixel-major copies: plain (B, hw, C), or -- when the plane is whole 128-pixel tiles and C % 32 == 0, i.e. when
+    // gram16w_kernel reads them -- pre-tiled [plane][pixel tile][channel chunk of 32][128 pixels][32 channels]: the 8 KB
+    // block a DMA'd K chunk of an operand row block needs is then contiguous (contiguous LDS-DMA sources cost far fewer
+    // L2 requests than 64-byte row segments a row apart)
+    const bool tiled = gram_tiled_layout(hw, C);
     if (threadIdx.x < 64) {
         const int p = p0 + threadIdx.x;
         float ss = 0.f;
@@ -783,7 +791,9 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
         if (p0 + p < hw && c0 + c < C) {
             const float val = tile[c][p];
             const half_t hi16 = (half_t)val;
-            const int64_t o = ((int64_t)b * hw + p0 + p) * C + c0 + c;
+            const int pp = p0 + p, cc = c0 + c;
+            const int64_t o = tiled ? ((((int64_t)b * (hw / GT) + pp / GT) * (C / 32) + cc / 32) * GT + pp % GT) * 32 + cc % 32
+                                    : ((int64_t)b * hw + pp) * C + cc;
             vph[o] = hi16;
             vpl[o] = (half_t)(val - (float)hi16);
         }
@@ -951,9 +961,11 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
         }
     }
     const int p0 = ti * GT, q0 = tj * GT;
-    const char* srcA_h = reinterpret_cast<const char*>(vph + ((int64_t)b * hw + p0) * C);
-    const char* srcA_l = reinterpret_cast<const char*>(vpl + ((int64_t)b * hw + p0) * C);
-    const int64_t dB = ((int64_t)q0 - p0) * C * 2;  // B rows relative to the A rows
+    // operands are pre-tiled (normalize_split_kernel): [plane][pixel tile][chunk][128][32] halfs, 8 KB per (tile, chunk)
+    const int nkc = C / GK16;
+    const char* srcA_h = reinterpret_cast<const char*>(vph + (((int64_t)b * (hw / GT) + ti) * nkc) * GT * GK16);
+    const char* srcA_l = reinterpret_cast<const char*>(vpl + (((int64_t)b * (hw / GT) + ti) * nkc) * GT * GK16);
+    const int64_t dB = ((int64_t)tj - ti) * nkc * GT * GK16 * 2;  // B row block relative to the A row block
     const uint32_t lds0 =
         __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)&lds2[0][0]);
 
@@ -971,14 +983,14 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
     for (int i = 0; i < NPW; ++i) {
         const int o = ((wave + 8 * i) % NPA) * 1024 + lane * 16;
         const int row = o / GROW, cc = (o % GROW) / 16;
-        doff[i] = (uint32_t)(row * C * 2 + (cc < GK16 / 8 ? cc * 16 : 0));
+        doff[i] = (uint32_t)(row * GK16 * 2 + (cc < GK16 / 8 ? cc * 16 : 0));
     }
     auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = wave + 8 * i;  // 0 .. 39
             const int arr = pc / NPA;     // Ah, Al, Bh, Bl
-            const char* src = ((arr & 1) ? srcA_l : srcA_h) + (int64_t)(arr >> 1) * dB + (int64_t)kc * GK16 * 2;
+            const char* src = ((arr & 1) ? srcA_l : srcA_h) + (int64_t)(arr >> 1) * dB + (int64_t)kc * GT * GK16 * 2;
             const uint32_t m0v = lds0 + (uint32_t)(slot * SLOT + pc * 1024);
             asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(doff[i]), "s"(src), "s"(m0v)
                          : "memory");
@@ -1492,7 +1504,7 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         {
             ProfScope ps(FRESCO_PROF_OPT_GRAM, B, C, hw, 0, st);
             if (f16_sv && C % 8 == 0) {
-                if (hw % GT == 0 && C % 32 == 0 && C >= 64)  // every whole-tile plane (measured 16^2 .. 64^2: 46 / 139 / 730 -> 37 / 109 / 604 us)
+                if (gram_tiled_layout(hw, C))  // every whole-tile plane (measured 16^2 .. 64^2: 46 / 139 / 730 -> 37 / 109 / 604 us)
                     hipLaunchKernelGGL(gram16w_kernel, dim3(nt * (nt + 1) / 2, 1, B), dim3(512), 0, st, w.vph, w.vpl,
                                        target, w.ssign, loss ? loss + 1 : nullptr, C, hw);
                 else if (hw <= 1024)
