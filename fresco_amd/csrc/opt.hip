@@ -744,6 +744,9 @@ __global__ __launch_bounds__(256) void sv_kernel(const float* __restrict__ vt,
 // ------------------------------------------------------------------------------------------------
 // (the condition under which the 8-wave Gram kernel runs and the pixel-major operand copies are stored pre-tiled)
 __host__ __device__ __forceinline__ bool gram_tiled_layout(int hw, int C) { return hw % 128 == 0 && C % 32 == 0 && C >= 64; }
+// (the condition under which sv16b_kernel runs: its operands -- vh / vl and the sign bytes -- are then stored pre-tiled too:
+// V as [plane][channel tile of 128][pixel chunk of 32][128][32] halfs, S as [plane][pixel tile of 256][chunk of 32][256][32] bytes)
+__host__ __device__ __forceinline__ bool sv_tiled_layout(int hw, int C) { return hw % 256 == 0 && C % 128 == 0; }
 
 // Normalisation for the fp16-split GEMMs, one pass over x (same arithmetic and summation order as normalize_kernel): the 64 x 64
 // tile of normalised values is written channel-major (vt fp32, vh / vl halfs: operands of S V) straight from the
@@ -762,6 +765,7 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
     // block a DMA'd K chunk of an operand row block needs is then contiguous (contiguous LDS-DMA sources cost far fewer
     // L2 requests than 64-byte row segments a row apart)
     const bool tiled = gram_tiled_layout(hw, C);
+    const bool sv_tiled = sv_tiled_layout(hw, C);
     if (threadIdx.x < 64) {
         const int p = p0 + threadIdx.x;
         float ss = 0.f;
@@ -780,8 +784,10 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
             val = cs[o] / nn[p];
             if (vt) vt[o] = val;
             const half_t hi16 = (half_t)val;
-            vh[o] = hi16;
-            vl[o] = (half_t)(val - (float)hi16);
+            const int cc = c0 + c, pp = p0 + p;
+            const int64_t ov = sv_tiled ? ((((int64_t)b * (C / 128) + cc / 128) * (hw / 32) + pp / 32) * 128 + cc % 128) * 32 + pp % 32 : o;
+            vh[ov] = hi16;
+            vl[ov] = (half_t)(val - (float)hi16);
         }
         tile[c][p] = val;
     }
@@ -1036,6 +1042,7 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
     // ---- epilogue: sign(G - T) bytes, tile and (off the diagonal) mirrored tile as 16-byte rows through LDS ----
     int8_t* tr = reinterpret_cast<int8_t*>(&lds2[0][0]);
     const bool mirror = ti != tj;
+    const bool s_tiled = sv_tiled_layout(hw, C);  // the S V kernel that reads the signs wants them pre-tiled
     float lsum = 0.f;
     int8_t sg[2][16];
     const int cl = wn * 32 + l31;
@@ -1054,8 +1061,10 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
         __syncthreads();
         for (int i = tid; i < GT * (GT / 16); i += 512) {
             const int rl = i / (GT / 16), ch = i % (GT / 16);
-            *reinterpret_cast<uint4*>(sgn_out + ((int64_t)b * hw + r0 + rl) * hw + c0 + ch * 16) =
-                *reinterpret_cast<const uint4*>(tr + rl * TRS + ch * 16);
+            const int gp = r0 + rl, gq = c0 + ch * 16;
+            const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
+                                       : ((int64_t)b * hw + gp) * hw + gq;
+            *reinterpret_cast<uint4*>(sgn_out + so) = *reinterpret_cast<const uint4*>(tr + rl * TRS + ch * 16);
         }
     };
     if (!(FRESCO_GRAM_ABL & 4) || lsum == 12345.f) flush(p0, q0);
@@ -1258,9 +1267,11 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_
     // (channel block fastest: neighbours in the range share their S rows, 1 MB per pixel tile; measured against pixel
     // tile fastest -- shared V tile, 2 MB --: 536 / 98 us instead of 547 / 107 at 64^2 / 32^2)
     const int c0 = (lin % gridDim.y) * SB_TC, p0 = ((lin / gridDim.y) % gridDim.x) * SB_TP;
-    const char* vhb = reinterpret_cast<const char*>(vh + ((int64_t)b * C + c0) * hw);
-    const char* vlb = reinterpret_cast<const char*>(vl + ((int64_t)b * C + c0) * hw);
-    const char* sbp = reinterpret_cast<const char*>(sgn_in + ((int64_t)b * hw + p0) * hw);
+    // operands are pre-tiled (sv_tiled_layout): per (channel tile, pixel chunk) 128 x 32 halfs, per (pixel tile, chunk) 256 x 32 bytes
+    static_assert(SB_TC == 128 && SB_K == 32 && TP == 256, "tiled operand layout");
+    const char* vhb = reinterpret_cast<const char*>(vh + ((int64_t)b * (C / 128) + c0 / 128) * hw * 128);
+    const char* vlb = reinterpret_cast<const char*>(vl + ((int64_t)b * (C / 128) + c0 / 128) * hw * 128);
+    const char* sbp = reinterpret_cast<const char*>(sgn_in + ((int64_t)b * (hw / 256) + p0 / 256) * hw * 256);
     const uint32_t lds0 =
         __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sb_smem);
 
@@ -1272,21 +1283,21 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_
         if (pc < 2 * (SB_VARR / 1024)) {  // a V array: rows of 5 chunks (4 data + pad)
             const int o = (pc % (SB_VARR / 1024)) * 1024 + lane * 16;
             const int row = o / SB_VROW, cc = (o % SB_VROW) / 16;
-            doff[i] = (uint32_t)(row * hw * 2 + (cc < 4 ? cc * 16 : 0));
+            doff[i] = (uint32_t)(row * SB_K * 2 + (cc < 4 ? cc * 16 : 0));
         } else {  // S: rows of 3 chunks (2 data + pad)
             const int o = (pc - 2 * (SB_VARR / 1024)) * 1024 + lane * 16;
             const int row = o / SB_SROW, cc = (o % SB_SROW) / 16;
-            doff[i] = (uint32_t)(row * hw + (cc < 2 ? cc * 16 : 0));
+            doff[i] = (uint32_t)(row * SB_K + (cc < 2 ? cc * 16 : 0));
         }
     }
     auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
-        const int k0 = kc * SB_K;
 #pragma unroll
         for (int i = 0; i < SB_NPW; ++i) {
             const int pc = wave + 8 * i;
             if (pc < SB_NP) {
                 const int arr = pc / (SB_VARR / 1024);  // 0: Vh, 1: Vl, >= 2: S
-                const char* src = arr == 0 ? vhb + (int64_t)k0 * 2 : (arr == 1 ? vlb + (int64_t)k0 * 2 : sbp + k0);
+                const char* src = arr == 0 ? vhb + (int64_t)kc * (128 * SB_K * 2)
+                                           : (arr == 1 ? vlb + (int64_t)kc * (128 * SB_K * 2) : sbp + (int64_t)kc * (256 * SB_K));
                 const uint32_t m0v = lds0 + (uint32_t)(slot * SB_SLOT + pc * 1024);
                 asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(doff[i]), "s"(src), "s"(m0v)
                              : "memory");
@@ -1520,7 +1531,7 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         const float coef = intra_weight / ((float)Bg * (float)hw * (float)hw);
         {
             ProfScope ps(FRESCO_PROF_OPT_SV, B, C, hw, 0, st);
-            if (f16_sv && hw % 256 == 0 && C % SB_TC == 0) {
+            if (f16_sv && sv_tiled_layout(hw, C) && gram_tiled_layout(hw, C)) {
                 // measured at (640, 64^2): 128 x 512 tiles / 3-slot ring / one workgroup per CU 617-629 us;
                 // 128 x 256 / 3 slots 619; 128 x 256 / 2 slots / two workgroups per CU (108 registers) 532
                 constexpr int lds = SB_NSLOT * SbCfg<256>::SLOT;
