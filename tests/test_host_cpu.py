@@ -198,3 +198,67 @@ def test_standin_unet_has_the_sd15_shapes():
         out = unet(x, 900, ctx, return_dict=False)
     assert tuple(out[0].shape) == (2, 4, 8, 8)
     assert [tuple(t.shape[1:]) for t in out[1:]] == [(1280, 1, 1), (1280, 2, 2), (1280, 4, 4), (640, 8, 8)]
+
+
+def test_processor_projects_only_the_selected_keys_in_cross_frame_only_mode(monkeypatch):
+    """Host plumbing of FRESCOAttnProcessor2_0 (no GPU: the operators are recorders): with the temporal pass off, K and V
+    are projected for the rows the cross-frame pass gathers only -- in the order it enumerates them (reference
+    src/diffusion_hacked.py:225-247) -- and the kernel is addressed without a row table; with the temporal pass on, all
+    rows are projected and the row table is passed."""
+    import fresco_amd
+    from fresco_amd import ops
+
+    N, chunk, HW, C, heads = 3, 2, 8, 16, 2
+    attn = torch.nn.Module()
+    for n in ("to_q", "to_k", "to_v"):
+        setattr(attn, n, torch.nn.Linear(C, C, bias=False))
+    attn.to_out = torch.nn.ModuleList([torch.nn.Linear(C, C), torch.nn.Identity()])
+    attn.heads, attn.spatial_norm, attn.group_norm, attn.norm_cross = heads, None, None, False
+    attn.residual_connection, attn.rescale_output_factor = False, 1.0
+    calls = []
+
+    def rec_attention(q, k, v, h, scale, **kw):
+        calls.append(("attn", tuple(q.shape), tuple(k.shape), tuple(v.shape),
+                      {a: (b.clone() if torch.is_tensor(b) else b) for a, b in kw.items() if a != "workspace"}))
+        return torch.zeros_like(q)
+
+    def rec_temporal(q, k, v, fm, tm, h, scale, ch):
+        calls.append(("temporal", tuple(k.shape)))
+        return torch.zeros_like(q)
+
+    monkeypatch.setattr(ops, "attention", rec_attention)
+    monkeypatch.setattr(ops, "temporal_attention", rec_temporal)
+    ctrl = fresco_amd.AttentionControl()
+    proc = fresco_amd.FRESCOAttnProcessor2_0(chunk, ctrl)
+    x = torch.randn(chunk * N, HW, C)
+    mask = torch.zeros(N, HW, dtype=torch.bool)
+    mask[0] = True
+    mask[1, [2, 5]] = True
+    mask[2, [7]] = True
+    rows = mask.reshape(-1).nonzero().squeeze(1)
+    ctrl.enable_cfattn([mask])
+    with torch.no_grad():
+        proc(attn, x)
+    (tag, qs, ks, vs, kw), = calls
+    M = int(mask.sum())
+    assert tag == "attn" and qs == (chunk * N, HW, C) and ks == vs == (chunk, M, C)
+    assert kw["n_groups"] == chunk and kw["M"] == M and kw["group_rows"] == M and kw.get("kv_rows") is None
+    # same rows, same order, same arithmetic as projecting everything and gathering afterwards
+    k_all = attn.to_k(x).view(chunk, N * HW, C)[:, rows]
+    calls.clear()
+    real_k = []
+    monkeypatch.setattr(ops, "attention", lambda q, k, v, h, s, **kw: (real_k.append(k), torch.zeros_like(q))[1])
+    with torch.no_grad():
+        proc(attn, x)
+    assert torch.allclose(real_k[0].float(), k_all.detach().half().float(), atol=2e-3)
+    # temporal pass on: every row is projected, the cross-frame pass gets the row table
+    monkeypatch.setattr(ops, "attention", rec_attention)
+    ctrl.enable_interattn(dict(fwd_mappings=[torch.arange(HW).repeat(N, 1).unsqueeze(1)],
+                               bwd_mappings=[torch.arange(HW).repeat(N, 1).unsqueeze(1)],
+                               interattn_masks=[torch.ones(HW, 1, N, N, dtype=torch.bool)]))
+    calls.clear()
+    with torch.no_grad():
+        proc(attn, x)
+    assert [c[0] for c in calls] == ["attn", "temporal"]
+    assert calls[0][2] == (chunk * N, HW, C) and torch.equal(calls[0][4]["kv_rows"].long(), rows)
+    assert calls[1][1] == (chunk * N, HW, C)
