@@ -47,6 +47,8 @@ SIGNATURES = {
     "fresco_dilate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "fresco_linear": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i,
                            _vp]),
+    "fresco_linear_rows": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i,
+                                _i, _vp]),
     "fresco_attn_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "fresco_flow_occlusion": (_i, [_vp] * 5 + [_i, _i, _i, _i, _f, _f, _f, _vp]),
     "fresco_warp_fuse_chain": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i, _vp]),

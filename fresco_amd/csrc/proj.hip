@@ -62,8 +62,8 @@ __device__ __forceinline__ void proj_wait_barrier() {
 
 template <int K, int NWV>
 __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
-    const half_t* __restrict__ x, int64_t x_ld, const half_t* __restrict__ W0, const half_t* __restrict__ W1,
-    const half_t* __restrict__ W2, const half_t* __restrict__ b0, const half_t* __restrict__ b1,
+    const half_t* __restrict__ x, int64_t x_ld, const int32_t* __restrict__ x_rows, const half_t* __restrict__ W0,
+    const half_t* __restrict__ W1, const half_t* __restrict__ W2, const half_t* __restrict__ b0, const half_t* __restrict__ b1,
     const half_t* __restrict__ b2, half_t* __restrict__ out0, half_t* __restrict__ out1, half_t* __restrict__ out2,
     int64_t ld0, int64_t ld1, int64_t ld2, int M, int N, int nF, int tiles_per_split) {
     using Cfg = ProjCfg<K, NWV>;
@@ -82,7 +82,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
     // every 32.
     half8_t xf[Cfg::NXF];
     {
-        const half_t* xp = x + (int64_t)(row < M ? row : M - 1) * x_ld + hi * (Cfg::KC / 2);
+        // (x_rows: problem row m reads input row x_rows[m] -- the gathered form, e.g. K / V of the selected tokens only)
+        const int rr = row < M ? row : M - 1;
+        const half_t* xp = x + (int64_t)(x_rows ? x_rows[rr] : rr) * x_ld + hi * (Cfg::KC / 2);
 #pragma unroll
         for (int kc = 0; kc < Cfg::NKC; ++kc)
 #pragma unroll
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
 }
 
 template <int K, int NWV>
-static int launch_linear(const half_t* x, int64_t x_ld, const half_t* const* W, const half_t* const* bias,
+static int launch_linear(const half_t* x, int64_t x_ld, const int32_t* x_rows, const half_t* const* W, const half_t* const* bias,
                          half_t* out0, half_t* out1, half_t* out2, int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M,
                          int N, hipStream_t st) {
     using Cfg = ProjCfg<K, NWV>;
@@ -251,7 +253,7 @@ static int launch_linear(const half_t* x, int64_t x_ld, const half_t* const* W, 
     const int tiles_per_split = (nF + splits - 1) / splits;
     splits = (nF + tiles_per_split - 1) / tiles_per_split;
     ProfScope ps(FRESCO_PROF_LINEAR, M, N, K, nw, st);
-    hipLaunchKernelGGL((linear_kernel<K, NWV>), dim3(row_blocks, splits), dim3(NWV * 64), lds_bytes, st, x, x_ld, W[0], W[1],
+    hipLaunchKernelGGL((linear_kernel<K, NWV>), dim3(row_blocks, splits), dim3(NWV * 64), lds_bytes, st, x, x_ld, x_rows, W[0], W[1],
                        W[2], bias[0], bias[1], bias[2], out0, out1, out2, ld0, ld1, ld2, M, N, nF, tiles_per_split);
     return check_launch();
 }
@@ -260,9 +262,9 @@ static int launch_linear(const half_t* x, int64_t x_ld, const half_t* const* W, 
 
 using namespace fresco;
 
-extern "C" int fresco_linear(const void* x, int64_t x_ld, const void* W0, const void* W1, const void* W2,
-                             const void* b0, const void* b1, const void* b2, void* out0, void* out1, void* out2,
-                             int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N, int K, void* stream) {
+static int linear_dispatch(const void* x, int64_t x_ld, const int32_t* x_rows, const void* W0, const void* W1,
+                           const void* W2, const void* b0, const void* b1, const void* b2, void* out0, void* out1,
+                           void* out2, int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N, int K, void* stream) {
     if (!x || !W0 || !out0 || nw < 1 || nw > 3 || M <= 0 || N <= 0 || K <= 0) return FRESCO_EINVAL;
     if ((nw > 1 && (!out1 || !W1)) || (nw > 2 && (!out2 || !W2))) return FRESCO_EINVAL;
     if (x_ld < K || x_ld % 8 != 0) return FRESCO_EINVAL;
@@ -280,6 +282,21 @@ extern "C" int fresco_linear(const void* x, int64_t x_ld, const void* W0, const 
 #ifndef FRESCO_PROJ_NWV
 #define FRESCO_PROJ_NWV 8
 #endif
-    if (K == 320) return launch_linear<320, FRESCO_PROJ_NWV>(xh, x_ld, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
-    return launch_linear<640, FRESCO_PROJ_NWV>(xh, x_ld, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
+    if (K == 320)
+        return launch_linear<320, FRESCO_PROJ_NWV>(xh, x_ld, x_rows, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
+    return launch_linear<640, FRESCO_PROJ_NWV>(xh, x_ld, x_rows, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
+}
+
+extern "C" int fresco_linear(const void* x, int64_t x_ld, const void* W0, const void* W1, const void* W2,
+                             const void* b0, const void* b1, const void* b2, void* out0, void* out1, void* out2,
+                             int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N, int K, void* stream) {
+    return linear_dispatch(x, x_ld, nullptr, W0, W1, W2, b0, b1, b2, out0, out1, out2, ld0, ld1, ld2, nw, M, N, K, stream);
+}
+
+extern "C" int fresco_linear_rows(const void* x, int64_t x_ld, const int32_t* x_rows, const void* W0, const void* W1,
+                                  const void* W2, const void* b0, const void* b1, const void* b2, void* out0,
+                                  void* out1, void* out2, int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N,
+                                  int K, void* stream) {
+    if (!x_rows) return FRESCO_EINVAL;
+    return linear_dispatch(x, x_ld, x_rows, W0, W1, W2, b0, b1, b2, out0, out1, out2, ld0, ld1, ld2, nw, M, N, K, stream);
 }

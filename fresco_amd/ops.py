@@ -105,11 +105,14 @@ def linear_supported(K, N, dtype):
     return dtype == torch.float16 and K in (320, 640) and N % 64 == 0
 
 
-def linear(x, weights, biases=None, outs=None):
+def linear(x, weights, biases=None, outs=None, x_rows=None, x_rows_trusted=False):
     """out_j = x W_j^T (+ b_j) for the 1..3 weight matrices in `weights` (each (N, K) fp16, read where it lives --
     nothing is stacked or cached), x (..., K) fp16 read once; `biases`: None or a list of (N,) fp16 / None.
     Returns len(weights) tensors shaped x.shape[:-1] + (N,); `outs` may supply them (dense in the last dim,
-    uniformly strided rows -- e.g. the two halves of a fused K|V buffer)."""
+    uniformly strided rows -- e.g. the two halves of a fused K|V buffer).
+    x_rows (int32, (M',)): gathered form -- output row m is the projection of x's flat row x_rows[m]; the outputs are
+    (M', N).  The table is bounds-checked once (a host synchronisation; cached with the tensor) unless the caller vouches
+    for it (`x_rows_trusted`: tables derived from a mask's non-zero positions)."""
     if torch.is_tensor(weights):
         weights = [weights]
     weights = list(weights)
@@ -130,8 +133,22 @@ def linear(x, weights, biases=None, outs=None):
         if b is not None and (b.dtype != torch.float16 or tuple(b.shape) != (N,) or not b.is_contiguous()):
             raise ValueError("linear: a bias must be a contiguous (N,) fp16 tensor")
     x2, x_ld, M = _rows(x)
+    if x_rows is not None:
+        _need_gpu(x_rows)
+        if x_rows.dtype != torch.int32 or x_rows.dim() != 1 or not x_rows.is_contiguous():
+            raise TypeError("linear: x_rows must be a contiguous 1-D int32 tensor")
+        n_x = M
+
+        def run(x_rows=x_rows, n_x=n_x):
+            lo, hi = int(x_rows.min()), int(x_rows.max())
+            if lo < 0 or hi >= n_x:
+                raise ValueError("linear: x_rows address rows %d..%d but x has %d rows" % (lo, hi, n_x))
+        if not x_rows_trusted:
+            _check_once(("xrows", x_rows.data_ptr(), x_rows.numel(), x_rows._version, n_x), x_rows, run)
+        M = x_rows.numel()
     if outs is None:
-        outs = [torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device) for _ in range(nw)]
+        shape = (M, N) if x_rows is not None else x.shape[:-1] + (N,)
+        outs = [torch.empty(shape, dtype=torch.float16, device=x.device) for _ in range(nw)]
     ptrs, lds = [], []
     for t in outs:
         t2, ld, rows = _rows(t)
@@ -144,8 +161,13 @@ def linear(x, weights, biases=None, outs=None):
     while len(ptrs) < 3:
         ptrs.append(None)
         lds.append(0)
-    rc = _lib.load().fresco_linear(x2.data_ptr(), x_ld, wp[0], wp[1], wp[2], bp[0], bp[1], bp[2], ptrs[0], ptrs[1],
-                                   ptrs[2], lds[0], lds[1], lds[2], nw, M, N, K, _stream())
+    if x_rows is not None:
+        rc = _lib.load().fresco_linear_rows(x2.data_ptr(), x_ld, x_rows.data_ptr(), wp[0], wp[1], wp[2], bp[0], bp[1],
+                                            bp[2], ptrs[0], ptrs[1], ptrs[2], lds[0], lds[1], lds[2], nw, M, N, K,
+                                            _stream())
+    else:
+        rc = _lib.load().fresco_linear(x2.data_ptr(), x_ld, wp[0], wp[1], wp[2], bp[0], bp[1], bp[2], ptrs[0], ptrs[1],
+                                       ptrs[2], lds[0], lds[1], lds[2], nw, M, N, K, _stream())
     _lib.check(rc, "fresco_linear(M=%d,N=%d,K=%d,nw=%d)" % (M, N, K, nw))
     return outs
 

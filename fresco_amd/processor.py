@@ -40,7 +40,7 @@ class FRESCOAttnProcessor2_0:
         self.sparse_kv_projection = True
 
     # ---- fused projections ---------------------------------------------------------------------------
-    def _project(self, attn, x, names, outs=None):
+    def _project(self, attn, x, names, outs=None, x_rows=None):
         """[attn.<name>(x) for name in names] in ONE launch that reads x once (fresco_linear), when every module
         is a plain bias-free fp16 nn.Linear of a supported width; otherwise the modules are called as the
         reference calls them (wrapped / LoRA / quantised layers keep their own forward).  The kernel reads each
@@ -50,7 +50,10 @@ class FRESCOAttnProcessor2_0:
                 and all(_plain_linear(m, False) for m in mods)
                 and len({(m.in_features, m.out_features) for m in mods}) == 1
                 and all(m.weight.is_contiguous() for m in mods)):
-            return ops.linear(x, [m.weight.detach() for m in mods], None, outs)
+            # (x_rows come from _sel_rows: positions of a mask's True entries, in range by construction)
+            return ops.linear(x, [m.weight.detach() for m in mods], None, outs, x_rows=x_rows, x_rows_trusted=True)
+        if x_rows is not None:  # (modules that keep their own forward: gather first)
+            x = x.reshape(-1, x.shape[-1]).index_select(0, x_rows.long())
         res = [m(x) for m in mods]
         if outs is not None:
             for o, r in zip(outs, res):
@@ -77,6 +80,18 @@ class FRESCOAttnProcessor2_0:
             hit = (weakref.ref(mask), rows64.to(torch.int32), rows64)
             self._rows_cache[key] = hit
         return hit[2] if as_long else hit[1]
+
+    def _sel_rows(self, mask, chunk, n_frames, hw, device):
+        """flat int32 row indices (into the (chunk * n_frames * hw, C) hidden states) of the cross-frame keys of every
+        CFG half, in the order the pass enumerates them; cached per mask (None: frame 0 of each half)"""
+        key = ("sel", None if mask is None else (mask.data_ptr(), tuple(mask.shape), mask._version), chunk, n_frames, hw)
+        hit = self._rows_cache.get(key)
+        if hit is None or (mask is not None and hit[0]() is not mask):
+            base = (torch.arange(hw, device=device) if mask is None else self._kv_rows(mask, as_long=True).to(device))
+            rows = torch.cat([base + c * n_frames * hw for c in range(chunk)]).to(torch.int32).contiguous()
+            hit = (weakref.ref(mask) if mask is not None else None, rows)
+            self._rows_cache[key] = hit
+        return hit[1]
 
     def _cf_mask(self, ctrl, hw):
         """the cross-frame key mask of this feature scale (None: every frame attends to frame 0 only)"""
@@ -118,9 +133,10 @@ class FRESCOAttnProcessor2_0:
                 (query,) = self._project(attn, hidden_states, ("to_q",))
                 chunk_, hw_ = self.unet_chunk_size, hidden_states.shape[1]
                 mask = self._cf_mask(ctrl, hw_)
-                xg = hidden_states.reshape(chunk_, -1, hidden_states.shape[-1])
-                x_sel = xg[:, :hw_] if mask is None else xg.index_select(1, self._kv_rows(mask, as_long=True))
-                key, value = self._project(attn, x_sel.contiguous(), ("to_k", "to_v"))
+                nf = hidden_states.shape[0] // chunk_
+                rows_all = self._sel_rows(mask, chunk_, nf, hw_, hidden_states.device)  # flat rows of both CFG halves
+                key, value = self._project(attn, hidden_states, ("to_k", "to_v"), x_rows=rows_all)
+                key, value = key.view(chunk_, -1, key.shape[-1]), value.view(chunk_, -1, value.shape[-1])
             else:
                 query, key, value = self._project(attn, hidden_states, ("to_q", "to_k", "to_v"))
         else:

@@ -110,6 +110,13 @@ int fresco_linear(const void* x, int64_t x_ld, const void* W0, const void* W1, c
                   const void* b1, const void* b2, void* out0, void* out1, void* out2, int64_t ld0, int64_t ld1,
                   int64_t ld2, int nw, int M, int N, int K, void* stream);
 
+/* The same with gathered input rows: problem row m reads x row x_rows[m] (int32, M entries, each inside the x buffer --
+ * the caller's contract).  Used for the K / V projection of the tokens the efficient cross-frame pass selects
+ * (DH:225-247) when nothing else reads K and V: project only what is gathered. */
+int fresco_linear_rows(const void* x, int64_t x_ld, const int32_t* x_rows, const void* W0, const void* W1,
+                       const void* W2, const void* b0, const void* b1, const void* b2, void* out0, void* out1,
+                       void* out2, int64_t ld0, int64_t ld1, int64_t ld2, int nw, int M, int N, int K, void* stream);
+
 
 int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* kv_rows,
                     void* out, void* workspace, size_t workspace_bytes,

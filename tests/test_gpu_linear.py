@@ -130,3 +130,26 @@ def test_processor_fuses_only_plain_linears_and_tracks_weight_updates():
         assert seen == [] and float((y4.float() - y2.float()).abs().max()) < 2e-3
     finally:
         fresco_amd.ops.linear = real
+
+
+def test_linear_gathered_rows():
+    """fresco_linear_rows: output row m = projection of input row x_rows[m] (the K / V projection of the selected
+    cross-frame tokens); out-of-range tables are refused."""
+    import fresco_amd.ops as ops
+    g = torch.Generator().manual_seed(3)
+    Mx, C = 5000, 320
+    x = torch.randn(Mx, C, generator=g).half().to(DEV)
+    Ws = [(torch.randn(C, C, generator=g) / C ** 0.5).half().to(DEV) for _ in range(2)]
+    rows = torch.randperm(Mx, generator=g)[:777].to(torch.int32).to(DEV)
+    k, v = ops.linear(x, Ws, x_rows=rows)
+    assert tuple(k.shape) == (777, C)
+    xs = x.index_select(0, rows.long())
+    for out, W in zip((k, v), Ws):
+        ref = (xs.float() @ W.float().t())
+        assert float((out.float() - ref).abs().max()) < 2e-3 + 2e-3 * float(ref.abs().max())
+    same_k, same_v = ops.linear(xs, Ws)
+    assert torch.equal(k, same_k) and torch.equal(v, same_v)  # bit-identical to gathering first
+    bad = rows.clone()
+    bad[3] = Mx
+    with pytest.raises(ValueError):
+        ops.linear(x, Ws, x_rows=bad)
