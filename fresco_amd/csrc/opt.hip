@@ -19,6 +19,8 @@
 //   gram           128x128 tiles of V V^T on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain);
 //                  epilogue writes sign(G - T) as int8 (or G itself for the Gram target)
 //   sv             dV^T = 2 coef V^T S on the same MFMA (S in {-1,0,1}, exact)
+//   (fp16-split forms, the ones the SD-1.5 shapes run: gram16w / gram16 and sv16b / sv16 further down -- three resp. two
+//   v_mfma_f32_32x32x16_f16 per fp32-accurate product, operands by LDS-DMA from pre-tiled copies, 16 waves per CU)
 //   adam_update    temporal gradient + norm backward + Adam step, fused, fp32 state
 #include "common.h"
 #include <math.h>
