@@ -9,8 +9,10 @@ mode of that denoising step.  Steps cycle through the reference's 15-step schedu
 num_warmup_steps=5; src/pipe_FRESCO.py:166-174): 1 x spatial+cross-frame+temporal, 7 x cross-frame+
 temporal, 7 x cross-frame only.  Inputs are resident in HBM before the timed region.
 
-N > 1 GPUs: the SAME 8-frame batch is sharded by frame (strong scaling); K/V of all frames are
-exchanged with one RCCL all-gather per layer before the cross-frame attention (fresco_amd/dist.py).
+N > 1 GPUs: the SAME 8-frame batch is sharded by frame (strong scaling).  Per layer call the ranks exchange frame 0's
+fused K|V rows (broadcast) and the other frames' selected rows (all-gather) for the cross-frame pass, and the temporal
+pass runs trajectory-sharded between two all-to-alls (fresco_amd/dist.py); `collective_bytes_received_per_rank` in the
+JSON line states the fabric bytes.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, attn_flash_kernel<40> on the
 up_blocks.3 cross-frame pass: algorithmic flop 4*B*HW*M*C per launch / mean HIP-event duration of those
@@ -27,7 +29,10 @@ import os
 import sys
 import time
 
-import torch
+# (multi-process GPU work on these hosts needs dmabuf IPC; set before the HIP runtime starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -280,10 +285,13 @@ def cfg2b_large_mask(layers, N, R, device, lib):
 
 
 def cfg2c_large_logits(layers, N, R, device, lib, rows):
-    """The dominant launch (up_blocks.3 cross-frame pass, the bench's key set) with activations whose logits are too
-    large for the flash kernel's Cauchy-Schwarz fast path: q, k ~ N(0,1) per channel (|logit| up to ~30 in log2 units),
-    so every wave runs the max-search / exact-scale passes.  Reported because the bench's own activations (random
-    projections of N(0,1) hidden states) never leave the fast path; a trained checkpoint's may."""
+    """The dominant launch (up_blocks.3 cross-frame pass, the bench's key set) with activations outside the flash
+    kernel's Cauchy-Schwarz fast regime: q, k ~ N(0,1) per channel (logit bound c|q||k| up to ~19 in log2 units, beyond
+    the 16 up to which the scale is folded into the fp16 Q).  By the kernel's decision rule (restated on the CPU in
+    tools/flash_regime.py) ~55 % of the waves then multiply every score by the scale in fp32 (the exact-scale pass) and
+    ~2 % keep the running-max search after tile 0; the workgroup barrier couples all eight waves to the slowest.
+    Reported because the bench's own activations (random projections of N(0,1) hidden states, bound ~7) never leave the
+    fast regime; a trained checkpoint's may."""
     import fresco_amd.ops as ops
 
     HW = (R // 8) ** 2
@@ -303,7 +311,7 @@ def cfg2c_large_logits(layers, N, R, device, lib, rows):
     t = [ms for tag, d, ms in read_prof(lib, 64) if tag == 1]
     mean_s = sum(t) / len(t) * 1e-3
     flop = 4.0 * 2 * N * HW * M * 320
-    return dict(workload="up_blocks.3 cross-frame pass, M = %d keys, q, k ~ N(0,1): max-search path on every wave" % M,
+    return dict(workload="up_blocks.3 cross-frame pass, M = %d keys, q, k ~ N(0,1): exact-scale pass on ~55 %% of the waves (logit bound above the fold limit)" % M,
                 flash_avg_us=round(mean_s * 1e6, 1), algorithmic_tflops=round(flop / mean_s / 1e12, 1),
                 frac_of_mfma_peak=round(flop / mean_s / PEAK_F16_DENSE, 4))
 

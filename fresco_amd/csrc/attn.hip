@@ -72,13 +72,21 @@ struct AttnCfg {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// (the three thresholds take -D overrides for A/B measurements: make DEFS=-DFOLD_MAX=...; tools/flash_regime.py
+// restates the two per-wave decisions on the CPU)
 // online softmax: skip the O rescale while the tile max grows by less than this (log2 units);
 // P then reaches at most 2^8 = 256, far inside fp16 range, and stays exactly normalised by the row sum
+#ifndef RESCALE_THR
 #define RESCALE_THR 8.0f
+#endif
 // no running max at all when |c q| max|k| - m_run stays below this (P <= 2^14 = 16384 < 65504)
+#ifndef NOMAX_THR
 #define NOMAX_THR 14.0f
+#endif
 // largest |exponent| (log2 units) for which the scale is folded into the fp16 Q
+#ifndef FOLD_MAX
 #define FOLD_MAX 16.0f
+#endif
 
 static inline int ntiles_of(int M) { return (M + 63) / 64; }
 
