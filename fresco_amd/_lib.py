@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfresco_hip.so")
+# FRESCO_HIP_LIB: an alternative build of the same library (A/B measurements of kernel variants, tools/ab_variants.sh);
+# it must exist and export every symbol like the default one -- there is no fallback either way
+LIB_PATH = os.environ.get("FRESCO_HIP_LIB") or os.path.join(_HERE, "lib", "libfresco_hip.so")
 
 OK = 0
 ERRORS = {

@@ -28,6 +28,10 @@
 #ifndef FRESCO_PROJ_ABL
 #define FRESCO_PROJ_ABL 0
 #endif
+// Experiment switch (the product builds 0): read the weight fragments of a step this many MFMAs ahead of their use
+#ifndef FRESCO_PROJ_PF
+#define FRESCO_PROJ_PF 0
+#endif
 
 namespace fresco {
 
@@ -178,6 +182,29 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
             const int slot2 = slot >= 1 ? slot - 1 : Cfg::NBUF - 1;  // the slot of step s-1 takes the slab of step s+AHEAD
             if (!(FRESCO_PROJ_ABL & 2) && s + AHEAD < nsteps) stage(s + AHEAD, slot2);
             const char* wr = smem + slot * Cfg::SLOT + frow * Cfg::ROWB + hi * Cfg::KC;  // hi * (KC/2) halfs
+#if FRESCO_PROJ_PF > 0
+            {   // experiment: weight fragments read FRESCO_PROJ_PF MFMAs ahead (hipcc's own schedule is read -> wait(0) -> MFMA)
+                constexpr int NFR = Cfg::KS * 2, PF = FRESCO_PROJ_PF < NFR ? FRESCO_PROJ_PF : NFR;
+                half8_t fr[NFR];
+#pragma unroll
+                for (int i = 0; i < PF; ++i)
+                    fr[i] = *reinterpret_cast<const half8_t*>(wr + (i & 1) * 32 * Cfg::ROWB + (i >> 1) * 16);
+#pragma unroll
+                for (int i = 0; i < NFR; ++i) {
+                    if (i + PF < NFR)
+                        fr[i + PF] = *reinterpret_cast<const half8_t*>(wr + ((i + PF) & 1) * 32 * Cfg::ROWB + ((i + PF) >> 1) * 16);
+                    const int ks = i >> 1, t = i & 1;
+                    acc[t][ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i], xf[kc * Cfg::KS + ks], acc[t][ks & 1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);  // PF LDS reads up front,
+#pragma unroll
+                for (int i = 0; i < NFR - PF; ++i) {                 // then one MFMA, one LDS read, ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);  // and the last PF MFMAs
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < Cfg::KS; ++ks)
 #pragma unroll
@@ -189,6 +216,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
                     else
                         acc[t][ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[kc * Cfg::KS + ks], acc[t][ks & 1], 0, 0, 0);
                 }
+#endif
             if (FRESCO_PROJ_ABL & 2) {
                 asm volatile("s_barrier" ::: "memory");
             } else if (s + 1 < nsteps) {

@@ -1,0 +1,58 @@
+#!/bin/bash
+# A/B build + timing of kernel variants in ONE GPU-box visit (each variant = one object file rebuilt with extra flags,
+# linked with the default objects into fresco_amd/lib/variants/libfresco_hip_<name>.so, selected via FRESCO_HIP_LIB).
+# usage (repo root, on the box):  bash tools/ab_variants.sh [tag]      -> gpurun_out/ab_<tag>.txt
+# Variants (name | source | flags):
+#   base        the shipped build
+#   noslp       attn.hip  -fno-slp-vectorize        no v_pk_mul_f32 in the exact-scale / rescale passes (packed f32 VALU is
+#                                                   an anti-lever beside MFMAs: MI355X_MICROARCH.md)
+#   foldinf     attn.hip  -DFOLD_MAX=1e9f           scale always folded: separates the exact pass from the data-dependent clock
+#   fold0       attn.hip  -DFOLD_MAX=0.f            scale never folded: the exact pass on the bench's own activations
+#   nomax15     attn.hip  -DNOMAX_THR=15.f
+#   pf4 / pf6   proj.hip  -DFRESCO_PROJ_PF=4 / 6    weight fragments read 4 / 6 MFMAs ahead
+TAG=${1:-r}
+OUT=$PWD/gpurun_out/ab_$TAG.txt
+mkdir -p gpurun_out fresco_amd/lib/variants fresco_amd/csrc/build_var
+make -C fresco_amd/csrc > /dev/null || exit 1
+HIPCC=/opt/rocm/bin/hipcc
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+build() {  # name source per-file-flags variant-flags
+  local name=$1 src=$2 extra=$3 var=$4
+  local obj=fresco_amd/csrc/build_var/${src%.hip}_$name.o
+  $HIPCC $BASE $extra $var -c fresco_amd/csrc/$src -o $obj || return 1
+  local objs=""
+  for o in common attn attn32 proj temporal warp opt mapping; do
+    if [ "$o.hip" = "$src" ]; then objs="$objs $obj"; else objs="$objs fresco_amd/csrc/build/$o.o"; fi
+  done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC $objs -o fresco_amd/lib/variants/libfresco_hip_$name.so
+}
+AT="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans"
+PR="-mllvm -amdgpu-mfma-vgpr-form"
+build noslp attn.hip "$AT" "-fno-slp-vectorize"
+build foldinf attn.hip "$AT" "-DFOLD_MAX=1e9f"
+build fold0 attn.hip "$AT" "-DFOLD_MAX=0.f"
+build nomax15 attn.hip "$AT" "-DNOMAX_THR=15.f"
+build pf4 proj.hip "$PR" "-DFRESCO_PROJ_PF=4"
+build pf6 proj.hip "$PR" "-DFRESCO_PROJ_PF=6"
+run() {  # name command...
+  local name=$1; shift
+  local lib=""
+  [ "$name" != base ] && lib=$PWD/fresco_amd/lib/variants/libfresco_hip_$name.so
+  echo "== $name: $*" >> $OUT
+  FRESCO_HIP_LIB=$lib timeout 300 "$@" >> $OUT 2>&1
+}
+: > $OUT
+for v in base noslp foldinf fold0 nomax15; do
+  run $v python tools/bench_flash.py 20 1.0      # N(0,1) q, k: the cfg2c regime
+  run $v python tools/bench_flash.py 20 0.3      # small logits: the headline regime
+done
+for v in noslp foldinf nomax15; do                # parity of the attention variants (fold0 is exact by construction)
+  run $v python -m pytest tests/test_gpu_attention.py -q -x -p no:cacheprovider
+done
+for v in base pf4 pf6; do
+  run $v python tools/bench_linear.py
+done
+for v in pf4 pf6; do
+  run $v python -m pytest tests/test_gpu_linear.py -q -x -p no:cacheprovider
+done
+grep -E "^==|small-M HW=4096|q,k,v|passed|failed" $OUT
