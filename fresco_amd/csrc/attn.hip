@@ -99,6 +99,10 @@ static inline int ntiles_of(int M) { return (M + 63) / 64; }
 #ifndef FRESCO_PRIO_M
 #define FRESCO_PRIO_M 1
 #endif
+// Experiment switch (the product builds 0): 16-byte epilogue stores via v_permlane32_swap pairs
+#ifndef FRESCO_EPI_WIDE
+#define FRESCO_EPI_WIDE 0
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // pack: grid (nT, H, G), 256 threads
@@ -613,6 +617,38 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         }
         const float inv = 1.f / l_tot;
         const int qr = qrow0 + 32 * j;
+#if FRESCO_EPI_WIDE
+        // experiment: a row's 8-column groups sit split over the two half-waves (lane l31: columns 8k .. 8k+3, lane
+        // l31 + 32: 8k+4 .. 8k+7).  One v_permlane32_swap per dword of a PAIR of groups leaves lanes 0-31 with the 16
+        // contiguous bytes of group k and lanes 32-63 with those of group k+1: one 16-byte store per pair instead of
+        // two 8-byte ones (the store tail of a row-per-lane epilogue is bound by store instructions, not bytes).
+        {
+            half_t* op = out + ((int64_t)b * Lq + (qr < Lq ? qr : 0)) * C + h * D;
+#pragma unroll
+            for (int db = 0; db < Cfg::NDB; ++db)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const int dA = db * 32 + gp * 16;  // first column of the pair
+                    if (dA >= D) continue;
+                    half4_t wa, wb;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        wa[jj] = (half_t)(o[j][db][(2 * gp) * 4 + jj] * inv);
+                        wb[jj] = (half_t)(o[j][db][(2 * gp + 1) * 4 + jj] * inv);
+                    }
+                    if (dA + 8 < D) {
+                        const u32x2 a = __builtin_bit_cast(u32x2, wa), bb = __builtin_bit_cast(u32x2, wb);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(a[0], bb[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(a[1], bb[1], false, false);
+                        u32x4 st;
+                        st[0] = s0[0]; st[1] = s1[0]; st[2] = s0[1]; st[3] = s1[1];
+                        if (qr < Lq) *reinterpret_cast<u32x4*>(op + dA + hi * 8) = st;
+                    } else if (qr < Lq) {  // a lone 8-column group (D % 16 == 8): the two 8-byte halves as before
+                        *reinterpret_cast<half4_t*>(op + dA + hi * 4) = wa;
+                    }
+                }
+        }
+#else
         if (qr < Lq) {
             half_t* op = out + ((int64_t)b * Lq + qr) * C + h * D;
 #pragma unroll
@@ -628,6 +664,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
                     }
                 }
         }
+#endif
     }
 }
 

@@ -9,6 +9,7 @@
 #   foldinf     attn.hip  -DFOLD_MAX=1e9f           scale always folded: separates the exact pass from the data-dependent clock
 #   fold0       attn.hip  -DFOLD_MAX=0.f            scale never folded: the exact pass on the bench's own activations
 #   nomax15     attn.hip  -DNOMAX_THR=15.f
+#   epiwide     attn.hip  -DFRESCO_EPI_WIDE=1       16-byte epilogue stores (v_permlane32_swap pairs)
 #   pf4 / pf6   proj.hip  -DFRESCO_PROJ_PF=4 / 6    weight fragments read 4 / 6 MFMAs ahead
 TAG=${1:-r}
 OUT=$PWD/gpurun_out/ab_$TAG.txt
@@ -32,6 +33,7 @@ build noslp attn.hip "$AT" "-fno-slp-vectorize"
 build foldinf attn.hip "$AT" "-DFOLD_MAX=1e9f"
 build fold0 attn.hip "$AT" "-DFOLD_MAX=0.f"
 build nomax15 attn.hip "$AT" "-DNOMAX_THR=15.f"
+build epiwide attn.hip "$AT" "-DFRESCO_EPI_WIDE=1"
 build pf4 proj.hip "$PR" "-DFRESCO_PROJ_PF=4"
 build pf6 proj.hip "$PR" "-DFRESCO_PROJ_PF=6"
 run() {  # name command...
@@ -42,11 +44,11 @@ run() {  # name command...
   FRESCO_HIP_LIB=$lib timeout 300 "$@" >> $OUT 2>&1
 }
 : > $OUT
-for v in base noslp foldinf fold0 nomax15; do
+for v in base noslp foldinf fold0 nomax15 epiwide; do
   run $v python tools/bench_flash.py 20 1.0      # N(0,1) q, k: the cfg2c regime
   run $v python tools/bench_flash.py 20 0.3      # small logits: the headline regime
 done
-for v in noslp foldinf nomax15; do                # parity of the attention variants (fold0 is exact by construction)
+for v in noslp foldinf nomax15 epiwide; do                # parity of the attention variants (fold0 is exact by construction)
   run $v python -m pytest tests/test_gpu_attention.py -q -x -p no:cacheprovider
 done
 for v in base pf4 pf6; do
