@@ -11,6 +11,9 @@
 #   nomax15     attn.hip  -DNOMAX_THR=15.f
 #   epiwide     attn.hip  -DFRESCO_EPI_WIDE=1       16-byte epilogue stores (v_permlane32_swap pairs)
 #   pf4 / pf6   proj.hip  -DFRESCO_PROJ_PF=4 / 6    weight fragments read 4 / 6 MFMAs ahead
+#   w4b2        proj.hip  -DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2   128-row workgroups, 2-slot ring (70 KB of LDS): TWO
+#                                                   workgroups per CU whose x loads / epilogues overlap the other's MFMAs
+#   w4b2pf4     both
 TAG=${1:-r}
 OUT=$PWD/gpurun_out/ab_$TAG.txt
 mkdir -p gpurun_out fresco_amd/lib/variants fresco_amd/csrc/build_var
@@ -36,6 +39,8 @@ build nomax15 attn.hip "$AT" "-DNOMAX_THR=15.f"
 build epiwide attn.hip "$AT" "-DFRESCO_EPI_WIDE=1"
 build pf4 proj.hip "$PR" "-DFRESCO_PROJ_PF=4"
 build pf6 proj.hip "$PR" "-DFRESCO_PROJ_PF=6"
+build w4b2 proj.hip "$PR" "-DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2"
+build w4b2pf4 proj.hip "$PR" "-DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2 -DFRESCO_PROJ_PF=4"
 run() {  # name command...
   local name=$1; shift
   local lib=""
@@ -51,10 +56,10 @@ done
 for v in noslp foldinf nomax15 epiwide; do                # parity of the attention variants (fold0 is exact by construction)
   run $v python -m pytest tests/test_gpu_attention.py -q -x -p no:cacheprovider
 done
-for v in base pf4 pf6; do
+for v in base pf4 pf6 w4b2 w4b2pf4; do
   run $v python tools/bench_linear.py
 done
-for v in pf4 pf6; do
+for v in pf4 pf6 w4b2 w4b2pf4; do
   run $v python -m pytest tests/test_gpu_linear.py -q -x -p no:cacheprovider
 done
 grep -E "^==|small-M HW=4096|q,k,v|passed|failed" $OUT
