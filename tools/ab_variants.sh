@@ -23,6 +23,9 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 build() {  # name source per-file-flags variant-flags
   local name=$1 src=$2 extra=$3 var=$4
   local obj=fresco_amd/csrc/build_var/${src%.hip}_$name.o
+  local so=fresco_amd/lib/variants/libfresco_hip_$name.so
+  # (variant libraries built in the dev container travel with the snapshot: rebuild only when a source is newer)
+  if [ -f $so ] && [ -z "$(find fresco_amd/csrc -maxdepth 1 \( -name '*.hip' -o -name '*.h' \) -newer $so)" ]; then return 0; fi
   $HIPCC $BASE $extra $var -c fresco_amd/csrc/$src -o $obj || return 1
   local objs=""
   for o in common attn attn32 proj temporal warp opt mapping; do
