@@ -99,6 +99,12 @@ static inline int ntiles_of(int M) { return (M + 63) / 64; }
 #ifndef FRESCO_PRIO_M
 #define FRESCO_PRIO_M 1
 #endif
+// Experiment switch (the product builds 0): 1 = group B (waves 4-7, the later-dispatched half, which loses the VALU
+// arbitration at the head of its post-barrier softmax segment) runs the whole key loop at s_setprio 1 and nobody flips
+// priorities per segment (MI355X_MICROARCH.md, "static priority for the younger half")
+#ifndef FRESCO_PRIO_STATIC
+#define FRESCO_PRIO_STATIC 0
+#endif
 // Experiment switch (the product builds 0): 16-byte epilogue stores via v_permlane32_swap pairs
 #ifndef FRESCO_EPI_WIDE
 #define FRESCO_EPI_WIDE 0
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         // The MFMA block runs at raised priority: against a partner wave in its softmax, an MFMA wave that loses the
         // issue arbitration (it does when it is the younger one) leaves the matrix pipe idle between MFMAs
         // (tools/ubench_rates.hip: 28 MFMAs beside a prioritised exp/cvt stream take 1590 cycles instead of 900).
-        __builtin_amdgcn_s_setprio(FRESCO_PRIO_M);
+        if (!FRESCO_PRIO_STATIC) __builtin_amdgcn_s_setprio(FRESCO_PRIO_M);
         // ---- O^T += V^T P^T  (row D of V^T is all ones when it is spare: O^T[D] = row sum)
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc)
@@ -578,10 +584,11 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         __builtin_amdgcn_sched_barrier(0);
         // ---- S^T of tile u+1
         if (!LAST) qk(kf);
-        __builtin_amdgcn_s_setprio(0);
+        if (!FRESCO_PRIO_STATIC) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    if (FRESCO_PRIO_STATIC && grpB) __builtin_amdgcn_s_setprio(1);
     const std::integral_constant<bool, true> yes;
     const std::integral_constant<bool, false> no_last, no;
     const std::integral_constant<bool, true> fast;

@@ -10,6 +10,7 @@
 #   fold0       attn.hip  -DFOLD_MAX=0.f            scale never folded: the exact pass on the bench's own activations
 #   nomax15     attn.hip  -DNOMAX_THR=15.f
 #   epiwide     attn.hip  -DFRESCO_EPI_WIDE=1       16-byte epilogue stores (v_permlane32_swap pairs)
+#   priostat    attn.hip  -DFRESCO_PRIO_STATIC=1    waves 4-7 at s_setprio 1 for the whole loop, no per-segment flips
 #   pf4 / pf6   proj.hip  -DFRESCO_PROJ_PF=4 / 6    weight fragments read 4 / 6 MFMAs ahead
 #   w4b2        proj.hip  -DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2   128-row workgroups, 2-slot ring (70 KB of LDS): TWO
 #                                                   workgroups per CU whose x loads / epilogues overlap the other's MFMAs
@@ -40,6 +41,7 @@ build foldinf attn.hip "$AT" "-DFOLD_MAX=1e9f"
 build fold0 attn.hip "$AT" "-DFOLD_MAX=0.f"
 build nomax15 attn.hip "$AT" "-DNOMAX_THR=15.f"
 build epiwide attn.hip "$AT" "-DFRESCO_EPI_WIDE=1"
+build priostat attn.hip "$AT" "-DFRESCO_PRIO_STATIC=1"
 build pf4 proj.hip "$PR" "-DFRESCO_PROJ_PF=4"
 build pf6 proj.hip "$PR" "-DFRESCO_PROJ_PF=6"
 build w4b2 proj.hip "$PR" "-DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2"
@@ -52,7 +54,7 @@ run() {  # name command...
   FRESCO_HIP_LIB=$lib timeout 300 "$@" >> $OUT 2>&1
 }
 : > $OUT
-for v in base noslp foldinf fold0 nomax15 epiwide; do
+for v in base noslp foldinf fold0 nomax15 epiwide priostat; do
   run $v python tools/bench_flash.py 20 1.0      # N(0,1) q, k: the cfg2c regime
   run $v python tools/bench_flash.py 20 0.3      # small logits: the headline regime
 done
