@@ -105,6 +105,10 @@ static inline int ntiles_of(int M) { return (M + 63) / 64; }
 #ifndef FRESCO_PRIO_STATIC
 #define FRESCO_PRIO_STATIC 0
 #endif
+// Experiment switch (the product builds 0): request the first key packs before the Q rows are loaded
+#ifndef FRESCO_EARLY_DMA
+#define FRESCO_EARLY_DMA 0
+#endif
 // Experiment switch (the product builds 0): 16-byte epilogue stores via v_permlane32_swap pairs
 #ifndef FRESCO_EPI_WIDE
 #define FRESCO_EPI_WIDE 0
@@ -252,6 +256,35 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int grpB = wave_s >= 4 ? 1 : 0;  // (flags are ints from scalar values: the branches on them stay scalar)
 
+#if FRESCO_EARLY_DMA
+    // experiment: the first four key packs are requested BEFORE the Q rows and the key-norm table are loaded (they depend
+    // on indices only), so that the two memory latencies of the prologue overlap.  The compiler's own vmcnt waits for
+    // the Q loads then also cover these (older) DMA requests: conservative, and the ring's first counted wait is met.
+    {
+        const int many_e = wave_s < (Cfg::NP % 8) ? 1 : 0;
+        const uint32_t lds0_e =
+            __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+        const char* src_e = img + (int64_t)(g * H + h) * (nT + 1) * Cfg::TILE;
+        const uint32_t lane_off_e = (wave * 64 + lane) * 16;
+        auto stage_e = [&](int p, int slot) __attribute__((always_inline)) {
+            const char* sp = src_e + (int64_t)p * Cfg::TILE;
+            const uint32_t dstb = lds0_e + slot * Cfg::TILE + wave_s * 1024;
+#pragma unroll
+            for (int i = 0; i < (Cfg::NP + 7) / 8; ++i) {
+                if (i < Cfg::NP / 8 || many_e) {
+                    const uint32_t m0v = dstb + i * 8192;
+                    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off_e), "s"(sp), "s"(m0v)
+                                 : "memory");
+                    sp += 8192;
+                }
+            }
+        };
+        stage_e(0, 3);
+        stage_e(1, 0);
+        if (nT > 1) stage_e(2, 1);
+        if (nT > 2) stage_e(3, 2);
+    }
+#endif
     // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
     half8_t qf[QB][Cfg::NKS];
     float q2[QB];  // |q|^2 of this lane's query
@@ -401,10 +434,12 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
 
     // ---- prologue: packs 0 .. 3 in flight (pack p = step p-1, slot (p+3) & 3), packs 0 and 1 landed,
     // S^T of tile 0 computed
+#if !FRESCO_EARLY_DMA
     stage(0, 3);
     stage(1, 0);
     if (nT > 1) stage(2, 1);
     if (nT > 2) stage(3, 2);
+#endif
     wait_barrier(nT > 2 ? 2 : (nT > 1 ? 1 : 0));
     {
         half8_t kf[2][Cfg::NKS];

@@ -11,6 +11,8 @@
 #   nomax15     attn.hip  -DNOMAX_THR=15.f
 #   epiwide     attn.hip  -DFRESCO_EPI_WIDE=1       16-byte epilogue stores (v_permlane32_swap pairs)
 #   priostat    attn.hip  -DFRESCO_PRIO_STATIC=1    waves 4-7 at s_setprio 1 for the whole loop, no per-segment flips
+#   earlydma    attn.hip  -DFRESCO_EARLY_DMA=1      first key packs requested before the Q rows are loaded
+#   combo       attn.hip  epiwide + priostat + earlydma
 #   pf4 / pf6   proj.hip  -DFRESCO_PROJ_PF=4 / 6    weight fragments read 4 / 6 MFMAs ahead
 #   w4b2        proj.hip  -DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2   128-row workgroups, 2-slot ring (70 KB of LDS): TWO
 #                                                   workgroups per CU whose x loads / epilogues overlap the other's MFMAs
@@ -42,6 +44,8 @@ build fold0 attn.hip "$AT" "-DFOLD_MAX=0.f"
 build nomax15 attn.hip "$AT" "-DNOMAX_THR=15.f"
 build epiwide attn.hip "$AT" "-DFRESCO_EPI_WIDE=1"
 build priostat attn.hip "$AT" "-DFRESCO_PRIO_STATIC=1"
+build earlydma attn.hip "$AT" "-DFRESCO_EARLY_DMA=1"
+build combo attn.hip "$AT" "-DFRESCO_EPI_WIDE=1 -DFRESCO_PRIO_STATIC=1 -DFRESCO_EARLY_DMA=1"
 build pf4 proj.hip "$PR" "-DFRESCO_PROJ_PF=4"
 build pf6 proj.hip "$PR" "-DFRESCO_PROJ_PF=6"
 build w4b2 proj.hip "$PR" "-DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2"
@@ -54,11 +58,11 @@ run() {  # name command...
   FRESCO_HIP_LIB=$lib timeout 300 "$@" >> $OUT 2>&1
 }
 : > $OUT
-for v in base noslp foldinf fold0 nomax15 epiwide priostat; do
+for v in base noslp foldinf fold0 nomax15 epiwide priostat earlydma combo; do
   run $v python tools/bench_flash.py 20 1.0      # N(0,1) q, k: the cfg2c regime
   run $v python tools/bench_flash.py 20 0.3      # small logits: the headline regime
 done
-for v in noslp foldinf nomax15 epiwide; do                # parity of the attention variants (fold0 is exact by construction)
+for v in noslp foldinf nomax15 epiwide earlydma combo; do                # parity of the attention variants (fold0 is exact by construction)
   run $v python -m pytest tests/test_gpu_attention.py -q -x -p no:cacheprovider
 done
 for v in base pf4 pf6 w4b2 w4b2pf4; do
