@@ -257,9 +257,10 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
     const int grpB = wave_s >= 4 ? 1 : 0;  // (flags are ints from scalar values: the branches on them stay scalar)
 
 #if FRESCO_EARLY_DMA
-    // experiment: the first four key packs are requested BEFORE the Q rows and the key-norm table are loaded (they depend
-    // on indices only), so that the two memory latencies of the prologue overlap.  The compiler's own vmcnt waits for
-    // the Q loads then also cover these (older) DMA requests: conservative, and the ring's first counted wait is met.
+    // experiment: the first two key packs (all that the first step reads) are requested BEFORE the Q rows and the
+    // key-norm table are loaded (they depend on indices only), so that the two memory latencies of the prologue overlap
+    // and the packs are first in the queues.  The compiler's own vmcnt waits for the Q loads then also cover these
+    // (older) DMA requests: conservative; the ring's first counted wait still finds packs 2 and 3 as the newest requests.
     {
         const int many_e = wave_s < (Cfg::NP % 8) ? 1 : 0;
         const uint32_t lds0_e =
@@ -279,10 +280,8 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
                 }
             }
         };
-        stage_e(0, 3);
+        stage_e(0, 3);  // what the first step needs; packs 2 and 3 follow the Q loads at their usual place
         stage_e(1, 0);
-        if (nT > 1) stage_e(2, 1);
-        if (nT > 2) stage_e(3, 2);
     }
 #endif
     // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
@@ -437,9 +436,9 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
 #if !FRESCO_EARLY_DMA
     stage(0, 3);
     stage(1, 0);
+#endif
     if (nT > 1) stage(2, 1);
     if (nT > 2) stage(3, 2);
-#endif
     wait_barrier(nT > 2 ? 2 : (nT > 1 ? 1 : 0));
     {
         half8_t kf[2][Cfg::NKS];
