@@ -109,6 +109,13 @@ static inline int ntiles_of(int M) { return (M + 63) / 64; }
 #ifndef FRESCO_EARLY_DMA
 #define FRESCO_EARLY_DMA 0
 #endif
+// Experiment switch (the product builds 0): 1 = one workgroup per CU walks its query blocks in a loop (no dispatch gap
+// between rounds); 2 = as 1, and the next block's first two key packs and Q rows are requested BEFORE the current
+// block's epilogue, so that the prologue's memory burst (every CU fetching ~100 KB at once, ~5 us per round) runs
+// under the epilogue and is spread out instead of repeating in lock-step every round
+#ifndef FRESCO_PERSIST
+#define FRESCO_PERSIST 0
+#endif
 // Experiment switch (the product builds 0): 16-byte epilogue stores via v_permlane32_swap pairs
 #ifndef FRESCO_EPI_WIDE
 #define FRESCO_EPI_WIDE 0
@@ -243,9 +250,60 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
     constexpr int ROWS = 256 * QB;  // query rows per workgroup
 
     const int nQblk = (Lq + ROWS - 1) / ROWS;
-    const int h = blockIdx.x % H;
-    const int qblk = (blockIdx.x / H) % nQblk;
-    const int b = blockIdx.x / (H * nQblk);
+#if FRESCO_PERSIST
+    // (experiment scaffolding: the body below is the loop body, left at its indentation)
+    const unsigned nblk = (unsigned)(H * nQblk * B);
+#if FRESCO_PERSIST == 2
+    half8_t qf[QB][Cfg::NKS];  // Q fragments, requested one block ahead
+    const int p_lane = threadIdx.x & 63, p_wave = threadIdx.x >> 6;
+    const int p_wave_s = __builtin_amdgcn_readfirstlane(p_wave);
+    auto request_block = [&](unsigned blk_) __attribute__((always_inline)) {
+        const int h_ = blk_ % H, qblk_ = (blk_ / H) % nQblk, b_ = blk_ / (H * nQblk), g_ = b_ / batch_per_group;
+        {   // key packs 0 and 1 -> ring slots 3 and 0
+            const int many_e = p_wave_s < (Cfg::NP % 8) ? 1 : 0;
+            const uint32_t lds0_e =
+                __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+            const char* sp = img + (int64_t)(g_ * H + h_) * (nT + 1) * Cfg::TILE;
+            const uint32_t lane_off_e = (p_wave * 64 + p_lane) * 16;
+#pragma unroll
+            for (int pk = 0; pk < 2; ++pk) {
+                const uint32_t dstb = lds0_e + (pk == 0 ? 3 : 0) * Cfg::TILE + p_wave_s * 1024;
+                const char* spp = sp + (int64_t)pk * Cfg::TILE;
+#pragma unroll
+                for (int i = 0; i < (Cfg::NP + 7) / 8; ++i) {
+                    if (i < Cfg::NP / 8 || many_e) {
+                        const uint32_t m0v = dstb + i * 8192;
+                        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off_e), "s"(spp), "s"(m0v)
+                                     : "memory");
+                        spp += 8192;
+                    }
+                }
+            }
+        }
+        const int qrow0_ = qblk_ * ROWS + p_wave * 32 * QB + (p_lane & 31);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const int qr = qrow0_ + 32 * j;
+            const half_t* qp = q + ((int64_t)b_ * Lq + (qr < Lq ? qr : Lq - 1)) * q_ld + h_ * D;
+#pragma unroll
+            for (int ks = 0; ks < Cfg::NKS; ++ks) {
+                const int d0 = ks * 16 + (p_lane >> 5) * 8;
+                half8_t t = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (d0 < D) t = *reinterpret_cast<const half8_t*>(qp + d0);
+                qf[j][ks] = t;
+            }
+        }
+    };
+    request_block(blockIdx.x);
+#endif
+    for (unsigned blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+#else
+    const unsigned blk = blockIdx.x;
+    {
+#endif
+    const int h = blk % H;
+    const int qblk = (blk / H) % nQblk;
+    const int b = blk / (H * nQblk);
     const int g = b / batch_per_group;
     const int C = H * D;
 
@@ -256,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int grpB = wave_s >= 4 ? 1 : 0;  // (flags are ints from scalar values: the branches on them stay scalar)
 
-#if FRESCO_EARLY_DMA
+#if FRESCO_EARLY_DMA && FRESCO_PERSIST != 2
     // experiment: the first two key packs (all that the first step reads) are requested BEFORE the Q rows and the
     // key-norm table are loaded (they depend on indices only), so that the two memory latencies of the prologue overlap
     // and the packs are first in the queues.  The compiler's own vmcnt waits for the Q loads then also cover these
@@ -285,6 +343,18 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
     }
 #endif
     // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
+#if FRESCO_PERSIST == 2
+    float q2[QB];  // (qf was requested by request_block, one block ahead)
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        q2[j] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < Cfg::NKS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q2[j] = fmaf((float)qf[j][ks][e], (float)qf[j][ks][e], q2[j]);
+        q2[j] += __shfl_xor(q2[j], 32, 64);
+    }
+#else
     half8_t qf[QB][Cfg::NKS];
     float q2[QB];  // |q|^2 of this lane's query
 #pragma unroll
@@ -303,6 +373,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         }
         q2[j] += __shfl_xor(q2[j], 32, 64);
     }
+#endif
 
     // Cauchy-Schwarz: every logit of this lane's query is bounded by |q| max|k| (max|k|^2 per key tile comes
     // from kv_pack).  Two per-wave decisions hang on it:
@@ -433,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
 
     // ---- prologue: packs 0 .. 3 in flight (pack p = step p-1, slot (p+3) & 3), packs 0 and 1 landed,
     // S^T of tile 0 computed
-#if !FRESCO_EARLY_DMA
+#if !FRESCO_EARLY_DMA && FRESCO_PERSIST != 2
     stage(0, 3);
     stage(1, 0);
 #endif
@@ -645,6 +716,13 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         step(u, yes, no);
     }
 
+#if FRESCO_PERSIST
+    // every wave is past its last fragment reads before the ring is refilled (by the next block's prologue, or here)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if FRESCO_PERSIST == 2
+    if (blk + gridDim.x < nblk) request_block(blk + gridDim.x);
+#endif
+#endif
     // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
@@ -707,6 +785,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         }
 #endif
     }
+    }  // block loop (FRESCO_PERSIST) / scope
 }
 
 template <int D, int QB>
@@ -720,7 +799,16 @@ static void launch_flash(const half_t* q, const char* img, half_t* out, int B, i
     const int nQblk = (Lq + 256 * QB - 1) / (256 * QB);
     const float log2e = 1.4426950408889634f;
     ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
-    hipLaunchKernelGGL((attn_flash_kernel<D, QB>), dim3(H * nQblk * B), dim3(512), Cfg::LDS_BYTES, st, q, img,
+    int grid = H * nQblk * B;
+#if FRESCO_PERSIST
+    {
+        int dev = 0, ncu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (grid > ncu) grid = ncu;
+    }
+#endif
+    hipLaunchKernelGGL((attn_flash_kernel<D, QB>), dim3(grid), dim3(512), Cfg::LDS_BYTES, st, q, img,
                        ktmax, out, B, H, Lq, M, nT, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
 }
 

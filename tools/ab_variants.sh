@@ -13,6 +13,9 @@
 #   priostat    attn.hip  -DFRESCO_PRIO_STATIC=1    waves 4-7 at s_setprio 1 for the whole loop, no per-segment flips
 #   earlydma    attn.hip  -DFRESCO_EARLY_DMA=1      first key packs requested before the Q rows are loaded
 #   combo       attn.hip  epiwide + priostat + earlydma
+#   persist1/2  attn.hip  -DFRESCO_PERSIST=1 / 2    one workgroup per CU walks its query blocks; 2: the next block's first
+#                                                   packs and Q rows are requested before the current epilogue
+#   persist2e   attn.hip  persist2 + epiwide
 #   pf4 / pf6   proj.hip  -DFRESCO_PROJ_PF=4 / 6    weight fragments read 4 / 6 MFMAs ahead
 #   w4b2        proj.hip  -DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2   128-row workgroups, 2-slot ring (70 KB of LDS): TWO
 #                                                   workgroups per CU whose x loads / epilogues overlap the other's MFMAs
@@ -46,6 +49,9 @@ build epiwide attn.hip "$AT" "-DFRESCO_EPI_WIDE=1"
 build priostat attn.hip "$AT" "-DFRESCO_PRIO_STATIC=1"
 build earlydma attn.hip "$AT" "-DFRESCO_EARLY_DMA=1"
 build combo attn.hip "$AT" "-DFRESCO_EPI_WIDE=1 -DFRESCO_PRIO_STATIC=1 -DFRESCO_EARLY_DMA=1"
+build persist1 attn.hip "$AT" "-DFRESCO_PERSIST=1"
+build persist2 attn.hip "$AT" "-DFRESCO_PERSIST=2"
+build persist2e attn.hip "$AT" "-DFRESCO_PERSIST=2 -DFRESCO_EPI_WIDE=1"
 build pf4 proj.hip "$PR" "-DFRESCO_PROJ_PF=4"
 build pf6 proj.hip "$PR" "-DFRESCO_PROJ_PF=6"
 build w4b2 proj.hip "$PR" "-DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2"
@@ -58,12 +64,18 @@ run() {  # name command...
   FRESCO_HIP_LIB=$lib timeout 300 "$@" >> $OUT 2>&1
 }
 : > $OUT
-for v in base noslp foldinf fold0 nomax15 epiwide priostat earlydma combo; do
+for v in base noslp foldinf nomax15; do
   run $v python tools/bench_flash.py 20 1.0      # N(0,1) q, k: the cfg2c regime
+done
+for v in base noslp fold0 epiwide priostat earlydma combo persist1 persist2 persist2e; do
   run $v python tools/bench_flash.py 20 0.3      # small logits: the headline regime
 done
 for v in noslp foldinf nomax15 epiwide earlydma combo; do                # parity of the attention variants (fold0 is exact by construction)
   run $v python -m pytest tests/test_gpu_attention.py -q -x -p no:cacheprovider
+done
+for v in persist1 persist2 persist2e; do          # several blocks per workgroup: full-size shapes + many-block fuzz
+  run $v python -m pytest tests/test_gpu_attention.py tests/test_gpu_fullsize.py -q -x -p no:cacheprovider
+  run $v python tools/fuzz_attn.py 24 1 big
 done
 for v in base pf4 pf6 w4b2 w4b2pf4; do
   run $v python tools/bench_linear.py
@@ -71,4 +83,4 @@ done
 for v in pf4 pf6 w4b2 w4b2pf4; do
   run $v python -m pytest tests/test_gpu_linear.py -q -x -p no:cacheprovider
 done
-grep -E "^==|small-M HW=4096|q,k,v|passed|failed" $OUT
+grep -E "^==|small-M HW=|spatial  HW=1024|q,k,v|passed|failed|all .* cases ok|FAIL" $OUT

@@ -1,6 +1,8 @@
 """Randomised stress of fresco_attn_fwd against an fp32 softmax on the same GPU: shapes, head dims, key groups,
 row selections, logit magnitudes (all three kernel paths: folded / exact scale, with / without the max search),
-diagonal bias.  usage: python tools/fuzz_attn.py [cases] [seed]"""
+diagonal bias.  usage: python tools/fuzz_attn.py [cases] [seed] [big]
+("big": 8 heads and up to 3000 query rows, i.e. more query blocks than CUs -- for kernel variants that walk several
+blocks per workgroup)"""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,17 +10,18 @@ from fresco_amd import ops
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 g = torch.Generator().manual_seed(seed)
 ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
 worst = 0.0
 for it in range(cases):
     D = [8, 16, 32, 40, 64, 80, 96, 128][ri(0, 7)]
-    H = [1, 2, 4, 8][ri(0, 3)]
+    H = 8 if big else [1, 2, 4, 8][ri(0, 3)]
     C = H * D
     G = ri(1, 3)
-    per = ri(1, 3)
+    per = ri(2, 3) if big else ri(1, 3)
     B = G * per
-    Lq = ri(1, 700)
+    Lq = ri(1500, 3000) if big else ri(1, 700)
     rows_per_group = ri(1, 900)
     use_rows = ri(0, 1) == 1
     gain = [0.3, 1.0, 2.5, 6.0, 20.0][ri(0, 4)]
