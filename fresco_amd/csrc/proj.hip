@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
     int col = (ft0 % tiles_per_out) * Cfg::TF;
 
     stage(0, 0);
-    if (nsteps > 1) stage(1, 1);
+    if (AHEAD > 1 && nsteps > 1) stage(1, 1);
     if (AHEAD > 2 && nsteps > 2) stage(2, 2);
     // biases -> LDS once (a global load inside the tile loop would make the compiler drain vmcnt there, DMA included)
     half_t* bias_s = reinterpret_cast<half_t*>(smem + Cfg::BIAS_OFF);
