@@ -1387,6 +1387,11 @@ struct AdamArgs {
     float beta1, beta2, step_size, bc2_sqrt, eps;
 };
 
+// Experiment switch (the product builds 1): channel octets per thread of adam_update_kernel
+#ifndef FRESCO_ADAM_NOCT
+#define FRESCO_ADAM_NOCT 1
+#endif
+
 __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs, float* __restrict__ m,
                                                            float* __restrict__ v2, TGradArgs tg,
                                                            const float* __restrict__ vt,
@@ -1397,6 +1402,25 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
                                                            AdamArgs a) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= hw) return;
+#if FRESCO_ADAM_NOCT > 1
+    // experiment: one thread walks FRESCO_ADAM_NOCT channel octets of its pixel, so that the pixel's CSR rows and
+    // occlusion factors (28 loads, the same for every channel) are fetched once per NOCT octets instead of once per octet
+    const int b = blockIdx.z, C8 = (C + ECPT - 1) / ECPT;
+    float dot = 0.f, inv_n = 0.f, n = 1.f;
+    if (has_s) {
+        for (int s = 0; s < S; ++s) dot += part[((int64_t)b * S + s) * hw + p];
+        n = nrm[(int64_t)b * hw + p];
+        inv_n = 1.f / n;
+    }
+    TGradPixel tp;
+    if (has_t) tp.init(tg, b, p, hw);
+    for (int oc = 0; oc < FRESCO_ADAM_NOCT; ++oc) {
+    const int c8 = blockIdx.y * FRESCO_ADAM_NOCT + oc;
+    if (c8 >= C8) break;
+    const int c0 = c8 * ECPT, cend = min(c0 + ECPT, C);
+    float tgv[ECPT] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (has_t) tp.values(tg, c8, p, C8, hw, tgv);
+#else
     const int b = blockIdx.z, c0 = blockIdx.y * ECPT, cend = min(c0 + ECPT, C);
     float dot = 0.f, inv_n = 0.f, n = 1.f;
     if (has_s) {
@@ -1411,6 +1435,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
         tp.init(tg, b, p, hw);
         tp.values(tg, blockIdx.y, p, gridDim.y, hw, tgv);
     }
+#endif
     for (int c = c0; c < cend; ++c) {
         const int64_t o = ((int64_t)b * C + c) * hw + p;
         float g = tgv[c - c0];
@@ -1427,6 +1452,9 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
             cs[o] = x - a.step_size * (mm / denom);
         }
     }
+#if FRESCO_ADAM_NOCT > 1
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1561,7 +1589,8 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
     }
     static_assert(OCPT == ECPT, "the temporal gradient is evaluated on the elementwise grid");
     const TGradArgs tg = {w.sgn1, w.sgn2, bwd_occ, fwd_occ, w.rowptr, w.src, w.wgt, L, kscale};
-    hipLaunchKernelGGL(adam_update_kernel, egrid, dim3(256), 0, st, cs, w.m, w.v, tg,
+    const dim3 agrid(egrid.x, (egrid.y + FRESCO_ADAM_NOCT - 1) / FRESCO_ADAM_NOCT, egrid.z);
+    hipLaunchKernelGGL(adam_update_kernel, agrid, dim3(256), 0, st, cs, w.m, w.v, tg,
                        v_stored ? w.vt : (const float*)nullptr, w.dvt, w.nrm, w.part, gout, C, hw, S, has_t, has_s, mode,
                        a);
 }

@@ -20,6 +20,8 @@
 #   w4b2        proj.hip  -DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2   128-row workgroups, 2-slot ring (70 KB of LDS): TWO
 #                                                   workgroups per CU whose x loads / epilogues overlap the other's MFMAs
 #   w4b2pf4     both
+#   adam2/adam4 opt.hip   -DFRESCO_ADAM_NOCT=2 / 4    adam_update: 2 / 4 channel octets per thread (the pixel's CSR rows are
+#                                                   fetched once per thread, not once per octet)
 TAG=${1:-r}
 OUT=$PWD/gpurun_out/ab_$TAG.txt
 mkdir -p gpurun_out fresco_amd/lib/variants fresco_amd/csrc/build_var
@@ -56,6 +58,8 @@ build pf4 proj.hip "$PR" "-DFRESCO_PROJ_PF=4"
 build pf6 proj.hip "$PR" "-DFRESCO_PROJ_PF=6"
 build w4b2 proj.hip "$PR" "-DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2"
 build w4b2pf4 proj.hip "$PR" "-DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2 -DFRESCO_PROJ_PF=4"
+build adam2 opt.hip "" "-DFRESCO_ADAM_NOCT=2"
+build adam4 opt.hip "" "-DFRESCO_ADAM_NOCT=4"
 run() {  # name command...
   local name=$1; shift
   local lib=""
@@ -83,4 +87,10 @@ done
 for v in pf4 pf6 w4b2 w4b2pf4; do
   run $v python -m pytest tests/test_gpu_linear.py -q -x -p no:cacheprovider
 done
-grep -E "^==|small-M HW=|spatial  HW=1024|q,k,v|passed|failed|all .* cases ok|FAIL" $OUT
+for v in base adam2 adam4; do
+  run $v python tools/bench_opt.py 20 --no-baselines
+done
+for v in adam2 adam4; do
+  run $v python -m pytest tests/test_gpu_opt.py -q -x -p no:cacheprovider
+done
+grep -E "^==|small-M HW=|spatial  HW=1024|q,k,v|passed|failed|all .* cases ok|FAIL|cfg3 extra" $OUT
