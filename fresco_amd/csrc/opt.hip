@@ -1471,7 +1471,7 @@ static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int 
                             int has_s, int n_pairs = 0) {
     // N = frames owned per CFG half; n_pairs = temporal pairs evaluated (N for the single-GPU ring)
     const size_t NP = n_pairs > 0 ? n_pairs : N;
-    const size_t B = (size_t)chunk * N, hw = (size_t)h * wd, E = B * C * hw, EP = (size_t)chunk * NP * C * hw;
+    const size_t B = (size_t)chunk * N, hw = (size_t)h * wd, E = B * C * hw;
     // size query: lay out from a fake non-null base (no memory is touched)
     if (!basep) basep = reinterpret_cast<char*>(static_cast<uintptr_t>(4096));
     char* p = basep;
