@@ -130,3 +130,37 @@ def test_cf_plan_tables():
     assert none["Rmax"] == 0 and none["table"].tolist() == list(range(HW)) and none["group_rows"] == HW
     with pytest.raises(ValueError):
         cf_plan(~mask, N, HW, world, 0)
+
+
+@pytest.mark.parametrize("world,N", [(2, 8), (4, 8), (8, 8), (8, 32), (4, 16)])
+@pytest.mark.parametrize("density", [0.0, 0.05, 0.5, 1.0])
+def test_cf_plan_emulated_exchange(world, N, density):
+    """The sparse cross-frame exchange at the world sizes the 8-GPU node runs (no process group: the broadcast and the
+    all-gather are emulated by writing every rank's contribution where the collectives put it).  Addressing the buffer
+    through the plan's table must reproduce the reference's key rows -- the True entries of the mask in row-major
+    (frame, pixel) order, src/diffusion_hacked.py:239 -- on every rank, including ranks that contribute no row."""
+    from fresco_amd.dist import cf_plan
+
+    HW, C, chunk = 40, 3, 2
+    g = torch.Generator().manual_seed(world * 100 + N + int(density * 10))
+    mask = torch.rand(N, HW, generator=g) < density
+    mask[0] = True
+    if density == 0.05:
+        mask[N // 2:] = False  # the upper ranks own no selected row at all
+        mask[0] = True
+    KV = torch.randn(chunk, N, HW, C, generator=g)
+    n_loc = N // world
+    plans = [cf_plan(mask, N, HW, world, r) for r in range(world)]
+    Rmax, rows = plans[0]["Rmax"], plans[0]["group_rows"]
+    want = mask.reshape(-1).nonzero().squeeze(1)
+    assert all(p["Rmax"] == Rmax and p["group_rows"] == rows and torch.equal(p["table"], plans[0]["table"]) for p in plans)
+    assert plans[0]["M"] == want.numel() and rows == HW + world * Rmax
+    buf = torch.full((chunk, rows, C), float("nan"))
+    buf[:, :HW] = KV[:, 0]                                   # broadcast of frame 0 (owner: rank 0)
+    for r, p in enumerate(plans):                            # all-gather: rank r's padded rows land at HW + r*Rmax
+        loc = KV[:, r * n_loc:(r + 1) * n_loc].reshape(chunk, n_loc * HW, C)
+        assert p["local_sel"].numel() == Rmax and (Rmax == 0 or int(p["local_sel"].max()) < n_loc * HW)
+        buf[:, HW + r * Rmax:HW + (r + 1) * Rmax] = loc[:, p["local_sel"]]
+    got = buf[:, plans[0]["table"].long()]
+    assert torch.equal(got, KV.reshape(chunk, N * HW, C)[:, want])
+    assert plans[0]["table"].unique().numel() == want.numel()  # every key row has its own slot
