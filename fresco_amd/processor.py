@@ -128,6 +128,12 @@ class FRESCOAttnProcessor2_0:
             sparse_kv = (self.sparse_kv_projection and bool(ctrl) and ctrl.use_cfattn and not ctrl.use_interattn
                          and hidden_states.shape[0] % self.unet_chunk_size == 0)
             if sparse_kv:
+                # (the row table below is built from the mask's own (frame, pixel) grid and handed to the kernel
+                # unchecked: a mask of another batch size takes the general path, whose row table IS bounds-checked)
+                m_ = self._cf_mask(ctrl, hidden_states.shape[1])
+                sparse_kv = m_ is None or (m_.dim() == 2 and
+                                           m_.shape[0] == hidden_states.shape[0] // self.unet_chunk_size)
+            if sparse_kv:
                 # the only reader of K and V is the cross-frame pass, which gathers frame 0 and the selected tokens of
                 # the other frames (225-247): project exactly those rows, in the order the pass enumerates them
                 (query,) = self._project(attn, hidden_states, ("to_q",))
