@@ -1,7 +1,8 @@
 #!/bin/bash
 # A/B build + timing of kernel variants in ONE GPU-box visit (each variant = one object file rebuilt with extra flags,
 # linked with the default objects into fresco_amd/lib/variants/libfresco_hip_<name>.so, selected via FRESCO_HIP_LIB).
-# usage (repo root, on the box):  bash tools/ab_variants.sh [tag]      -> gpurun_out/ab_<tag>.txt
+# usage (repo root, on the box):  bash tools/ab_variants.sh [tag] ["stages"]   -> gpurun_out/ab_<tag>.txt
+# (all stages: roughly 25 minutes of box time; stages: flash parity persist linear opt)
 # Variants (name | source | flags):
 #   base        the shipped build
 #   noslp       attn.hip  -fno-slp-vectorize        no v_pk_mul_f32 in the exact-scale / rescale passes (packed f32 VALU is
@@ -68,29 +69,37 @@ run() {  # name command...
   FRESCO_HIP_LIB=$lib timeout 300 "$@" >> $OUT 2>&1
 }
 : > $OUT
-for v in base noslp foldinf nomax15; do
-  run $v python tools/bench_flash.py 20 1.0      # N(0,1) q, k: the cfg2c regime
-done
-for v in base noslp fold0 epiwide priostat earlydma combo persist1 persist2 persist2e; do
-  run $v python tools/bench_flash.py 20 0.3      # small logits: the headline regime
-done
-for v in noslp foldinf nomax15 epiwide earlydma combo; do                # parity of the attention variants (fold0 is exact by construction)
-  run $v python -m pytest tests/test_gpu_attention.py -q -x -p no:cacheprovider
-done
-for v in persist1 persist2 persist2e; do          # several blocks per workgroup: full-size shapes + many-block fuzz
-  run $v python -m pytest tests/test_gpu_attention.py tests/test_gpu_fullsize.py -q -x -p no:cacheprovider
-  run $v python tools/fuzz_attn.py 24 1 big
-done
-for v in base pf4 pf6 w4b2 w4b2pf4; do
-  run $v python tools/bench_linear.py
-done
-for v in pf4 pf6 w4b2 w4b2pf4; do
-  run $v python -m pytest tests/test_gpu_linear.py -q -x -p no:cacheprovider
-done
-for v in base adam2 adam4; do
-  run $v python tools/bench_opt.py 20 --no-baselines
-done
-for v in adam2 adam4; do
-  run $v python -m pytest tests/test_gpu_opt.py -q -x -p no:cacheprovider
-done
+STAGES=${2:-"flash parity persist linear opt"}   # second argument: a subset of the stages, e.g. "flash linear"
+for st in $STAGES; do case $st in
+flash)    # timing only (~15 s per line)
+  for v in base noslp foldinf nomax15; do
+    run $v python tools/bench_flash.py 20 1.0      # N(0,1) q, k: the cfg2c regime
+  done
+  for v in base noslp fold0 epiwide priostat earlydma combo persist1 persist2 persist2e; do
+    run $v python tools/bench_flash.py 20 0.3      # small logits: the headline regime
+  done ;;
+parity)   # the attention variants against the test-suite (fold0 is exact by construction)
+  for v in noslp foldinf nomax15 epiwide earlydma combo; do
+    run $v python -m pytest tests/test_gpu_attention.py -q -x -p no:cacheprovider
+  done ;;
+persist)  # several blocks per workgroup: full-size shapes + many-block fuzz
+  for v in persist1 persist2 persist2e; do
+    run $v python -m pytest tests/test_gpu_attention.py tests/test_gpu_fullsize.py -q -x -p no:cacheprovider
+    run $v python tools/fuzz_attn.py 24 1 big
+  done ;;
+linear)
+  for v in base pf4 pf6 w4b2 w4b2pf4; do
+    run $v python tools/bench_linear.py
+  done
+  for v in pf4 pf6 w4b2 w4b2pf4; do
+    run $v python -m pytest tests/test_gpu_linear.py -q -x -p no:cacheprovider
+  done ;;
+opt)
+  for v in base adam2 adam4; do
+    run $v python tools/bench_opt.py 20 --no-baselines
+  done
+  for v in adam2 adam4; do
+    run $v python -m pytest tests/test_gpu_opt.py -q -x -p no:cacheprovider
+  done ;;
+esac; done
 grep -E "^==|small-M HW=|spatial  HW=1024|q,k,v|passed|failed|all .* cases ok|FAIL|cfg3 extra" $OUT
