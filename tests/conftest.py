@@ -21,6 +21,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def headdim_golden():
+    import numpy as np
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "proc_headdim_golden.npz")))
+
+
+@pytest.fixture(scope="session")
 def paras_golden():
     import numpy as np
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "paras_golden.npz")))

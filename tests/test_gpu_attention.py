@@ -174,6 +174,24 @@ def test_processor_reference_golden_kat7(golden, mode):
     _check(out, ref, atol=1e-3, rtol=2e-3, what="KAT7 " + mode)
 
 
+@pytest.mark.parametrize("heads", [2, 1])
+@pytest.mark.parametrize("mode", ["full", "cf_temporal", "cf"])
+def test_processor_reference_golden_decoder_head_dims(headdim_golden, heads, mode):
+    """The KAT-7 inputs widened to C = 80, i.e. head dim 40 (up_blocks.3) with 2 heads and 80 (up_blocks.2) with 1:
+    outputs of the UNMODIFIED reference (fp32, CPU; tests/golden/make_proc_headdim_golden.py) as golden for the flash and
+    temporal kernels at the head dims the decoder runs (the projections of this width stay the modules' own GEMMs)."""
+    d = cf.base_case()
+    C, HW, B = 80, 64, 8
+    W = cf.attn_weights(C)
+    fm, bm, tm = O.mapping_ind(d["bwd"], d["bo"], d["imgs"], scale=8.0)
+    case = dict(attn=synth.FakeAttn(C, heads, W), hidden=cf.attn_hidden(B, HW, C, 0.0),
+                ref=cf.attn_hidden(B, HW, C, 0.4), fwd_map=fm, bwd_map=bm, tmask=tm,
+                cf_mask=O.cross_frame_masks(d["bo"], scales=(8.0,))[0], N=4, HW=HW, C=C, heads=heads)
+    out = _run_processor(case, mode)
+    ref = torch.from_numpy(headdim_golden["proc_d%d_%s" % (C // heads, mode)])
+    _check(out, ref, atol=1e-3, rtol=2e-3, what="D=%d %s" % (C // heads, mode))
+
+
 @pytest.mark.parametrize("layer", ["L2", "L3"])
 @pytest.mark.parametrize("mode", MODES)
 def test_processor_vs_oracle_cfg1(layer, mode):
