@@ -79,6 +79,7 @@ flash)    # timing only (~15 s per line)
     run $v python tools/bench_flash.py 20 0.3      # small logits: the headline regime
   done ;;
 parity)   # the attention variants against the test-suite (fold0 is exact by construction)
+  FRESCO_TEST_QUEUED=1 run base python -m pytest tests/test_gpu_attention.py -q -p no:cacheprovider -k decoder_head_dims
   for v in noslp foldinf nomax15 epiwide earlydma combo; do
     run $v python -m pytest tests/test_gpu_attention.py -q -x -p no:cacheprovider
   done ;;
