@@ -466,13 +466,17 @@ def main():
     M3 = int(params[8][3].sum())
     dom = [ms for tag, d, ms in recs if tag == 1 and d == (B_loc * 8, HW3, M3, 40)]
     roofline = None
+    pmc = pmc_traffic_bytes("attn_flash_kernelILi40")
     if dom:
         flop = 4.0 * B_loc * HW3 * M3 * 320
         mean_s = sum(dom) / len(dom) * 1e-3
         ach = flop / mean_s
         roofline = dict(bound="mfma", kernel="attn_flash_kernel<40> (up_blocks.3 cross-frame pass)",
                         achieved=round(ach / 1e12, 2), peak=PEAK_F16_DENSE / 1e12, unit="TFLOP/s",
-                        frac=round(ach / PEAK_F16_DENSE, 4), traffic=pmc_traffic_bytes("attn_flash_kernelILi40"),
+                        frac=round(ach / PEAK_F16_DENSE, 4),
+                        # HBM bytes per launch from the committed PMC passes (a number, or null without a profile)
+                        traffic=(pmc or {}).get("bytes"), traffic_source=(pmc or {}).get("source"),
+                        traffic_note=(pmc or {}).get("note"),
                         algorithmic_bytes_per_launch=int(2 * B_loc * HW3 * 320 * 2 + 2 * 2 * M3 * 320 * 2),
                         launches=len(dom),
                         executed_flop_per_launch=flop * 1.4,
