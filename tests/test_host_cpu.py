@@ -262,3 +262,38 @@ def test_processor_projects_only_the_selected_keys_in_cross_frame_only_mode(monk
     assert [c[0] for c in calls] == ["attn", "temporal"]
     assert calls[0][2] == (chunk * N, HW, C) and torch.equal(calls[0][4]["kv_rows"].long(), rows)
     assert calls[1][1] == (chunk * N, HW, C)
+
+
+def test_bench_workload_helpers():
+    """bench.py's synthetic FRESCO parameters are valid inputs (trajectory maps = permutations with their inverses, frame 0
+    of the cross-frame mask all True, symmetric trajectory masks with a True diagonal), the schedule is the reference's
+    15-step mix (src/pipe_FRESCO.py:166-174), and the fabric-byte arithmetic of the frame-sharded run is what DESIGN.md
+    section 6 states."""
+    import bench
+
+    assert len(bench.SCHEDULE) == 15 and bench.SCHEDULE.count("full") == 1
+    assert bench.SCHEDULE.count("cf_temporal") == 7 and bench.SCHEDULE.count("cf") == 7
+    N, side = 4, 8
+    HW = side * side
+    fwd, bwd, tmask, cfm = bench.synth_params(N, side, torch.Generator().manual_seed(0), 0.1)
+    assert fwd.shape == bwd.shape == (N, 1, HW) and tmask.shape[0] == HW and cfm.shape == (N, HW)
+    ar = torch.arange(HW)
+    for f in range(N):
+        assert torch.equal(fwd[f, 0].sort().values, ar)            # a permutation ...
+        assert torch.equal(fwd[f, 0][bwd[f, 0]], ar)               # ... and its inverse
+    assert bool(cfm[0].all()) and cfm.dtype == torch.bool
+    tm = tmask.reshape(HW, N, N)
+    assert torch.equal(tm, tm.transpose(1, 2)) and bool(tm.diagonal(dim1=1, dim2=2).all())
+    # per-step fabric bytes a rank receives, 8 frames 512^2 on 8 ranks, M_rest = selected rows of the fullest rank
+    out = bench.collective_bytes_per_step(8, 512, 8, {"L2": 10, "L3": 40})
+    cf3 = 2 * 4096 * 2 * 320 * 2 + 2 * 7 * 40 * 2 * 320 * 2
+    a2a3 = 7 / 8 * (2 * 1 * 4096) * (4 * 320) * 2
+    assert out["L3"] == dict(cross_frame=cf3, temporal_all_to_all=int(a2a3))
+    cf2 = 2 * 1024 * 2 * 640 * 2 + 2 * 7 * 10 * 2 * 640 * 2
+    a2a2 = 7 / 8 * (2 * 1 * 1024) * (4 * 640) * 2
+    assert out["per_step_mean"] == int(3 * (cf3 + a2a3 * 8 / 15) + 3 * (cf2 + a2a2 * 8 / 15))
+    # one GPU: nothing crosses the fabric
+    assert bench.collective_bytes_per_step(8, 512, 1, {"L2": 0, "L3": 0})["per_step_mean"] == 0
+    # the PMC summary the roofline's `traffic` is read from parses to a byte count
+    t = bench.pmc_traffic_bytes("attn_flash_kernelILi40")
+    assert t is None or (isinstance(t["bytes"], int) and t["bytes"] > 0)
