@@ -1,0 +1,68 @@
+"""Register / scratch budgets of the hot kernels, read from the hipcc listing (no GPU needed: hipcc cross-compiles gfx950).
+
+The occupancy each kernel was tuned for is a property of the BUILD, and a refactor can silently lose it (a spill inside
+the flash loop cost 2.7x once): two waves per SIMD need <= 256 VGPRs, four need <= 128, and the
+SD-1.5 shapes (head dims 40 / 80, K = 320 / 640) must not touch scratch memory."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "fresco_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only"]
+# per-file flags of fresco_amd/csrc/Makefile
+EXTRA = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"], "proj.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
+def _listing(src, tmp_path):
+    out = str(tmp_path / (src + ".s"))
+    subprocess.run([HIPCC] + BASE + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", out], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    kernels = {}
+    for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:", open(out).read(), re.S):
+        blk = m.group(0)
+        g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)  # noqa: E731
+        kernels[g("name")] = dict(vgpr=int(g("vgpr_count")), agpr=int(g("agpr_count")), spill=int(g("vgpr_spill_count")),
+                                  scratch=int(g("private_segment_fixed_size")))
+    return kernels
+
+
+def _one(kernels, pattern):
+    hits = [(n, k) for n, k in kernels.items() if re.search(pattern, n)]
+    assert len(hits) == 1, (pattern, [n for n, _ in hits])
+    return hits[0][1]
+
+
+pytestmark = pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not found")
+
+
+def test_flash_and_projection_kernels_fit_two_waves_per_simd(tmp_path):
+    k = _listing("attn.hip", tmp_path)
+    for pat in (r"attn_flash_kernelILi40ELi2E", r"attn_flash_kernelILi80ELi1E"):  # up_blocks.3 / up_blocks.2
+        r = _one(k, pat)
+        assert r["vgpr"] + r["agpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+    k = _listing("proj.hip", tmp_path)
+    for pat in (r"linear_kernelILi320ELi8E", r"linear_kernelILi640ELi8E"):
+        r = _one(k, pat)
+        assert r["vgpr"] + r["agpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+
+
+def test_gram_and_sv_kernels_fit_four_waves_per_simd(tmp_path):
+    k = _listing("opt.hip", tmp_path)
+    for pat in (r"gram16w_kernel", r"sv16b_kernelILi256ELi2E"):  # launch_bounds(512, 4): 16 waves per CU
+        r = _one(k, pat)
+        assert r["vgpr"] + r["agpr"] <= 128 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+    r = _one(k, r"adam_update_kernel")
+    assert r["spill"] == 0 and r["scratch"] == 0, r
+
+
+def test_temporal_kernels_do_not_spill(tmp_path):
+    k = _listing("temporal.hip", tmp_path)
+    for pat in (r"temporal_mfma_kernelILi40ELi1E", r"temporal_mfma_kernelILi80ELi1E", r"temporal_mfma_kernelILi40ELi2E",
+                r"temporal_mfma_kernelILi80ELi2E"):
+        r = _one(k, pat)
+        assert r["spill"] == 0 and r["scratch"] == 0, (pat, r)
