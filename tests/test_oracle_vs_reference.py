@@ -123,3 +123,19 @@ def test_optimize_feature_one_and_three_iterations(ref, C, h, seed):
             # L1 losses + Adam: a sign flip at a near-tie moves single elements by up to lr per iteration; the bulk agrees
             err = (got - want).abs()
             assert float(err.median()) < 1e-5 and float((err > 1e-3).float().mean()) < 0.01 * iters
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_adain_dilate_and_forward_backward_check(ref, seed):
+    dh, fu, geo, ut = ref
+    v = _video(4, 32, seed)
+    g = v["g"]
+    with torch.no_grad():
+        a, b = torch.randn(6, 7, 9, 5, generator=g), 2.0 * torch.randn(6, 7, 9, 5, generator=g) + 0.5
+        assert _maxdiff(O.adain(a, b), ut.adaptive_instance_normalization(a, b)) < 2e-5
+        for k in (7, 13):
+            m = (torch.rand(3, 1, 32, 32, generator=g) < 0.05).float()
+            assert torch.equal(O.dilate(m, k), ut.Dilate(kernel_size=k, device="cpu")(m))
+        fo, bo = geo.forward_backward_consistency_check(v["fwd"], v["bwd"])
+        fo2, bo2 = O.fb_consistency_check(v["fwd"], v["bwd"])
+        assert torch.equal(fo2.float(), fo.float()) and torch.equal(bo2.float(), bo.float())
