@@ -101,7 +101,11 @@ def test_processor(ref, heads, C, seed, mode):
             kw = dict(fwd_map=fm[:, 0], tmask=tm[:, 0])
         want = proc(attn, hs)
         got = O.fresco_attention(hs, W[0], W[1], W[2], W[3], torch.zeros(C), heads, **kw)
+        # the op-for-op port that bench.py times as `torch_gpu_baseline` (the "reference PyTorch path")
+        from oracle import torch_path as TP
+        got_tp = TP.processor_call(hs, W[0], W[1], W[2], W[3], torch.zeros(C), heads, **kw)
     assert _maxdiff(got, want) < 1e-4 * max(1.0, float(want.abs().max()))
+    assert _maxdiff(got_tp, want) < 1e-4 * max(1.0, float(want.abs().max()))
 
 
 @pytest.mark.parametrize("C,h,seed", [(12, 8, 9), (8, 6, 10)])
