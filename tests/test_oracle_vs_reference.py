@@ -127,6 +127,11 @@ def test_optimize_feature_one_and_three_iterations(ref, C, h, seed):
             # L1 losses + Adam: a sign flip at a near-tie moves single elements by up to lr per iteration; the bulk agrees
             err = (got - want).abs()
             assert float(err.median()) < 1e-5 and float((err > 1e-3).float().mean()) < 0.01 * iters
+            # the autograd + Adam port that bench.py times as cfg3's `torch_gpu_baseline`: the reference's own op sequence
+            from oracle import torch_opt_path as TOP
+            got_tp = TOP.optimize_feature(x, fl, oc, corr, iters=iters)
+            err = (got_tp - want).abs()
+            assert float(err.median()) < 1e-5 and float((err > 1e-3).float().mean()) < 0.01 * iters
 
 
 @pytest.mark.parametrize("seed", [11, 12])
