@@ -890,6 +890,10 @@ __global__ __launch_bounds__(256) void gram16_kernel(const half_t* __restrict__ 
     };
     const int nk = (C + GK16 - 1) / GK16;
     load(0, rgA);
+// Experiment switch (the product builds 0): chunk-major enumeration of gram16w_kernel's sign-tile stores
+#ifndef FRESCO_GRAM_FLUSH2
+#define FRESCO_GRAM_FLUSH2 0
+#endif
 #ifndef FRESCO_GRAM_ABL
 #define FRESCO_GRAM_ABL 0
 #endif
@@ -1062,7 +1066,14 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
     auto flush = [&](int r0, int c0) {
         __syncthreads();
         for (int i = tid; i < GT * (GT / 16); i += 512) {
+#if FRESCO_GRAM_FLUSH2
+            // experiment: in the pre-tiled sign layout the 128 rows x 32 bytes of one column chunk are 4 KB CONTIGUOUS;
+            // enumerate them chunk-major so that a wave's store is one 1 KB run instead of 32 runs of 32 bytes
+            const int rl = s_tiled ? (i % (2 * GT)) / 2 : i / (GT / 16);
+            const int ch = s_tiled ? (i / (2 * GT)) * 2 + (i & 1) : i % (GT / 16);
+#else
             const int rl = i / (GT / 16), ch = i % (GT / 16);
+#endif
             const int gp = r0 + rl, gq = c0 + ch * 16;
             const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
                                        : ((int64_t)b * hw + gp) * hw + gq;

@@ -23,6 +23,8 @@
 #   w4b2pf4     both
 #   adam2/adam4 opt.hip   -DFRESCO_ADAM_NOCT=2 / 4    adam_update: 2 / 4 channel octets per thread (the pixel's CSR rows are
 #                                                   fetched once per thread, not once per octet)
+#   gflush2     opt.hip   -DFRESCO_GRAM_FLUSH2=1      gram16w: sign-tile stores enumerated chunk-major (1 KB runs per wave store
+#                                                   in the pre-tiled layout instead of 32-byte runs)
 TAG=${1:-r}
 OUT=$PWD/gpurun_out/ab_$TAG.txt
 mkdir -p gpurun_out fresco_amd/lib/variants fresco_amd/csrc/build_var
@@ -61,6 +63,7 @@ build w4b2 proj.hip "$PR" "-DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2"
 build w4b2pf4 proj.hip "$PR" "-DFRESCO_PROJ_NWV=4 -DFRESCO_PROJ_NBUF=2 -DFRESCO_PROJ_PF=4"
 build adam2 opt.hip "" "-DFRESCO_ADAM_NOCT=2"
 build adam4 opt.hip "" "-DFRESCO_ADAM_NOCT=4"
+build gflush2 opt.hip "" "-DFRESCO_GRAM_FLUSH2=1"
 run() {  # name command...
   local name=$1; shift
   local lib=""
@@ -96,10 +99,10 @@ linear)
     run $v python -m pytest tests/test_gpu_linear.py -q -x -p no:cacheprovider
   done ;;
 opt)
-  for v in base adam2 adam4; do
+  for v in base adam2 adam4 gflush2; do
     run $v python tools/bench_opt.py 20 --no-baselines
   done
-  for v in adam2 adam4; do
+  for v in adam2 adam4 gflush2; do
     run $v python -m pytest tests/test_gpu_opt.py -q -x -p no:cacheprovider
   done ;;
 esac; done
