@@ -90,37 +90,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static inline int ntiles_of(int M) { return (M + 63) / 64; }
 
-// Ablation switch for tools/attn_abl.hip (timing experiments only, results are wrong; the product builds 0):
-// 1 = no exp / cvt, 2 = no MFMAs, 5 = no DMA, no vmcnt wait (barrier kept), 6 = no LDS fragment reads,
-// 7 = no barrier at all (and no DMA)
-#ifndef FRESCO_ABL
-#define FRESCO_ABL 0
-#endif
-#ifndef FRESCO_PRIO_M
-#define FRESCO_PRIO_M 1
-#endif
-// Experiment switch (the product builds 0): 1 = group B (waves 4-7, the later-dispatched half, which loses the VALU
-// arbitration at the head of its post-barrier softmax segment) runs the whole key loop at s_setprio 1 and nobody flips
-// priorities per segment (MI355X_MICROARCH.md, "static priority for the younger half")
-#ifndef FRESCO_PRIO_STATIC
-#define FRESCO_PRIO_STATIC 0
-#endif
-// Experiment switch (the product builds 0): request the first key packs before the Q rows are loaded
-#ifndef FRESCO_EARLY_DMA
-#define FRESCO_EARLY_DMA 0
-#endif
-// Experiment switch (the product builds 0): 1 = one workgroup per CU walks its query blocks in a loop (no dispatch gap
-// between rounds); 2 = as 1, and the next block's first two key packs and Q rows are requested BEFORE the current
-// block's epilogue, so that the prologue's memory burst (every CU fetching ~100 KB at once, ~5 us per round) runs
-// under the epilogue and is spread out instead of repeating in lock-step every round
-#ifndef FRESCO_PERSIST
-#define FRESCO_PERSIST 0
-#endif
-// Experiment switch (the product builds 0): 16-byte epilogue stores via v_permlane32_swap pairs
-#ifndef FRESCO_EPI_WIDE
-#define FRESCO_EPI_WIDE 0
-#endif
-
 // ---------------------------------------------------------------------------------------------
 // pack: grid (nT, H, G), 256 threads
 // ---------------------------------------------------------------------------------------------
@@ -250,57 +219,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
     constexpr int ROWS = 256 * QB;  // query rows per workgroup
 
     const int nQblk = (Lq + ROWS - 1) / ROWS;
-#if FRESCO_PERSIST
-    // (experiment scaffolding: the body below is the loop body, left at its indentation)
-    const unsigned nblk = (unsigned)(H * nQblk * B);
-#if FRESCO_PERSIST == 2
-    half8_t qf[QB][Cfg::NKS];  // Q fragments, requested one block ahead
-    const int p_lane = threadIdx.x & 63, p_wave = threadIdx.x >> 6;
-    const int p_wave_s = __builtin_amdgcn_readfirstlane(p_wave);
-    auto request_block = [&](unsigned blk_) __attribute__((always_inline)) {
-        const int h_ = blk_ % H, qblk_ = (blk_ / H) % nQblk, b_ = blk_ / (H * nQblk), g_ = b_ / batch_per_group;
-        {   // key packs 0 and 1 -> ring slots 3 and 0
-            const int many_e = p_wave_s < (Cfg::NP % 8) ? 1 : 0;
-            const uint32_t lds0_e =
-                __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
-            const char* sp = img + (int64_t)(g_ * H + h_) * (nT + 1) * Cfg::TILE;
-            const uint32_t lane_off_e = (p_wave * 64 + p_lane) * 16;
-#pragma unroll
-            for (int pk = 0; pk < 2; ++pk) {
-                const uint32_t dstb = lds0_e + (pk == 0 ? 3 : 0) * Cfg::TILE + p_wave_s * 1024;
-                const char* spp = sp + (int64_t)pk * Cfg::TILE;
-#pragma unroll
-                for (int i = 0; i < (Cfg::NP + 7) / 8; ++i) {
-                    if (i < Cfg::NP / 8 || many_e) {
-                        const uint32_t m0v = dstb + i * 8192;
-                        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off_e), "s"(spp), "s"(m0v)
-                                     : "memory");
-                        spp += 8192;
-                    }
-                }
-            }
-        }
-        const int qrow0_ = qblk_ * ROWS + p_wave * 32 * QB + (p_lane & 31);
-#pragma unroll
-        for (int j = 0; j < QB; ++j) {
-            const int qr = qrow0_ + 32 * j;
-            const half_t* qp = q + ((int64_t)b_ * Lq + (qr < Lq ? qr : Lq - 1)) * q_ld + h_ * D;
-#pragma unroll
-            for (int ks = 0; ks < Cfg::NKS; ++ks) {
-                const int d0 = ks * 16 + (p_lane >> 5) * 8;
-                half8_t t = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (d0 < D) t = *reinterpret_cast<const half8_t*>(qp + d0);
-                qf[j][ks] = t;
-            }
-        }
-    };
-    request_block(blockIdx.x);
-#endif
-    for (unsigned blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-#else
     const unsigned blk = blockIdx.x;
-    {
-#endif
     const int h = blk % H;
     const int qblk = (blk / H) % nQblk;
     const int b = blk / (H * nQblk);
@@ -314,47 +233,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int grpB = wave_s >= 4 ? 1 : 0;  // (flags are ints from scalar values: the branches on them stay scalar)
 
-#if FRESCO_EARLY_DMA && FRESCO_PERSIST != 2
-    // experiment: the first two key packs (all that the first step reads) are requested BEFORE the Q rows and the
-    // key-norm table are loaded (they depend on indices only), so that the two memory latencies of the prologue overlap
-    // and the packs are first in the queues.  The compiler's own vmcnt waits for the Q loads then also cover these
-    // (older) DMA requests: conservative; the ring's first counted wait still finds packs 2 and 3 as the newest requests.
-    {
-        const int many_e = wave_s < (Cfg::NP % 8) ? 1 : 0;
-        const uint32_t lds0_e =
-            __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
-        const char* src_e = img + (int64_t)(g * H + h) * (nT + 1) * Cfg::TILE;
-        const uint32_t lane_off_e = (wave * 64 + lane) * 16;
-        auto stage_e = [&](int p, int slot) __attribute__((always_inline)) {
-            const char* sp = src_e + (int64_t)p * Cfg::TILE;
-            const uint32_t dstb = lds0_e + slot * Cfg::TILE + wave_s * 1024;
-#pragma unroll
-            for (int i = 0; i < (Cfg::NP + 7) / 8; ++i) {
-                if (i < Cfg::NP / 8 || many_e) {
-                    const uint32_t m0v = dstb + i * 8192;
-                    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off_e), "s"(sp), "s"(m0v)
-                                 : "memory");
-                    sp += 8192;
-                }
-            }
-        };
-        stage_e(0, 3);  // what the first step needs; packs 2 and 3 follow the Q loads at their usual place
-        stage_e(1, 0);
-    }
-#endif
     // Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
-#if FRESCO_PERSIST == 2
-    float q2[QB];  // (qf was requested by request_block, one block ahead)
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-        q2[j] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < Cfg::NKS; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) q2[j] = fmaf((float)qf[j][ks][e], (float)qf[j][ks][e], q2[j]);
-        q2[j] += __shfl_xor(q2[j], 32, 64);
-    }
-#else
     half8_t qf[QB][Cfg::NKS];
     float q2[QB];  // |q|^2 of this lane's query
 #pragma unroll
@@ -373,7 +252,6 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         }
         q2[j] += __shfl_xor(q2[j], 32, 64);
     }
-#endif
 
     // Cauchy-Schwarz: every logit of this lane's query is bounded by |q| max|k| (max|k|^2 per key tile comes
     // from kv_pack).  Two per-wave decisions hang on it:
@@ -495,19 +373,14 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int j = 0; j < QB; ++j) {
-                    if (FRESCO_ABL == 2)
-                        s[j][kb][ks] += (float)kf[kb][ks][0] * (float)qf[j][ks][1];
-                    else
-                        s[j][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[j][ks], s[j][kb], 0, 0, 0);
+                    s[j][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[j][ks], s[j][kb], 0, 0, 0);
                 }
     };
 
     // ---- prologue: packs 0 .. 3 in flight (pack p = step p-1, slot (p+3) & 3), packs 0 and 1 landed,
     // S^T of tile 0 computed
-#if !FRESCO_EARLY_DMA && FRESCO_PERSIST != 2
     stage(0, 3);
     stage(1, 0);
-#endif
     if (nT > 1) stage(2, 1);
     if (nT > 2) stage(3, 2);
     wait_barrier(nT > 2 ? 2 : (nT > 1 ? 1 : 0));
@@ -541,10 +414,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         const int exact = !folded;
         // barrier u: pack u+2 (step u+1) has landed for everyone; its predecessor's slot takes pack u+4
         auto ring_sync = [&]() __attribute__((always_inline)) {
-            if (FAST && FRESCO_ABL == 7) {
-            } else if (FAST && FRESCO_ABL == 5) {
-                asm volatile("s_barrier" ::: "memory");
-            } else if (FAST) {
+            if (FAST) {
                 ring_wait_barrier<NPW_LO>();  // (waves with an extra piece per pack wait for one piece more)
                 stage(u + 4, (u + 3) & 3);
             } else {
@@ -563,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
             for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
                 for (int db = 0; db < Cfg::NDB; ++db)
-                    vf[kc][db] = (FAST && FRESCO_ABL == 6) ? qf[0][0] : *reinterpret_cast<const half8_t*>(vb_ + (kc * 2 * Cfg::DPV + db * 32) * 16);
+                    vf[kc][db] = *reinterpret_cast<const half8_t*>(vb_ + (kc * 2 * Cfg::DPV + db * 32) * 16);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -635,14 +505,6 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    if (FRESCO_ABL == 1) {
-                        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-                        const half2_t hp = __builtin_bit_cast(half2_t, __builtin_bit_cast(uint32_t, s[j][kb][r]) ^
-                                                                           __builtin_bit_cast(uint32_t, s[j][kb][r + 1]));
-                        pf[j][kb * 2 + (r >> 3)][r & 7] = hp[0];
-                        pf[j][kb * 2 + (r >> 3)][(r & 7) + 1] = hp[1];
-                        continue;
-                    }
                     const float p0 = __builtin_amdgcn_exp2f(s[j][kb][r]);
                     const float p1 = __builtin_amdgcn_exp2f(s[j][kb][r + 1]);
                     if (!Cfg::ONES) psum += p0 + p1;
@@ -662,18 +524,13 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
 
         // ---- K fragments of tile u+1 (same pack), in flight under the PV MFMAs
         half8_t kf[2][Cfg::NKS];
-        if (FAST && FRESCO_ABL == 6) {
-#pragma unroll
-            for (int ks = 0; ks < Cfg::NKS; ++ks) kf[0][ks] = kf[1][ks] = qf[0][ks];
-        } else if (!LAST) {
-            read_k(kf, slot);
-        }
+        if (!LAST) read_k(kf, slot);
         __builtin_amdgcn_sched_barrier(0);
 
         // The MFMA block runs at raised priority: against a partner wave in its softmax, an MFMA wave that loses the
         // issue arbitration (it does when it is the younger one) leaves the matrix pipe idle between MFMAs
         // (tools/ubench_rates.hip: 28 MFMAs beside a prioritised exp/cvt stream take 1590 cycles instead of 900).
-        if (!FRESCO_PRIO_STATIC) __builtin_amdgcn_s_setprio(FRESCO_PRIO_M);
+        __builtin_amdgcn_s_setprio(1);
         // ---- O^T += V^T P^T  (row D of V^T is all ones when it is spare: O^T[D] = row sum)
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc)
@@ -681,19 +538,15 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
             for (int db = 0; db < Cfg::NDB; ++db)
 #pragma unroll
                 for (int j = 0; j < QB; ++j) {
-                    if (FRESCO_ABL == 2)
-                        o[j][db][kc] += (float)vf[kc][db][0] * (float)pf[j][kc][1];
-                    else
-                        o[j][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kc][db], pf[j][kc], o[j][db], 0, 0, 0);
+                    o[j][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kc][db], pf[j][kc], o[j][db], 0, 0, 0);
                 }
         __builtin_amdgcn_sched_barrier(0);
         // ---- S^T of tile u+1
         if (!LAST) qk(kf);
-        if (!FRESCO_PRIO_STATIC) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    if (FRESCO_PRIO_STATIC && grpB) __builtin_amdgcn_s_setprio(1);
     const std::integral_constant<bool, true> yes;
     const std::integral_constant<bool, false> no_last, no;
     const std::integral_constant<bool, true> fast;
@@ -716,13 +569,6 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         step(u, yes, no);
     }
 
-#if FRESCO_PERSIST
-    // every wave is past its last fragment reads before the ring is refilled (by the next block's prologue, or here)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if FRESCO_PERSIST == 2
-    if (blk + gridDim.x < nblk) request_block(blk + gridDim.x);
-#endif
-#endif
     // ---- epilogue: normalise, store O[q][h*D + d] -------------------------------------------------
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
@@ -736,8 +582,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
         }
         const float inv = 1.f / l_tot;
         const int qr = qrow0 + 32 * j;
-#if FRESCO_EPI_WIDE
-        // experiment: a row's 8-column groups sit split over the two half-waves (lane l31: columns 8k .. 8k+3, lane
+        // A row's 8-column groups sit split over the two half-waves (lane l31: columns 8k .. 8k+3, lane
         // l31 + 32: 8k+4 .. 8k+7).  One v_permlane32_swap per dword of a PAIR of groups leaves lanes 0-31 with the 16
         // contiguous bytes of group k and lanes 32-63 with those of group k+1: one 16-byte store per pair instead of
         // two 8-byte ones (the store tail of a row-per-lane epilogue is bound by store instructions, not bytes).
@@ -767,25 +612,7 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
                     }
                 }
         }
-#else
-        if (qr < Lq) {
-            half_t* op = out + ((int64_t)b * Lq + qr) * C + h * D;
-#pragma unroll
-            for (int db = 0; db < Cfg::NDB; ++db)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int d0 = db * 32 + g4 * 8 + hi * 4;
-                    if (d0 < D) {
-                        half4_t w;
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) w[jj] = (half_t)(o[j][db][g4 * 4 + jj] * inv);
-                        *reinterpret_cast<half4_t*>(op + d0) = w;
-                    }
-                }
-        }
-#endif
     }
-    }  // block loop (FRESCO_PERSIST) / scope
 }
 
 template <int D, int QB>
@@ -799,15 +626,7 @@ static void launch_flash(const half_t* q, const char* img, half_t* out, int B, i
     const int nQblk = (Lq + 256 * QB - 1) / (256 * QB);
     const float log2e = 1.4426950408889634f;
     ProfScope ps(FRESCO_PROF_ATTN_FLASH, B * H, Lq, M, D, st);
-    int grid = H * nQblk * B;
-#if FRESCO_PERSIST
-    {
-        int dev = 0, ncu = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (grid > ncu) grid = ncu;
-    }
-#endif
+    const int grid = H * nQblk * B;
     hipLaunchKernelGGL((attn_flash_kernel<D, QB>), dim3(grid), dim3(512), Cfg::LDS_BYTES, st, q, img,
                        ktmax, out, B, H, Lq, M, nT, B / n_groups, scale * log2e, diag_bias * log2e, q_ld);
 }

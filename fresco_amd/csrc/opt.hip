@@ -890,19 +890,12 @@ __global__ __launch_bounds__(256) void gram16_kernel(const half_t* __restrict__ 
     };
     const int nk = (C + GK16 - 1) / GK16;
     load(0, rgA);
-// Experiment switch (the product builds 0): chunk-major enumeration of gram16w_kernel's sign-tile stores
-#ifndef FRESCO_GRAM_FLUSH2
-#define FRESCO_GRAM_FLUSH2 0
-#endif
-#ifndef FRESCO_GRAM_ABL
-#define FRESCO_GRAM_ABL 0
-#endif
     for (int kc = 0; kc + 1 < nk; ++kc) {
-        if (!(FRESCO_GRAM_ABL & 1)) store(rgA);  // the previous chunk's LDS reads are behind the barrier that ended the last iteration
-        if (!(FRESCO_GRAM_ABL & 2)) __syncthreads();
-        if (!(FRESCO_GRAM_ABL & 1)) load((kc + 1) * GK16, rgA);
+        store(rgA);  // the previous chunk's LDS reads are behind the barrier that ended the last iteration
+        __syncthreads();
+        load((kc + 1) * GK16, rgA);
         compute();
-        if (!(FRESCO_GRAM_ABL & 2)) __syncthreads();
+        __syncthreads();
     }
     store(rgA);
     __syncthreads();
@@ -1019,7 +1012,7 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int kc = 0; kc < nk; ++kc) {
-        if ((!(FRESCO_GRAM_ABL & 1) || kc == 0) && kc + 1 < nk) stage(kc + 1, (kc + 1) & 1);
+        if (kc + 1 < nk) stage(kc + 1, (kc + 1) & 1);
         const char* L = &lds2[kc & 1][0];
 #pragma unroll
         for (int ks = 0; ks < GK16 / 16; ++ks) {
@@ -1066,22 +1059,15 @@ __global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restric
     auto flush = [&](int r0, int c0) {
         __syncthreads();
         for (int i = tid; i < GT * (GT / 16); i += 512) {
-#if FRESCO_GRAM_FLUSH2
-            // experiment: in the pre-tiled sign layout the 128 rows x 32 bytes of one column chunk are 4 KB CONTIGUOUS;
-            // enumerate them chunk-major so that a wave's store is one 1 KB run instead of 32 runs of 32 bytes
-            const int rl = s_tiled ? (i % (2 * GT)) / 2 : i / (GT / 16);
-            const int ch = s_tiled ? (i / (2 * GT)) * 2 + (i & 1) : i % (GT / 16);
-#else
             const int rl = i / (GT / 16), ch = i % (GT / 16);
-#endif
             const int gp = r0 + rl, gq = c0 + ch * 16;
             const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
                                        : ((int64_t)b * hw + gp) * hw + gq;
             *reinterpret_cast<uint4*>(sgn_out + so) = *reinterpret_cast<const uint4*>(tr + rl * TRS + ch * 16);
         }
     };
-    if (!(FRESCO_GRAM_ABL & 4) || lsum == 12345.f) flush(p0, q0);
-    if (mirror && (!(FRESCO_GRAM_ABL & 4) || lsum == 12345.f)) {
+    flush(p0, q0);
+    if (mirror) {
         __syncthreads();
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -1184,12 +1170,9 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
     load(0);
     store(0);
     __syncthreads();
-#ifndef FRESCO_SV_ABL
-#define FRESCO_SV_ABL 0  // timing experiments only: 1 = no staging of the next chunk, 2 = no barriers
-#endif
     for (int kc = 0; kc < nk; ++kc) {
-        const int st = (FRESCO_SV_ABL & 1) ? 0 : (kc & 1);
-        if (!(FRESCO_SV_ABL & 1) && kc + 1 < nk) load((kc + 1) * SK);
+        const int st = kc & 1;
+        if (kc + 1 < nk) load((kc + 1) * SK);
         const char* ah = &lds[st][0][0];
         const char* al = &lds[st][1][0];
         const char* bs = &lds[st][2][0];
@@ -1211,8 +1194,8 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (!(FRESCO_SV_ABL & 1) && kc + 1 < nk) store(st ^ 1);
-        if (!(FRESCO_SV_ABL & 2)) __syncthreads();
+        if (kc + 1 < nk) store(st ^ 1);
+        __syncthreads();
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -1342,7 +1325,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
         // the slot of chunk kc - 1 takes chunk kc + NS - 1
-        if ((!(FRESCO_SV_ABL & 1) || kc == 0) && kc + NS - 1 < nk) stage(kc + NS - 1, slot >= 1 ? slot - 1 : NS - 1);
+        if (kc + NS - 1 < nk) stage(kc + NS - 1, slot >= 1 ? slot - 1 : NS - 1);
         const char* base = sb_smem + slot * SB_SLOT;
 #pragma unroll
         for (int ks = 0; ks < SB_K / 16; ++ks) {
@@ -1372,8 +1355,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if ((!(FRESCO_SV_ABL & 2) || kc < 2) && kc + 1 < nk)
-            wait_barrier(((FRESCO_SV_ABL & 1) && kc > 0) || NS == 2 ? 0 : (kc + 2 < nk ? 1 : 0));
+        if (kc + 1 < nk) wait_barrier(NS == 2 ? 0 : (kc + 2 < nk ? 1 : 0));
         slot = slot == NS - 1 ? 0 : slot + 1;
     }
 #pragma unroll
@@ -1398,11 +1380,6 @@ struct AdamArgs {
     float beta1, beta2, step_size, bc2_sqrt, eps;
 };
 
-// Experiment switch (the product builds 1): channel octets per thread of adam_update_kernel
-#ifndef FRESCO_ADAM_NOCT
-#define FRESCO_ADAM_NOCT 1
-#endif
-
 __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs, float* __restrict__ m,
                                                            float* __restrict__ v2, TGradArgs tg,
                                                            const float* __restrict__ vt,
@@ -1413,25 +1390,6 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
                                                            AdamArgs a) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= hw) return;
-#if FRESCO_ADAM_NOCT > 1
-    // experiment: one thread walks FRESCO_ADAM_NOCT channel octets of its pixel, so that the pixel's CSR rows and
-    // occlusion factors (28 loads, the same for every channel) are fetched once per NOCT octets instead of once per octet
-    const int b = blockIdx.z, C8 = (C + ECPT - 1) / ECPT;
-    float dot = 0.f, inv_n = 0.f, n = 1.f;
-    if (has_s) {
-        for (int s = 0; s < S; ++s) dot += part[((int64_t)b * S + s) * hw + p];
-        n = nrm[(int64_t)b * hw + p];
-        inv_n = 1.f / n;
-    }
-    TGradPixel tp;
-    if (has_t) tp.init(tg, b, p, hw);
-    for (int oc = 0; oc < FRESCO_ADAM_NOCT; ++oc) {
-    const int c8 = blockIdx.y * FRESCO_ADAM_NOCT + oc;
-    if (c8 >= C8) break;
-    const int c0 = c8 * ECPT, cend = min(c0 + ECPT, C);
-    float tgv[ECPT] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (has_t) tp.values(tg, c8, p, C8, hw, tgv);
-#else
     const int b = blockIdx.z, c0 = blockIdx.y * ECPT, cend = min(c0 + ECPT, C);
     float dot = 0.f, inv_n = 0.f, n = 1.f;
     if (has_s) {
@@ -1446,7 +1404,6 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
         tp.init(tg, b, p, hw);
         tp.values(tg, blockIdx.y, p, gridDim.y, hw, tgv);
     }
-#endif
     for (int c = c0; c < cend; ++c) {
         const int64_t o = ((int64_t)b * C + c) * hw + p;
         float g = tgv[c - c0];
@@ -1463,9 +1420,6 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
             cs[o] = x - a.step_size * (mm / denom);
         }
     }
-#if FRESCO_ADAM_NOCT > 1
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1600,8 +1554,7 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
     }
     static_assert(OCPT == ECPT, "the temporal gradient is evaluated on the elementwise grid");
     const TGradArgs tg = {w.sgn1, w.sgn2, bwd_occ, fwd_occ, w.rowptr, w.src, w.wgt, L, kscale};
-    const dim3 agrid(egrid.x, (egrid.y + FRESCO_ADAM_NOCT - 1) / FRESCO_ADAM_NOCT, egrid.z);
-    hipLaunchKernelGGL(adam_update_kernel, agrid, dim3(256), 0, st, cs, w.m, w.v, tg,
+    hipLaunchKernelGGL(adam_update_kernel, egrid, dim3(256), 0, st, cs, w.m, w.v, tg,
                        v_stored ? w.vt : (const float*)nullptr, w.dvt, w.nrm, w.part, gout, C, hw, S, has_t, has_s, mode,
                        a);
 }

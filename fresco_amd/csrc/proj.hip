@@ -22,17 +22,6 @@
 // so that a store instruction writes whole 128-byte lines (16-byte pieces of 32 rows each: +4 us).
 #include "common.h"
 
-// Ablation switch for tools/proj_abl.hip (timing experiments only; the product builds 0):
-// bit mask: 1 = no output stores, 2 = no weight DMA after the first slab (no vmcnt waits), 4 = no MFMAs, 8 = no LDS
-// fragment reads
-#ifndef FRESCO_PROJ_ABL
-#define FRESCO_PROJ_ABL 0
-#endif
-// Experiment switch (the product builds 0): read the weight fragments of a step this many MFMAs ahead of their use
-#ifndef FRESCO_PROJ_PF
-#define FRESCO_PROJ_PF 0
-#endif
-
 namespace fresco {
 
 template <int K, int NWV>
@@ -47,10 +36,7 @@ struct ProjCfg {
     static constexpr int NP = (TF * CPR + 63) / 64;  // 1 KiB DMA pieces per slab (the last one is partly pad)
     static constexpr int NPW_LO = NP / NWV, NPW_HI = (NP + NWV - 1) / NWV, NREM = NP % NWV;
     static constexpr int SLOT = NPW_HI * NWV * 1024;  // LDS bytes per ring slot
-#ifndef FRESCO_PROJ_NBUF
-#define FRESCO_PROJ_NBUF 3
-#endif
-    static constexpr int NBUF = FRESCO_PROJ_NBUF;  // ring slots: slabs are staged NBUF - 1 steps ahead
+    static constexpr int NBUF = 3;  // ring slots: slabs are staged NBUF - 1 steps ahead
     static constexpr int RING_BYTES = NBUF * SLOT;
     // epilogue: a wave's 32 x 64 output tile is transposed through LDS so that every store instruction writes whole
     // 128-byte lines (8 lanes per row); rows padded to 144 B (conflict-free ds_write_b128 of 16 rows)
@@ -180,11 +166,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
 #pragma unroll
         for (int kc = 0; kc < Cfg::NKC; ++kc, ++s) {
             const int slot2 = slot >= 1 ? slot - 1 : Cfg::NBUF - 1;  // the slot of step s-1 takes the slab of step s+AHEAD
-            if (!(FRESCO_PROJ_ABL & 2) && s + AHEAD < nsteps) stage(s + AHEAD, slot2);
+            if (s + AHEAD < nsteps) stage(s + AHEAD, slot2);
             const char* wr = smem + slot * Cfg::SLOT + frow * Cfg::ROWB + hi * Cfg::KC;  // hi * (KC/2) halfs
-#if FRESCO_PROJ_PF > 0
-            {   // experiment: weight fragments read FRESCO_PROJ_PF MFMAs ahead (hipcc's own schedule is read -> wait(0) -> MFMA)
-                constexpr int NFR = Cfg::KS * 2, PF = FRESCO_PROJ_PF < NFR ? FRESCO_PROJ_PF : NFR;
+            {   // weight fragments are read PF MFMAs ahead of their use (hipcc's own schedule is read -> wait(0) -> MFMA per
+                // fragment; r03: 60.7 -> 55.6 us for the L3 q,k,v launch, profiles/r03_ab_variants.txt)
+                constexpr int NFR = Cfg::KS * 2, PF = 4;
                 half8_t fr[NFR];
 #pragma unroll
                 for (int i = 0; i < PF; ++i)
@@ -204,22 +190,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);  // and the last PF MFMAs
             }
-#else
-#pragma unroll
-            for (int ks = 0; ks < Cfg::KS; ++ks)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const half8_t a = (FRESCO_PROJ_ABL & 8) ? xf[(ks + t) % Cfg::NXF]
-                                                           : *reinterpret_cast<const half8_t*>(wr + t * 32 * Cfg::ROWB + ks * 16);
-                    if (FRESCO_PROJ_ABL & 4)
-                        acc[t][ks & 1][ks] += (float)a[0] * (float)xf[kc * Cfg::KS + ks][1];
-                    else
-                        acc[t][ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[kc * Cfg::KS + ks], acc[t][ks & 1], 0, 0, 0);
-                }
-#endif
-            if (FRESCO_PROJ_ABL & 2) {
-                asm volatile("s_barrier" ::: "memory");
-            } else if (s + 1 < nsteps) {
+            if (s + 1 < nsteps) {
                 wait_barrier(min(nsteps - 2 - s, AHEAD - 1));  // slabs newer than s+1 that exist
             }
             slot = slot == Cfg::NBUF - 1 ? 0 : slot + 1;
@@ -245,7 +216,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
                 for (int e = 0; e < 8; ++e) w[e] = (half_t)(acc[t][0][half * 8 + e] + acc[t][1][half * 8 + e] + bv[e]);
                 *reinterpret_cast<half8_t*>(scr + l31 * Cfg::OROW + ((t * 2 + half) * 2 + hi) * 16) = w;
             }
-        if (!(FRESCO_PROJ_ABL & 1) || acc[0][0][0] == 12345.f) {
+        {
             const int row0 = blockIdx.x * (NWV * 32) + wave * 32;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -307,12 +278,8 @@ static int linear_dispatch(const void* x, int64_t x_ld, const int32_t* x_rows, c
     half_t* o0 = static_cast<half_t*>(out0);
     half_t* o1 = static_cast<half_t*>(out1);
     half_t* o2 = static_cast<half_t*>(out2);
-#ifndef FRESCO_PROJ_NWV
-#define FRESCO_PROJ_NWV 8
-#endif
-    if (K == 320)
-        return launch_linear<320, FRESCO_PROJ_NWV>(xh, x_ld, x_rows, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
-    return launch_linear<640, FRESCO_PROJ_NWV>(xh, x_ld, x_rows, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
+    if (K == 320) return launch_linear<320, 8>(xh, x_ld, x_rows, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
+    return launch_linear<640, 8>(xh, x_ld, x_rows, wh, bh, o0, o1, o2, ld0, ld1, ld2, nw, M, N, st);
 }
 
 extern "C" int fresco_linear(const void* x, int64_t x_ld, const void* W0, const void* W1, const void* W2,

@@ -175,10 +175,6 @@ def test_processor_reference_golden_kat7(golden, mode):
     _check(out, ref, atol=1e-3, rtol=2e-3, what="KAT7 " + mode)
 
 
-# (written when the round's GPU budget was spent: not yet run on a GPU, so it is opt-in until it has been --
-# FRESCO_TEST_QUEUED=1 python -m pytest tests -m gpu -k decoder_head_dims; the oracle side of the same goldens runs in
-# tests/test_oracle_golden.py)
-@pytest.mark.skipif(os.environ.get("FRESCO_TEST_QUEUED") != "1", reason="queued: first GPU run pending")
 @pytest.mark.parametrize("heads", [2, 1])
 @pytest.mark.parametrize("mode", ["full", "cf_temporal", "cf"])
 def test_processor_reference_golden_decoder_head_dims(headdim_golden, heads, mode):
