@@ -41,59 +41,17 @@
 //
 // MFMA 32x32x16 f16 operand layout (gfx950): lane l supplies 8 consecutive k for row/col (l & 31), k-chunk
 // (l >> 5); C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = 0..15.
-#include "common.h"
+#include "attn_cfg.h"
 #include <type_traits>
 
 namespace fresco {
 
-template <int D>
-struct AttnCfg {
-    static constexpr int DPK = (D + 15) / 16 * 16;  // head dim padded for the QK^T contraction
-    static constexpr int DPV = (D + 31) / 32 * 32;  // head dim padded to whole 32-row blocks of O^T
-    static constexpr int NKS = DPK / 16;            // MFMA k-steps per QK^T block
-    static constexpr int NDB = DPV / 32;            // 32-row blocks of O^T
-    // LDS / packed image of one 64-key tile, in 16-byte chunks (8 halfs):
-    //   K  : chunk ((ks*2 + c)*64 + key)   = K[key][ks*16 + c*8 .. +8]                     (c = MFMA k-chunk)
-    //   V^T: chunk ((kc*2 + c)*DPV + d)    = V[kc*16 + slot(c, e)][d],  e = 0..7           (kc = 16-key MFMA step)
-    //        slot(c, e) = (e & 3) + 8*(e >> 2) + 4*c: the order in which a lane's C-tile registers hold the keys
-    // A 16-lane ds_read_b128 group reads 16 different keys (or 16 different d) at a chunk stride of 1 and one
-    // c: conflict-free without padding.
-    static constexpr int KTILE = DPK * 128;  // bytes
-    static constexpr int VTILE = DPV * 128;
-    static constexpr int TILE = KTILE + VTILE;
-    static constexpr int NP = TILE / 1024;  // 1 KiB DMA pieces per tile
-    static constexpr int NBUF = 4;          // ring slots
-    static constexpr int LDS_BYTES = NBUF * TILE;
-    static constexpr bool ONES = DPV > D;  // spare V^T row D holds ones: the PV MFMA also yields the row sum
-    static constexpr bool MCOL = DPK > D;  // spare K column D holds ones: Q column D carries -m_run, so the
-                                           // QK MFMA subtracts the running max (no C operand to keep around)
-};
-
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// (the three thresholds take -D overrides for A/B measurements: make DEFS=-DFOLD_MAX=...; tools/flash_regime.py
-// restates the two per-wave decisions on the CPU)
-// online softmax: skip the O rescale while the tile max grows by less than this (log2 units);
-// P then reaches at most 2^8 = 256, far inside fp16 range, and stays exactly normalised by the row sum
-#ifndef RESCALE_THR
-#define RESCALE_THR 8.0f
-#endif
-// no running max at all when |c q| max|k| - m_run stays below this (P <= 2^14 = 16384 < 65504)
-#ifndef NOMAX_THR
-#define NOMAX_THR 14.0f
-#endif
-// largest |exponent| (log2 units) for which the scale is folded into the fp16 Q
-#ifndef FOLD_MAX
-#define FOLD_MAX 16.0f
-#endif
-
-static inline int ntiles_of(int M) { return (M + 63) / 64; }
-
 // ---------------------------------------------------------------------------------------------
-// pack: grid (nT, H, G), 256 threads
+// pack: grid (nT, H, G), 256 threads.  Pack p of the image = K fragments of tile p || V^T fragments of tile p - LAG:
+// what ONE loop step of the consuming kernel reads (LAG 1: attn_flash_kernel below, PV(u) next to QK(u+1); LAG 2:
+// attn_pipe_kernel of attnp.hip, PV(t-1) next to QK(t+1)); nT + LAG packs.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int LAG>
 __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__ k,
                                                        const half_t* __restrict__ v,
                                                        const int32_t* __restrict__ kv_rows,
@@ -130,9 +88,7 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
     }
     __syncthreads();
 
-    // pack p of the image = K fragments of tile p ‖ V^T fragments of tile p-1: what one loop step of the flash
-    // kernel reads (O^T += V^T P^T of tile p-1, S^T of tile p); nT + 1 packs
-    char* dst = img + ((int64_t)(g * H + h) * (nT + 1) + tile) * Cfg::TILE;
+    char* dst = img + ((int64_t)(g * H + h) * (nT + LAG) + tile) * Cfg::TILE;
     // K chunks
     for (int c = threadIdx.x; c < Cfg::NKS * 128; c += 256) {
         const int key = c & 63, d0 = (c >> 6) * 8;
@@ -157,7 +113,7 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
                 val = (half_t)1;  // ones row: only real keys count towards the softmax denominator
             o[e] = val;
         }
-        *reinterpret_cast<half8_t*>(dst + Cfg::TILE + Cfg::KTILE + (int64_t)c * 16) = o;
+        *reinterpret_cast<half8_t*>(dst + LAG * Cfg::TILE + Cfg::KTILE + (int64_t)c * 16) = o;
     }
     // largest squared key norm of the tile (four threads per key, fixed summation order): the flash kernel
     // bounds every logit of a query by |q| max|k| (Cauchy-Schwarz) and drops the running-max search when
@@ -639,12 +595,21 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
     using Cfg = AttnCfg<D>;
     const int nT = ntiles_of(M);
     char* img = ws;
-    float* ktmax = reinterpret_cast<float*>(ws + align_up((size_t)n_groups * H * (nT + 1) * Cfg::TILE, 256));
+    const bool pipe = attn_pipe_supported(D, nT, diag_bias);
+    float* ktmax = reinterpret_cast<float*>(ws + align_up((size_t)n_groups * H * (nT + 2) * Cfg::TILE, 256));
     dim3 pg(nT, H, n_groups);
     {
         ProfScope ps(FRESCO_PROF_KV_PACK, n_groups, H, M, D, st);
-        hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, img, ktmax, H, M, nT,
-                           group_rows, kv_ld);
+        if (pipe)
+            hipLaunchKernelGGL((kv_pack_kernel<D, 2>), pg, dim3(256), 0, st, k, v, kv_rows, img, ktmax, H, M, nT,
+                               group_rows, kv_ld);
+        else
+            hipLaunchKernelGGL((kv_pack_kernel<D, 1>), pg, dim3(256), 0, st, k, v, kv_rows, img, ktmax, H, M, nT,
+                               group_rows, kv_ld);
+    }
+    if (pipe) {
+        const int rc = launch_attn_pipe(q, img, ktmax, out, B, H, Lq, M, nT, n_groups, scale, q_ld, D, st);
+        return rc != FRESCO_OK ? rc : check_launch();
     }
     // Two query blocks (64 rows) per wave while the accumulators leave room (two waves per SIMD = 256
     // registers each): every K / V^T fragment read from LDS then feeds two (four) MFMAs.
@@ -658,7 +623,7 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
 static size_t attn_ws_bytes(int n_groups, int H, int M, int D) {
     const size_t nT = ntiles_of(M);
     const size_t dpk = (D + 15) / 16 * 16, dpv = (D + 31) / 32 * 32;
-    return align_up((size_t)n_groups * H * (nT + 1) * ((dpk + dpv) * 128), 256) +
+    return align_up((size_t)n_groups * H * (nT + 2) * ((dpk + dpv) * 128), 256) +
            align_up((size_t)n_groups * H * nT * sizeof(float), 256);
 }
 

@@ -1,0 +1,53 @@
+// Shared configuration of the dense-attention kernels (attn.hip: the 8-wave ping-pong kernel and the key-pack
+// kernel; attnp.hip: the software-pipelined one-wave-per-SIMD kernel).  Not part of the public ABI.
+#pragma once
+#include "common.h"
+
+namespace fresco {
+
+template <int D>
+struct AttnCfg {
+    static constexpr int DPK = (D + 15) / 16 * 16;  // head dim padded for the QK^T contraction
+    static constexpr int DPV = (D + 31) / 32 * 32;  // head dim padded to whole 32-row blocks of O^T
+    static constexpr int NKS = DPK / 16;            // MFMA k-steps per QK^T block
+    static constexpr int NDB = DPV / 32;            // 32-row blocks of O^T
+    // LDS / packed image of one 64-key tile, in 16-byte chunks (8 halfs):
+    //   K  : chunk ((ks*2 + c)*64 + key)   = K[key][ks*16 + c*8 .. +8]                     (c = MFMA k-chunk)
+    //   V^T: chunk ((kc*2 + c)*DPV + d)    = V[kc*16 + slot(c, e)][d],  e = 0..7           (kc = 16-key MFMA step)
+    //        slot(c, e) = (e & 3) + 8*(e >> 2) + 4*c: the order in which a lane's C-tile registers hold the keys
+    // A 16-lane ds_read_b128 group reads 16 different keys (or 16 different d) at a chunk stride of 1 and one
+    // c: conflict-free without padding.
+    static constexpr int KTILE = DPK * 128;  // bytes
+    static constexpr int VTILE = DPV * 128;
+    static constexpr int TILE = KTILE + VTILE;
+    static constexpr int NP = TILE / 1024;  // 1 KiB DMA pieces per tile
+    static constexpr int NBUF = 4;          // ring slots
+    static constexpr int LDS_BYTES = NBUF * TILE;
+    static constexpr bool ONES = DPV > D;  // spare V^T row D holds ones: the PV MFMA also yields the row sum
+    static constexpr bool MCOL = DPK > D;  // spare K column D holds ones: Q column D carries -m_run, so the
+                                           // QK MFMA subtracts the running max (no C operand to keep around)
+};
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// (tools/flash_regime.py restates the two per-wave decisions these thresholds drive on the CPU)
+// online softmax: skip the O rescale while the tile max grows by less than this (log2 units);
+// P then reaches at most 2^8 = 256, far inside fp16 range, and stays exactly normalised by the row sum
+constexpr float RESCALE_THR = 8.0f;
+// no running max at all when |c q| max|k| - m_run stays below this (P <= 2^14 = 16384 < 65504)
+constexpr float NOMAX_THR = 14.0f;
+// largest |exponent| (log2 units) for which the scale is folded into the fp16 Q
+constexpr float FOLD_MAX = 16.0f;
+
+static inline int ntiles_of(int M) { return (M + 63) / 64; }
+
+// attnp.hip: software-pipelined flash kernel (D = 40, no diagonal bias, >= PIPE_MIN_TILES key tiles).  Consumes packs
+// with LAG = 2 (pack p = K fragments of tile p || V^T fragments of tile p - 2).  Returns FRESCO_OK after launching.
+constexpr int PIPE_NBUF = 8, PIPE_LEAD = 6;  // ring slots of the pipelined kernel; pack t + LEAD is requested in step t
+constexpr int PIPE_MIN_TILES = 6;
+bool attn_pipe_supported(int D, int nT, float diag_bias);
+int launch_attn_pipe(const half_t* q, const char* img, const float* ktmax, half_t* out, int B, int H, int Lq, int M,
+                     int nT, int n_groups, float scale, int64_t q_ld, int D, hipStream_t st);
+
+}  // namespace fresco

@@ -11,9 +11,11 @@ not read):
      occluded tokens of the other frames (controller.attn_mask, src/diffusion_hacked.py:935-938).  Frame 0's fused
      K|V rows are BROADCAST from their owner; the other frames' selected rows are compacted per rank, padded
      to the largest rank's count (the mask is replicated, so every rank knows the counts) and ALL-GATHERED.
-     Both land in one (chunk, HW + world*Rmax, 2C) buffer whose rows the kernel addresses through the
-     remapped row table of `cf_plan` -- no re-layout pass after the collectives.  At 8 x 512^2 on 8 GPUs a
-     rank receives 10.5 MB + 0.1 MB per up_blocks.3 call instead of the 73 MB of an all-gather of every
+     Both land in one (HW + world*Rmax, chunk, 2C) buffer -- the CFG halves side by side in a row, so that frame 0's
+     rows of BOTH halves are one contiguous block (ONE broadcast) and the ranks' selected rows another (ONE
+     all-gather): two collectives per layer call.  The kernel addresses the buffer through the remapped row table of
+     `cf_plan` (row t of half c = flat row t*chunk + c) -- no re-layout pass after the collectives.  At 8 x 512^2 on
+     8 GPUs a rank receives 10.5 MB + 0.1 MB per up_blocks.3 call instead of the 73 MB of an all-gather of every
      frame's K|V.  The collectives are launched right after the K / V projection and overlap the spatial pass.
   2. temporal-guided pass (`temporal`): sharded by TRAJECTORY, not by frame.  fresco_temporal_pack gathers the
      local frames' q | k | v rows along the trajectories into per-destination ranges, an ALL-TO-ALL delivers
@@ -30,6 +32,8 @@ frame chain is a scan over frames and is not sharded (replicas).
 
 The index arithmetic lives in plain functions so that it is testable on CPU (gloo, world_size 2).
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -156,36 +160,53 @@ class FrameShard:
         return out
 
     def cf_plan(self, mask, HW, device):
-        """cached `cf_plan` of a mask tensor (or None) for this rank, index tensors on `device`"""
-        key = ("none", HW) if mask is None else (mask.data_ptr(), tuple(mask.shape), mask._version)
+        """cached `cf_plan` of a mask tensor (or None) for this rank, index tensors on `device`.  Adds the flat
+        addressing of the exchange buffer: `kv_table` = table * chunk with `kv_group_rows` = 1 (row t of CFG half c
+        is flat row t*chunk + c of the (rows, chunk, 2C) buffer).  The cache entry holds a weak reference to the mask:
+        the pipeline builds a new mask per keyframe batch and the allocator may hand back an old address."""
+        device = torch.device(device)
+        key = ("none", HW, str(device)) if mask is None else (mask.data_ptr(), tuple(mask.shape), mask._version, str(device))
         hit = self._rows_cache.get(key)
-        if hit is None:
+        if hit is None or (mask is not None and hit["mask_ref"]() is not mask):
             if len(self._rows_cache) > 16:
                 self._rows_cache.clear()
             hit = cf_plan(mask, self.N, HW, self.world, self.rank)
             hit["table"] = hit["table"].to(device)
+            hit["kv_table"] = (hit["table"] * self.chunk).to(torch.int32)
+            hit["kv_group_rows"] = 1
             hit["local_sel"] = hit["local_sel"].to(device)
+            hit["mask_ref"] = weakref.ref(mask) if mask is not None else None
             self._rows_cache[key] = hit
         return hit
 
+    def _global_rank(self, group_rank):
+        """rank inside `self.group` -> global rank (what dist.broadcast's `src` means)"""
+        if self.group is None or not dist.is_initialized():
+            return group_rank
+        return dist.get_global_rank(self.group, group_rank)
+
     def exchange_cf(self, kv_loc, plan):
-        """kv_loc: this rank's fused K|V rows (chunk*n_loc, HW, 2C).  Starts the broadcast of frame 0's rows and the
-        all-gather of the other frames' selected rows into one (chunk, HW + world*Rmax, 2C) buffer; returns
-        (buffer, [works]) -- wait on the works before the kernel reads the buffer."""
+        """kv_loc: this rank's fused K|V rows (chunk*n_loc, HW, 2C).  Starts ONE broadcast (frame 0's rows of both CFG
+        halves) and ONE all-gather (every rank's selected rows of its other frames) into a (HW + world*Rmax, chunk, 2C)
+        buffer; returns (buffer, [works]) -- wait on the works before the kernel reads the buffer through
+        plan["kv_table"] / plan["kv_group_rows"]."""
         Bl, HW, C2 = kv_loc.shape
         Rmax = plan["Rmax"]
-        buf = torch.empty(self.chunk, HW + self.world * Rmax, C2, dtype=kv_loc.dtype, device=kv_loc.device)
+        buf = torch.empty(HW + self.world * Rmax, self.chunk, C2, dtype=kv_loc.dtype, device=kv_loc.device)
         x = kv_loc.view(self.chunk, self.n_loc, HW, C2)
         works = []
-        if self.rank == 0:  # frame 0 lives on rank 0
-            buf[:, :HW].copy_(x[:, 0])
-        for c in range(self.chunk):
-            works.append(self.broadcast(buf[c, :HW], src=0, async_op=True))
+        if self.rank == 0:  # frame 0 lives on the group's rank 0
+            buf[:HW].copy_(x[:, 0].transpose(0, 1))
+        works.append(self.broadcast(buf[:HW], src=self._global_rank(0), async_op=True))
         if Rmax > 0:
             mine = x.reshape(self.chunk, self.n_loc * HW, C2).index_select(1, plan["local_sel"])  # (chunk, Rmax, 2C)
-            for c in range(self.chunk):
-                works.append(self.all_gather_into(buf[c, HW:], mine[c], async_op=True))
+            works.append(self.all_gather_into(buf[HW:], mine.transpose(0, 1).contiguous(), async_op=True))
         return buf, [w for w in works if w is not None]
+
+    # collectives one layer call issues (bench.py reports the count per step)
+    @staticmethod
+    def cf_collectives(plan):
+        return 1 + (1 if plan["Rmax"] > 0 else 0)
 
     def temporal(self, q, k, v, fwd_map, mask, heads, scale):
         """trajectory-sharded temporal-guided pass: q, k, v local (chunk*n_loc, HW, C); returns the local rows"""

@@ -13,6 +13,7 @@ the controller interaction are the reference's; the data 
     `to_out[0]` at C = 320) when they are plain nn.Linear modules; wrapped modules keep their forward.
 """
 import math
+import warnings
 import weakref
 
 import torch
@@ -89,9 +90,21 @@ class FRESCOAttnProcessor2_0:
         if hit is None or (mask is not None and hit[0]() is not mask):
             base = (torch.arange(hw, device=device) if mask is None else self._kv_rows(mask, as_long=True).to(device))
             rows = torch.cat([base + c * n_frames * hw for c in range(chunk)]).to(torch.int32).contiguous()
+            # the table is handed to fresco_linear_rows unchecked on every later call: check it once, here
+            if rows.numel() and not (0 <= int(rows.min()) and int(rows.max()) < chunk * n_frames * hw):
+                raise ValueError("fresco_amd: cross-frame mask of shape %s addresses tokens outside the (%d, %d, %d) batch"
+                                 % (tuple(mask.shape), chunk, n_frames, hw))
             hit = (weakref.ref(mask) if mask is not None else None, rows)
             self._rows_cache[key] = hit
         return hit[1]
+
+    def _warn_rounding(self, dtype):
+        """fp32 / bf16 pipelines: said once per processor (values beyond +-65504 would become inf in the fp16 kernels)"""
+        if not getattr(self, "_warned_rounding", False):
+            self._warned_rounding = True
+            warnings.warn("fresco_amd: %s activations are rounded to fp16 for the attention kernels and the result is "
+                          "cast back (the reference computes in the input dtype); |q|, |k|, |v| must stay below 65504"
+                          % dtype, RuntimeWarning, stacklevel=3)
 
     def _cf_mask(self, ctrl, hw):
         """the cross-frame key mask of this feature scale (None: every frame attends to frame 0 only)"""
@@ -157,6 +170,7 @@ class FRESCOAttnProcessor2_0:
         # to fp16 after the projections and the result is cast back: same HIP path, no eager branch
         out_dtype = query.dtype
         if out_dtype != torch.float16:
+            self._warn_rounding(out_dtype)
             query, key, value = query.half(), key.half(), value.half()
 
         heads = attn.heads
@@ -223,8 +237,9 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
     other frames' selected rows; temporal pass: all-to-all to trajectory shards and back; the rest is local."""
     if input_ndim != 3:
         raise NotImplementedError("fresco_amd: frame-sharded attention expects (B, HW, C) hidden states")
-    if hidden_states.dtype != torch.float16:
-        raise TypeError("fresco_amd: frame-sharded attention expects fp16 hidden states (got %s)" % hidden_states.dtype)
+    out_dtype = hidden_states.dtype
+    if out_dtype != torch.float16:  # same policy as the single-GPU path: modules in their dtype, kernels in fp16
+        self._warn_rounding(out_dtype)
     ctrl, sh = self.controller, self.shard
     chunk = self.unet_chunk_size
     heads = attn.heads
@@ -234,8 +249,8 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
     sm_scale = 1.0 / math.sqrt(head_dim)
     assert B_loc == sh.B_loc and chunk == sh.chunk
     # q, k, v in one pass over the hidden states; K and V land fused per row (K | V), the layout of the exchange
-    query = torch.empty(B_loc, hw, C, dtype=hidden_states.dtype, device=hidden_states.device)
-    kv_loc = torch.empty(B_loc, hw, 2 * C, dtype=hidden_states.dtype, device=hidden_states.device)
+    query = torch.empty(B_loc, hw, C, dtype=torch.float16, device=hidden_states.device)
+    kv_loc = torch.empty(B_loc, hw, 2 * C, dtype=torch.float16, device=hidden_states.device)
     key, value = kv_loc[..., :C], kv_loc[..., C:]
     self._project(attn, hidden_states, ("to_q", "to_k", "to_v"), outs=[query, key, value])
     works = []
@@ -253,6 +268,8 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
         ref = ctrl(None)
         assert ref.shape == hidden_states.shape
         q_ref, k_ref = self._project(attn, ref, ("to_q", "to_k"))
+        if q_ref.dtype != torch.float16:
+            q_ref, k_ref = q_ref.half(), k_ref.half()
         q_att = ops.attention(q_ref, k_ref, query, heads,
                               ctrl.intraattn_scale_factor * sm_scale, diag_bias=float(ctrl.intraattn_bias),
                               workspace=self._ws)
@@ -260,8 +277,8 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
         w.wait()
     if ctrl.use_cfattn:
         flat = kvbuf.view(-1, 2 * C)
-        hs = ops.attention(q_att, flat[:, :C], flat[:, C:], heads, sm_scale, kv_rows=plan["table"],
-                           n_groups=chunk, M=plan["M"], group_rows=plan["group_rows"], workspace=self._ws)
+        hs = ops.attention(q_att, flat[:, :C], flat[:, C:], heads, sm_scale, kv_rows=plan["kv_table"],
+                           n_groups=chunk, M=plan["M"], group_rows=plan["kv_group_rows"], workspace=self._ws)
     else:
         hs = ops.attention(q_att, key, value, heads, sm_scale, workspace=self._ws)
     if ctrl.use_interattn:
@@ -275,7 +292,7 @@ def _sharded_self_attention(self, attn, hidden_states, residual, input_ndim):
             raise ValueError("fresco_amd: no temporal-attention parameters for %d tokens" % hw)
         hs = sh.temporal(query, key, hs, fwd_mapping, interattn_mask, heads,
                          ctrl.interattn_scale_factor * sm_scale)
-    hs = self._project_out(attn, hs.to(query.dtype))
+    hs = self._project_out(attn, hs.to(out_dtype))
     hs = attn.to_out[1](hs)
     if attn.residual_connection:
         hs = hs + residual
@@ -293,8 +310,8 @@ def apply_FRESCO_attn(pipe):
 
     Narrower than the reference on purpose (there is no eager fallback behind the HIP kernels): the processor takes
     CUDA hidden states and computes the attention in fp16 (the dtype run_fresco.py runs the UNet in, :63-80): fp32 /
-    bf16 activations are rounded to fp16 after the projections and the result is cast back (frame-sharded runs: fp16
-    only); and no `attention_mask` (the pipeline never passes one to these layers) -- a mask raises NotImplementedError."""
+    bf16 activations are rounded to fp16 after the projections and the result is cast back (one RuntimeWarning per
+    processor; frame-sharded runs follow the same policy); and no `attention_mask` (the pipeline never passes one to these layers) -- a mask raises NotImplementedError."""
     from diffusers.models.attention_processor import AttnProcessor2_0
 
     frescoProc = FRESCOAttnProcessor2_0(2, AttentionControl())

@@ -35,8 +35,9 @@ def _worker(rank, world, port, N, chunk, HW, C, ret):
         sel = sh.local_batch_index()
         kv_loc = torch.cat((K[sel], V[sel]), dim=-1).contiguous()  # fused K|V rows, the exchange layout
         ok = True
-        # (1) sparse cross-frame exchange: broadcast of frame 0 + all-gather of the other frames' selected rows;
-        # C-ABI addressing g*group_rows + table[m] into the exchange buffer must give the reference's key rows
+        # (1) sparse cross-frame exchange: ONE broadcast of frame 0 (both CFG halves) + ONE all-gather of the other
+        # frames' selected rows; C-ABI addressing g*kv_group_rows + kv_table[m] into the flat (rows*chunk, 2C) exchange
+        # buffer must give the reference's key rows
         rows = mask.reshape(-1).nonzero().squeeze(1)
         for m_ in (mask, None):
             plan = sh.cf_plan(m_, HW, "cpu")
@@ -47,12 +48,24 @@ def _worker(rank, world, port, N, chunk, HW, C, ret):
             want_rows = rows if m_ is not None else torch.arange(HW)
             assert plan["M"] == want_rows.numel()
             for grp in range(chunk):
-                got = flat[grp * plan["group_rows"] + plan["table"].long()]
+                got = flat[grp * plan["kv_group_rows"] + plan["kv_table"].long()]
                 ok &= torch.equal(got[:, :C], K.view(chunk, N * HW, C)[grp, want_rows])
                 ok &= torch.equal(got[:, C:], V.view(chunk, N * HW, C)[grp, want_rows])
             # what crosses the fabric: frame 0 once + the padded selected rows, not every frame
             n_rest = int(mask[1:].sum()) if m_ is not None else 0
-            assert buf.shape[1] <= HW + world * max(n_rest, 1) and buf.shape[1] < N * HW
+            assert buf.shape[0] <= HW + world * max(n_rest, 1) and buf.shape[0] < N * HW
+            assert sh.cf_collectives(plan) == (2 if plan["Rmax"] > 0 else 1)
+        # a NEW mask object at a recycled address must not hit the cached plan of the old one
+        m1 = mask.clone()
+        p1 = sh.cf_plan(m1, HW, "cpu")
+        addr = m1.data_ptr()
+        m1.copy_(~mask | (torch.arange(N).view(N, 1) == 0))   # same storage, new contents: _version differs -> rebuilt
+        p2 = sh.cf_plan(m1, HW, "cpu")
+        ok &= p2 is not p1 and p2["M"] == int(m1.sum())
+        fake = dict(p2)
+        fake["mask_ref"] = lambda: None                        # entry whose mask object died: same key, other tensor
+        sh._rows_cache[(addr, tuple(m1.shape), m1._version, "cpu")] = fake
+        ok &= sh.cf_plan(m1, HW, "cpu") is not fake
         # (2) the all-to-all that turns frame shards into trajectory shards and back (the pack / unpack kernels are
         # emulated with index arithmetic here; the kernels themselves are checked on the GPU)
         fwd = torch.stack([torch.randperm(HW, generator=g) for _ in range(N)])

@@ -32,6 +32,9 @@ class ThreadShard:
     def cf_plan(self, *a):
         return self._base.cf_plan(*a)
 
+    def _global_rank(self, r):
+        return r
+
     def all_gather(self, x, async_op=False):
         return torch.stack([t.contiguous() for t in self._exchange(x.contiguous())], 0), None
 
@@ -57,14 +60,22 @@ class ThreadShard:
         return FrameShard.temporal(self, *a)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+# (world, N, which frames keep their occlusion tokens in the cross-frame mask): 8 ranks x 1 frame is the node the
+# driver runs (rank 0 owns nothing but frame 0); "f1" leaves the last rank without a single selected token (its slab of
+# the all-gather is padding only); "f0" selects frame 0 alone (no all-gather at all, one broadcast)
+@pytest.mark.parametrize("world,N,keep", [(2, 4, "all"), (4, 4, "all"), (8, 8, "all"), (2, 4, "f1"), (4, 8, "f0")])
 @pytest.mark.parametrize("mode", ["cf", "cf_temporal", "full", "temporal"])
-def test_sharded_processor_equals_single_gpu(world, mode):
+def test_sharded_processor_equals_single_gpu(world, N, keep, mode):
     import fresco_amd
     from fresco_amd.dist import FrameShard
 
-    N = 4
+    if keep != "all" and mode == "temporal":
+        pytest.skip("the mask variants only touch the cross-frame pass")
     case = synth.make_attention_case(N, 128, "L3", seed=4)
+    if keep == "f1":
+        case["cf_mask"][2:] = False
+    elif keep == "f0":
+        case["cf_mask"][1:] = False
     attn = copy.deepcopy(case["attn"]).to(DEV).half()
     hidden = case["hidden"].to(DEV)
     with torch.no_grad():

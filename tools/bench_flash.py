@@ -1,6 +1,6 @@
 """Kernel-only timing of the cross-frame / spatial attention launches (HIP events from fresco_prof_*):
 cfg2 up_blocks.3 (HW=4096, D=40) and up_blocks.2 (HW=1024, D=80), small-M and block-occlusion large-M masks.
-usage: python tools/bench_flash.py [reps] [gain]    (gain scales q and k: 1.0 = N(0,1) per channel, logit bound ~19 log2
+usage: python tools/bench_flash.py [reps] [gain] [case]    (gain scales q and k: 1.0 = N(0,1) per channel, logit bound ~19 log2
 units, the exact-scale regime; 0.3 = small logits, the regime of the headline bench)"""
 import ctypes, math, os, sys
 import torch
@@ -9,6 +9,7 @@ from fresco_amd import ops, _lib
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 gain = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+only = sys.argv[3] if len(sys.argv) > 3 else None   # e.g. "spatial40": one (label, D) case
 lib = _lib.load()
 g = torch.Generator().manual_seed(0)
 N, chunk, H = 8, 2, 8
@@ -18,6 +19,8 @@ for (HW, C, D) in ((4096, 320, 40), (1024, 640, 80)):
     k = (gain * torch.randn(B, HW, C, generator=g)).half().cuda()
     v = torch.randn(B, HW, C, generator=g).half().cuda()
     for label, p in (("small-M", 0.004), ("large-M", 0.5), ("spatial", None)):
+        if only and only != "%s%d" % (label, D):
+            continue
         if p is None:
             kw = dict(n_groups=B, M=HW, group_rows=HW)
             scale = 0.2 / math.sqrt(D)
