@@ -47,11 +47,10 @@
 namespace fresco {
 
 // ---------------------------------------------------------------------------------------------
-// pack: grid (nT, H, G), 256 threads.  Pack p of the image = K fragments of tile p || V^T fragments of tile p - LAG:
-// what ONE loop step of the consuming kernel reads (LAG 1: attn_flash_kernel below, PV(u) next to QK(u+1); LAG 2:
-// attn_pipe_kernel of attnp.hip, PV(t-1) next to QK(t+1)); nT + LAG packs.
+// pack: grid (nT, H, G), 256 threads.  Pack p of the image = K fragments of tile p || V^T fragments of tile p - 1: what
+// ONE loop step of attn_flash_kernel reads (PV(u) next to QK(u+1)); nT + 1 packs.
 // ---------------------------------------------------------------------------------------------
-template <int D, int LAG>
+template <int D>
 __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__ k,
                                                        const half_t* __restrict__ v,
                                                        const int32_t* __restrict__ kv_rows,
@@ -88,7 +87,7 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
     }
     __syncthreads();
 
-    char* dst = img + ((int64_t)(g * H + h) * (nT + LAG) + tile) * Cfg::TILE;
+    char* dst = img + ((int64_t)(g * H + h) * (nT + 1) + tile) * Cfg::TILE;
     // K chunks
     for (int c = threadIdx.x; c < Cfg::NKS * 128; c += 256) {
         const int key = c & 63, d0 = (c >> 6) * 8;
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
                 val = (half_t)1;  // ones row: only real keys count towards the softmax denominator
             o[e] = val;
         }
-        *reinterpret_cast<half8_t*>(dst + LAG * Cfg::TILE + Cfg::KTILE + (int64_t)c * 16) = o;
+        *reinterpret_cast<half8_t*>(dst + Cfg::TILE + Cfg::KTILE + (int64_t)c * 16) = o;
     }
     // largest squared key norm of the tile (four threads per key, fixed summation order): the flash kernel
     // bounds every logit of a query by |q| max|k| (Cauchy-Schwarz) and drops the running-max search when
@@ -595,21 +594,12 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
     using Cfg = AttnCfg<D>;
     const int nT = ntiles_of(M);
     char* img = ws;
-    const bool pipe = attn_pipe_supported(D, nT, diag_bias);
-    float* ktmax = reinterpret_cast<float*>(ws + align_up((size_t)n_groups * H * (nT + 2) * Cfg::TILE, 256));
+    float* ktmax = reinterpret_cast<float*>(ws + align_up((size_t)n_groups * H * (nT + 1) * Cfg::TILE, 256));
     dim3 pg(nT, H, n_groups);
     {
         ProfScope ps(FRESCO_PROF_KV_PACK, n_groups, H, M, D, st);
-        if (pipe)
-            hipLaunchKernelGGL((kv_pack_kernel<D, 2>), pg, dim3(256), 0, st, k, v, kv_rows, img, ktmax, H, M, nT,
-                               group_rows, kv_ld);
-        else
-            hipLaunchKernelGGL((kv_pack_kernel<D, 1>), pg, dim3(256), 0, st, k, v, kv_rows, img, ktmax, H, M, nT,
-                               group_rows, kv_ld);
-    }
-    if (pipe) {
-        const int rc = launch_attn_pipe(q, img, ktmax, out, B, H, Lq, M, nT, n_groups, scale, q_ld, D, st);
-        return rc != FRESCO_OK ? rc : check_launch();
+        hipLaunchKernelGGL((kv_pack_kernel<D>), pg, dim3(256), 0, st, k, v, kv_rows, img, ktmax, H, M, nT, group_rows,
+                           kv_ld);
     }
     // Two query blocks (64 rows) per wave while the accumulators leave room (two waves per SIMD = 256
     // registers each): every K / V^T fragment read from LDS then feeds two (four) MFMAs.
@@ -623,7 +613,7 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
 static size_t attn_ws_bytes(int n_groups, int H, int M, int D) {
     const size_t nT = ntiles_of(M);
     const size_t dpk = (D + 15) / 16 * 16, dpv = (D + 31) / 32 * 32;
-    return align_up((size_t)n_groups * H * (nT + 2) * ((dpk + dpv) * 128), 256) +
+    return align_up((size_t)n_groups * H * (nT + 1) * ((dpk + dpv) * 128), 256) +
            align_up((size_t)n_groups * H * nT * sizeof(float), 256);
 }
 

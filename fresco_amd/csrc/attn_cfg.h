@@ -1,5 +1,5 @@
-// Shared configuration of the dense-attention kernels (attn.hip: the 8-wave ping-pong kernel and the key-pack
-// kernel; attnp.hip: the software-pipelined one-wave-per-SIMD kernel).  Not part of the public ABI.
+// Configuration of the dense-attention kernels of attn.hip (packed key-image geometry, softmax thresholds).  Not part of
+// the public ABI.
 #pragma once
 #include "common.h"
 
@@ -41,13 +41,5 @@ constexpr float NOMAX_THR = 14.0f;
 constexpr float FOLD_MAX = 16.0f;
 
 static inline int ntiles_of(int M) { return (M + 63) / 64; }
-
-// attnp.hip: software-pipelined flash kernel (D = 40, no diagonal bias, >= PIPE_MIN_TILES key tiles).  Consumes packs
-// with LAG = 2 (pack p = K fragments of tile p || V^T fragments of tile p - 2).  Returns FRESCO_OK after launching.
-constexpr int PIPE_NBUF = 8, PIPE_LEAD = 6;  // ring slots of the pipelined kernel; pack t + LEAD is requested in step t
-constexpr int PIPE_MIN_TILES = 6;
-bool attn_pipe_supported(int D, int nT, float diag_bias);
-int launch_attn_pipe(const half_t* q, const char* img, const float* ktmax, half_t* out, int B, int H, int Lq, int M,
-                     int nT, int n_groups, float scale, int64_t q_ld, int D, hipStream_t st);
 
 }  // namespace fresco

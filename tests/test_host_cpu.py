@@ -27,11 +27,11 @@ def test_capi_exports_every_declared_symbol():
 def test_workspace_queries_are_host_only():
     from fresco_amd import _lib
     lib = _lib.load()
-    # cfg2 up_blocks.3 cross-frame: 2 groups x 8 heads x (67 tiles + 2: the V^T half of a pack lags its K half by up
-    # to two tiles) packs of 64 keys x (48 + 64) halfs (K | V^T fragment images: head dim padded to 48 for the QK
+    # cfg2 up_blocks.3 cross-frame: 2 groups x 8 heads x (67 tiles + 1: the V^T half of a pack lags its K half by one
+    # tile) packs of 64 keys x (48 + 64) halfs (K | V^T fragment images: head dim padded to 48 for the QK
     # contraction, to 64 rows for the PV product), plus one fp32 max|k|^2 per tile; each block rounded up to 256 B
     r256 = lambda n: (n + 255) // 256 * 256
-    assert lib.fresco_attn_workspace_bytes(2, 8, 4237, 40) == r256(2 * 8 * 69 * 64 * 112 * 2) + r256(2 * 8 * 67 * 4)
+    assert lib.fresco_attn_workspace_bytes(2, 8, 4237, 40) == r256(2 * 8 * 68 * 64 * 112 * 2) + r256(2 * 8 * 67 * 4)
     assert lib.fresco_attn_workspace_bytes(0, 8, 10, 40) == 0
     full = lib.fresco_opt_workspace_bytes(2, 8, 640, 64, 64, 1, 1)
     assert full > lib.fresco_opt_workspace_bytes(2, 8, 640, 64, 64, 1, 0) > lib.fresco_opt_workspace_bytes(2, 8, 640, 64, 64, 0, 0)

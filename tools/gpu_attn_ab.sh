@@ -1,6 +1,5 @@
 #!/bin/bash
-# One GPU-box visit for the flash kernels: parity (test-suite, fuzz, full-size) of the default dispatch, then timing of
-# the pipelined kernel (attnp.hip) against the 8-wave ping-pong kernel (FRESCO_ATTN_PIPE=0) in both logit regimes.
+# One GPU-box visit for the flash kernel: parity (test-suite, fuzz, full-size), then timing in both logit regimes.
 # usage (repo root, on the box): bash tools/gpu_attn_ab.sh <tag> [quick]
 TAG=${1:-r}
 OUT=$PWD/gpurun_out/attn_ab_$TAG.txt
@@ -13,9 +12,6 @@ if [ "$2" != quick ]; then
   run python -m pytest tests/test_gpu_fullsize.py -q -x -p no:cacheprovider --tb=short -k "processor or attention"
 fi
 for gain in 0.3 1.0; do
-  for mode in 1 2 0; do   # 1 = pipelined, two waves per SIMD (default); 2 = pipelined, one wave per SIMD; 0 = ping-pong
-    echo "-- FRESCO_ATTN_PIPE=$mode" >> $OUT
-    FRESCO_ATTN_PIPE=$mode run python tools/bench_flash.py 20 $gain
-  done
+  run python tools/bench_flash.py 20 $gain
 done
 grep -E "^==|^--|^rc=|passed|failed|HW=4096|all .* cases ok|FAIL|Error|error" $OUT | cut -c1-200
