@@ -120,7 +120,9 @@ def test_attention_logit_ranges(D, qgain):
     out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, scale)
     ref = _dense_ref(q.float(), k.float(), v.float(), H, scale, list(range(B)))
     assert bool(torch.isfinite(out).all())
-    _check(out, ref, atol=3e-3, rtol=3e-3, what="qgain %g D=%d" % (qgain, D))
+    # the 1e-3 contract also in the large-logit regime (tools/fold_margin.py: the kernel's arithmetic, emulated on the CPU,
+    # stays within 0.65 of this bar on exactly these inputs, folded or exact scale; fp16 output rounding adds <= 0.25)
+    _check(out, ref, what="qgain %g D=%d" % (qgain, D))
 
 
 @pytest.mark.parametrize("D,H,N,HW", [

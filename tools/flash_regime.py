@@ -1,7 +1,7 @@
 """Which per-wave regime of attn_flash_kernel do given activations fall into?  A CPU restatement of the kernel's two
 wave-uniform decisions (fresco_amd/csrc/attn.hip, the Cauchy-Schwarz block in front of the key loop), for analysis only:
 
-  folded : scale * log2(e) * |q| * max|k| <= FOLD_MAX (16) for all 64 queries of the wave -> the scale is multiplied
+  folded : scale * log2(e) * |q| * max|k| <= FOLD_MAX (24) for all 64 queries of the wave -> the scale is multiplied
            into the fp16 Q once; otherwise every score is multiplied in fp32 (the "exact" pass, 32 v_pk_mul_f32 per
            64 x 64 block)
   nomax  : after tile 0 has anchored the reference point m, (bound - m) <= NOMAX_THR (14) for all 64 queries -> no
@@ -14,7 +14,7 @@ import sys
 
 import torch
 
-FOLD_MAX, NOMAX_THR = 16.0, 14.0
+FOLD_MAX, NOMAX_THR = 24.0, 14.0
 
 
 def regimes(q, k, scale, rows_per_wave=64):
