@@ -602,11 +602,18 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
                            kv_ld);
     }
     // Two query blocks (64 rows) per wave while the accumulators leave room (two waves per SIMD = 256
-    // registers each): every K / V^T fragment read from LDS then feeds two (four) MFMAs.
-    if constexpr (D <= 48 && Cfg::MCOL)
-        launch_flash<D, 2>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
-    else
+    // registers each): every K / V^T fragment read from LDS then feeds two (four) MFMAs.  Exception: a launch whose
+    // 512-row workgroups would leave CUs idle (a frame shard of a multi-GPU run: 2 batch rows x 8 heads x 8 query blocks
+    // = 128 workgroups for 256 CUs) takes 256-row workgroups instead -- twice as many, each half as long.
+    if constexpr (D <= 48 && Cfg::MCOL) {
+        const int grid2 = H * ((Lq + 511) / 512) * B;
+        if (Lq > 256 && grid2 < 256)
+            launch_flash<D, 1>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
+        else
+            launch_flash<D, 2>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
+    } else {
         launch_flash<D, 1>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
+    }
     return check_launch();
 }
 

@@ -86,6 +86,22 @@ def test_attention_grouped_rows_and_bias(D, H):
     _check(outb, refb, what="diag bias")
 
 
+@pytest.mark.parametrize("B,Lq,M", [(2, 1024, 300), (1, 700, 1500)])
+def test_attention_underfilled_grid_takes_small_workgroups(B, Lq, M):
+    """D = 40 launches whose 512-row workgroups would not fill the chip (the shape of a frame shard in a multi-GPU run)
+    switch to 256-row workgroups (one query block per wave): same arithmetic, other instantiation."""
+    import fresco_amd.ops as ops
+    g = synth.gen(B * 1000 + Lq)
+    H, D = 8, 40
+    C = H * D
+    q = torch.randn(B, Lq, C, generator=g).half()
+    k = torch.randn(B, M, C, generator=g).half()
+    v = torch.randn(B, M, C, generator=g).half()
+    scale = 1.0 / math.sqrt(D)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, scale)
+    _check(out, _dense_ref(q.float(), k.float(), v.float(), H, scale, list(range(B))), what="small workgroups")
+
+
 def test_attention_forced_rescale():
     """One key dominates late in the sequence: exercises the running-max rescale of every tile."""
     import fresco_amd.ops as ops

@@ -4,7 +4,7 @@
 TAG=${1:-r}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/pytest_$TAG.log 2>&1
+python -m pytest tests -m gpu -q -s --tb=short -p no:cacheprovider > $OUT/pytest_$TAG.log 2>&1
 tail -25 $OUT/pytest_$TAG.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; tail -4 $OUT/smoke_$TAG.log
 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; cat $OUT/bench_$TAG.json; tail -3 $OUT/bench_$TAG.err

@@ -12,9 +12,10 @@ P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_I
 P2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE"
 P3="FETCH_SIZE"
 P4="WRITE_SIZE"
+P5="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"   # L2 hit rate and fabric-side read requests
 i=0
-PASSES=${PASSES:-4}
-for P in "$P1" "$P2" "$P3" "$P4"; do
+PASSES=${PASSES:-5}
+for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   [ $i -ge $PASSES ] && break
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python $REPO/tools/run_attn_only.py 3 $GAIN > $OUT/pass$i.log 2>&1
