@@ -496,7 +496,8 @@ def main():
     M3 = int(params[8][3].sum())
     dom = [ms for tag, d, ms in recs if tag == 1 and d == (B_loc * 8, HW3, M3, 40)]
     roofline = None
-    pmc = pmc_traffic_bytes("attn_flash_kernelILi40")
+    # (the committed PMC passes profile the single-GPU launch: no traffic figure for a frame shard's smaller launch)
+    pmc = pmc_traffic_bytes("attn_flash_kernelILi40") if world == 1 else None
     if dom:
         flop = 4.0 * B_loc * HW3 * M3 * 320
         mean_s = sum(dom) / len(dom) * 1e-3
