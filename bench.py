@@ -440,49 +440,13 @@ def main():
             run_step(proc, ctrl, layers, mode, refs, paras, masks)
     torch.cuda.synchronize()
 
-    run = run_eager
-    run(0, args.warmup)
-    # hipGraph replay: one graph per attention mode, captured after the warm-up and replayed in the timed region -- the same
-    # kernels (and, sharded, the same RCCL collectives) without the Python / launch gaps between them.  One GPU: capture of
-    # the ctypes-launched kernels works and replay is 3 % SLOWER than eager (the step is GPU-bound, eager launches run
-    # ahead), so eager stays the default there.  N > 1: host time (0.84 ms per step) exceeds a rank's share of the kernels,
-    # so replay is the DEFAULT (FRESCO_BENCH_GRAPH=0 turns it off).  Capture with collectives inside could not be exercised
-    # on the single-GPU build boxes: if it fails on ANY rank every rank falls back to eager launches (agreed through an
-    # all-reduce) and the JSON line says so in `launch_mode`.
-    launch_mode = "eager"
-    want_graph = os.environ.get("FRESCO_BENCH_GRAPH", "1" if (world > 1 and backend == "nccl") else "0") == "1"
-    if want_graph:
-        graphs, err = {}, None
-        try:
-            with torch.no_grad():
-                for mode in sorted(set(SCHEDULE)):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        run_step(proc, ctrl, layers, mode, refs, paras, masks)
-                    graphs[mode] = g
-        except Exception as e:  # noqa: BLE001 -- any capture failure means eager
-            err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
-        torch.cuda.synchronize()
-        ok = 0.0 if err else 1.0
-        if world > 1:
-            t = torch.tensor([ok], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = float(t.item())
-        if ok == 1.0:
-            launch_mode = "hipGraph replay (one graph per attention mode)"
-
-            def run(k0, k):  # noqa: F811
-                for s in range(k0, k0 + k):
-                    graphs[SCHEDULE[s % len(SCHEDULE)]].replay()
-        else:
-            launch_mode = "eager (graph capture failed on some rank%s)" % (": " + err if err else "")
-            with torch.no_grad():  # the step once more outside any capture, so that every rank is in the same state
-                run_eager(0, 1)
+    run_eager(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    run(0, args.steps)
+    run_eager(0, args.steps)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    launch_mode = "eager"
 
     # instrumented replay of the same K steps: per-launch HIP-event durations of the dominant kernel
     cap = args.steps * 64 + 64
@@ -593,10 +557,67 @@ def main():
             res["cfg3"] = bench_opt.measure(N=N, R=R, dev=device)
         elif world == 1:
             res["cpu_baseline"] = None
+    # ---- hipGraph replay (N > 1 by default; FRESCO_BENCH_GRAPH=0 / 1 overrides): one graph per attention mode, captured
+    # after the eager measurement above and replayed over the same K steps -- the same kernels (and, sharded, the same RCCL
+    # collectives) without the Python / launch gaps between them.  One GPU: replay is 3 % SLOWER than eager (the step is
+    # GPU-bound, eager launches run ahead), hence off.  N > 1: host time (0.84 ms per step) exceeds a rank's share of the
+    # kernels.  Capture with collectives inside could not be exercised on the single-GPU build boxes, so it is fenced: the
+    # eager result is complete before it starts; a failure on ANY rank (agreed through an all-reduce) keeps the eager
+    # result; a HANG is cut by a watchdog that prints the eager line and exits.  `value` is the faster of the two modes,
+    # both timed over exactly K steps; `launch_mode` and `ms_per_step_by_mode` say what happened.
+    want_graph = os.environ.get("FRESCO_BENCH_GRAPH", "1" if (world > 1 and backend == "nccl") else "0") == "1"
+    if want_graph:
+        import threading
+
+        def bail():
+            if rank == 0:
+                res["launch_mode"] = "eager (graph capture / replay did not finish within the watchdog time)"
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(float(os.environ.get("FRESCO_BENCH_GRAPH_TIMEOUT", "120")), bail)
+        dog.daemon = True
+        dog.start()
+        graphs, err = {}, None
+        try:
+            with torch.no_grad():
+                for mode in sorted(set(SCHEDULE)):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        run_step(proc, ctrl, layers, mode, refs, paras, masks)
+                    graphs[mode] = g
+        except Exception as e:  # noqa: BLE001 -- any capture failure means eager
+            err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+        torch.cuda.synchronize()
+        ok = 0.0 if err else 1.0
+        if world > 1:
+            t = torch.tensor([ok], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = float(t.item())
+        if ok == 1.0:
+            def run_graph(k0, k):
+                for s_ in range(k0, k0 + k):
+                    graphs[SCHEDULE[s_ % len(SCHEDULE)]].replay()
+
+            run_graph(0, args.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            run_graph(0, args.steps)
+            barrier()
+            dt_g = max_over_ranks(time.perf_counter() - t0)
+            if rank == 0:
+                res["ms_per_step_by_mode"] = {"eager": round(1e3 * dt / args.steps, 4), "graph": round(1e3 * dt_g / args.steps, 4)}
+                if dt_g < dt:
+                    res["value"] = round(args.steps / dt_g, 3)
+                    res["ms_per_step"] = round(1e3 * dt_g / args.steps, 4)
+                    res["launch_mode"] = "hipGraph replay (one graph per attention mode)"
+        elif rank == 0:
+            res["launch_mode"] = "eager (graph capture failed on some rank%s)" % (": " + err if err else "")
+        dog.cancel()
+    if rank == 0:
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
-
 
 if __name__ == "__main__":
     main()
