@@ -327,15 +327,19 @@ def test_processor_4d_input_residual_rescale_groupnorm():
     x = torch.randn(B, C, h, w, generator=g).half()
     proc = fresco_amd.FRESCOAttnProcessor2_0(2, fresco_amd.AttentionControl())
     with torch.no_grad():
-        out = proc(copy.deepcopy(attn).to(DEV).half(), x.to(DEV))
-        xs = x.float().view(B, C, h * w).transpose(1, 2)
-        xn = attn.group_norm(xs.transpose(1, 2)).transpose(1, 2)
+        attn_dev = copy.deepcopy(attn).to(DEV).half()
+        out = proc(attn_dev, x.to(DEV))
+        # the group norm in front of the attention is the MODULE's own (PyTorch, fp16 on the GPU), not part of the path under
+        # test: the oracle starts from its fp16 output, so that the bar below measures the HIP path alone
+        xs16 = x.to(DEV).view(B, C, h * w).transpose(1, 2)
+        xn = attn_dev.group_norm(xs16.transpose(1, 2)).transpose(1, 2).float().cpu()
         W = [p.detach().float() for p in attn.weights()]
         core = O.fresco_attention(xn, W[0], W[1], W[2], W[3], attn.to_out[0].bias.detach().float(), heads,
                                   round_dtype=torch.float16)
         ref = (core.transpose(-1, -2).reshape(B, C, h, w) + x.float()) / 2.0
     assert out.shape == (B, C, h, w) and out.dtype == torch.float16
-    _check(out, ref, atol=3e-3, rtol=3e-3, what="4-D / residual / rescale")
+    # (residual add and 1/rescale run in fp16 on values up to ~4: rtol covers that output grid)
+    _check(out, ref, atol=1e-3, rtol=2e-3, what="4-D / residual / rescale")
 
 
 def test_processor_rejects_unsupported_inputs():
