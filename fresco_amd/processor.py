@@ -106,6 +106,60 @@ class FRESCOAttnProcessor2_0:
                           "cast back (the reference computes in the input dtype); |q|, |k|, |v| must stay below 65504"
                           % dtype, RuntimeWarning, stacklevel=3)
 
+    # ---- attention_mask (reference :192-196, 303-305) ---------------------------------------------------------------
+    # The pipeline never passes one to these layers (src/pipe_FRESCO.py:201-209), so this is a plain-speed side path with NO
+    # kernel of its own: an additive per-(batch, head, key) bias b is an extra contraction dimension --
+    # [q, 1/scale] . [k, b] * scale = q.k * scale + b -- so q, k, v are padded to the next head dim the flash kernel
+    # supports, column D carries 1/scale resp. the bias, and the ordinary kernel runs.
+    _HEAD_DIMS = (8, 16, 32, 40, 64, 80, 96, 128)
+
+    def _mask_bias(self, attn, attention_mask, seq_len, batch_size):
+        """-> additive bias (B, heads, Lk) fp32 from the mask forms the reference accepts: whatever
+        `attn.prepare_attention_mask` returns ((B*heads, 1, Lk), reference :193), or a (B, Lk) / (B, 1, Lk) tensor;
+        bool masks mean "attend where True".  Query-dependent masks are not supported."""
+        m = attention_mask
+        if hasattr(attn, "prepare_attention_mask"):
+            m = attn.prepare_attention_mask(m, seq_len, batch_size)
+            m = m.view(batch_size, attn.heads, -1, m.shape[-1])
+        else:
+            if m.dim() == 2:
+                m = m[:, None, None, :]
+            elif m.dim() == 3:
+                m = m[:, None, :, :]
+            m = m.expand(batch_size, attn.heads, m.shape[-2], m.shape[-1])
+        if m.shape[2] != 1:
+            raise NotImplementedError("fresco_amd: query-dependent attention masks are not supported (mask shape %s)"
+                                      % (tuple(attention_mask.shape),))
+        m = m[:, :, 0, :]
+        if m.dtype == torch.bool:
+            m = torch.zeros(m.shape, dtype=torch.float32, device=m.device).masked_fill_(~m, -6.0e4)
+        # (-6e4: "never attended" inside fp16 range; the reference's own UNet builds -10000, diffusion_hacked.py:569)
+        return m.float().clamp_min(-6.0e4).contiguous()
+
+    def _masked_attention(self, q, k, v, heads, scale, bias):
+        B, Lq, C = q.shape
+        Lk = k.shape[1]
+        D = C // heads
+        if bias.shape != (B, heads, Lk) or k.shape[0] != B:
+            raise ValueError("fresco_amd: attention_mask of shape %s does not match %d batches x %d heads x %d keys"
+                             % (tuple(bias.shape), B, heads, Lk))
+        Dp = next((d for d in self._HEAD_DIMS if d > D), None)
+        if Dp is None:
+            raise NotImplementedError("fresco_amd: attention_mask with head dim %d (no larger kernel head dim)" % D)
+
+        def pad(x, L, col):
+            xp = x.new_zeros(B, L, heads, Dp)
+            xp[..., :D] = x.view(B, L, heads, D)
+            if col is not None:
+                xp[..., D] = col
+            return xp.view(B, L, heads * Dp)
+
+        qp = pad(q, Lq, 1.0 / scale)
+        kp = pad(k, Lk, bias.transpose(1, 2).to(k.dtype))
+        vp = pad(v, Lk, None)
+        out = ops.attention(qp, kp, vp, heads, scale, workspace=self._ws)
+        return out.view(B, Lq, heads, Dp)[..., :D].reshape(B, Lq, C)
+
     def _cf_mask(self, ctrl, hw):
         """the cross-frame key mask of this feature scale (None: every frame attends to frame 0 only)"""
         mask = None
@@ -124,9 +178,10 @@ class FRESCOAttnProcessor2_0:
             batch_size, channel, height, width = hidden_states.shape
             hidden_states = hidden_states.view(batch_size, channel, height * width).transpose(1, 2)
         batch_size = hidden_states.shape[0]
-        if attention_mask is not None:
-            raise NotImplementedError("fresco_amd: attention_mask is not supported (the FRESCO pipeline "
-                                      "never passes one, src/pipe_FRESCO.py:201-209)")
+        mask_bias = None
+        if attention_mask is not None:  # reference :192-196
+            seq_len = hidden_states.shape[1] if encoder_hidden_states is None else encoder_hidden_states.shape[1]
+            mask_bias = self._mask_bias(attn, attention_mask, seq_len, batch_size)
         if attn.group_norm is not None:
             hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
 
@@ -137,6 +192,8 @@ class FRESCOAttnProcessor2_0:
             if ctrl and ctrl.store:
                 ctrl(hidden_states.detach().clone())
             if self.shard is not None and ctrl and (ctrl.use_cfattn or ctrl.use_interattn):
+                if mask_bias is not None:
+                    raise ValueError("fresco_amd: attention_mask is not supported in the frame-sharded FRESCO branch")
                 return self._sharded_self_attention(attn, hidden_states, residual, input_ndim)
             sparse_kv = (self.sparse_kv_projection and bool(ctrl) and ctrl.use_cfattn and not ctrl.use_interattn
                          and hidden_states.shape[0] % self.unet_chunk_size == 0)
@@ -192,7 +249,14 @@ class FRESCOAttnProcessor2_0:
                                   diag_bias=float(ctrl.intraattn_bias), workspace=self._ws)
 
         # main pass: efficient cross-frame attention (225-247, 303-305) or plain attention
-        if fresco and ctrl.use_cfattn and sparse_kv:
+        if mask_bias is not None:
+            if fresco and ctrl.use_cfattn:
+                # (the reference hands SDPA a mask shaped for `sequence_length` keys next to M != sequence_length
+                # cross-frame keys, :303-305: it cannot run this combination either)
+                raise ValueError("fresco_amd: attention_mask cannot be combined with cross-frame attention "
+                                 "(the mask addresses %d keys, the cross-frame pass has another key set)" % mask_bias.shape[-1])
+            hs = self._masked_attention(q_att, key, value, heads, sm_scale, mask_bias)
+        elif fresco and ctrl.use_cfattn and sparse_kv:
             hs = ops.attention(q_att, key, value, heads, sm_scale, n_groups=chunk, M=key.shape[1],
                                group_rows=key.shape[1], workspace=self._ws)
         elif fresco and ctrl.use_cfattn:
@@ -311,7 +375,9 @@ def apply_FRESCO_attn(pipe):
     Narrower than the reference on purpose (there is no eager fallback behind the HIP kernels): the processor takes
     CUDA hidden states and computes the attention in fp16 (the dtype run_fresco.py runs the UNet in, :63-80): fp32 /
     bf16 activations are rounded to fp16 after the projections and the result is cast back (one RuntimeWarning per
-    processor; frame-sharded runs follow the same policy); and no `attention_mask` (the pipeline never passes one to these layers) -- a mask raises NotImplementedError."""
+    processor; frame-sharded runs follow the same policy); an `attention_mask` (the pipeline never passes one to these layers)
+    is honoured on the plain / cross-attention path through a padded-head-dim side path, and rejected where the reference
+    itself cannot use it (together with cross-frame attention) or where it depends on the query."""
     from diffusers.models.attention_processor import AttnProcessor2_0
 
     frescoProc = FRESCOAttnProcessor2_0(2, AttentionControl())

@@ -351,5 +351,56 @@ def test_processor_rejects_unsupported_inputs():
     assert proc(attn, x32).dtype == torch.float32   # fp32 activations: computed in fp16, cast back (documented)
     with pytest.raises(TypeError):                  # the operator itself takes fp16 only
         ops.attention(x32, x32, x32, 8, 1.0)
-    with pytest.raises(NotImplementedError):
-        proc(attn.half(), x32.half(), attention_mask=torch.zeros(2, 1, 16, device=DEV))
+    with pytest.raises(NotImplementedError):        # a mask that depends on the query
+        proc(attn.half(), x32.half(), attention_mask=torch.zeros(2, 16, 16, device=DEV))
+
+
+@pytest.mark.parametrize("C,heads", [(320, 8), (640, 8)])
+@pytest.mark.parametrize("kind", ["additive", "bool"])
+def test_processor_attention_mask(C, heads, kind):
+    """attention_mask on the plain self-attention path and on the cross-attention path (reference :192-196, 303-305: an
+    additive bias handed to SDPA): the processor folds it into an extra contraction dimension of the ordinary kernel.
+    Reference: fp32 softmax(q k^T / sqrt(D) + bias) v from the same fp16-rounded projections."""
+    import fresco_amd
+    g = synth.gen(C + len(kind))
+    B, L, Lk = 3, 96, 77
+    attn = synth.FakeAttn(C, heads)
+    with torch.no_grad():
+        for p in attn.parameters():
+            p.copy_(p.half().float())
+    D = C // heads
+
+    def ref_call(x, enc, bias):
+        q = (x.float() @ attn.to_q.weight.T).half().float()
+        k = (enc.float() @ attn.to_k.weight.T).half().float()
+        v = (enc.float() @ attn.to_v.weight.T).half().float()
+        qh, kh, vh = (t.view(t.shape[0], t.shape[1], heads, D).transpose(1, 2) for t in (q, k, v))
+        sc = qh @ kh.transpose(-1, -2) / math.sqrt(D) + bias[:, None, None, :]
+        o = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(x.shape[0], x.shape[1], C).half().float()
+        return o @ attn.to_out[0].weight.T + attn.to_out[0].bias
+
+    proc = fresco_amd.FRESCOAttnProcessor2_0(2, None)
+    dev_attn = copy.deepcopy(attn).to(DEV).half()
+    for cross in (False, True):
+        x = torch.randn(B, L, C, generator=g).half()
+        enc = torch.randn(B, Lk, C, generator=g).half() if cross else x
+        n = enc.shape[1]
+        keep = torch.rand(B, n, generator=g) < 0.7
+        keep[:, 0] = True
+        if kind == "bool":
+            mask, bias = keep, torch.zeros(B, n).masked_fill(~keep, float("-inf"))
+        else:  # the reference's own construction (diffusion_hacked.py:569) plus a soft part
+            soft = 0.5 * torch.randn(B, n, generator=g)
+            bias = (1 - keep.float()) * -10000.0 + soft
+            mask = bias
+        with torch.no_grad():
+            out = proc(dev_attn, x.to(DEV), encoder_hidden_states=enc.to(DEV) if cross else None,
+                       attention_mask=mask.to(DEV))
+            ref = ref_call(x, enc, bias)
+        _check(out, ref, atol=1e-3, rtol=2e-3, what="mask %s cross=%d D=%d" % (kind, cross, D))
+    # together with cross-frame attention the reference cannot use a mask either: rejected
+    ctrl = fresco_amd.AttentionControl()
+    ctrl.enable_cfattn([torch.ones(1, L, dtype=torch.bool, device=DEV)])
+    procf = fresco_amd.FRESCOAttnProcessor2_0(1, ctrl)
+    with pytest.raises(ValueError):
+        procf(dev_attn, torch.randn(1, L, C).half().to(DEV), attention_mask=torch.zeros(1, L, device=DEV))
