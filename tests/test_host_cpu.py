@@ -297,3 +297,33 @@ def test_bench_workload_helpers():
     # the PMC summary the roofline's `traffic` is read from parses to a byte count
     t = bench.pmc_traffic_bytes("attn_flash_kernelILi40")
     assert t is None or (isinstance(t["bytes"], int) and t["bytes"] > 0)
+
+
+def test_attention_mask_forms_and_rejections():
+    """host half of the attention_mask side path (processor._mask_bias / _masked_attention, reference
+    src/diffusion_hacked.py:192-196): accepted mask forms become one additive (B, heads, Lk) fp32 bias; query-dependent
+    masks and mismatched shapes are rejected before any kernel is reached."""
+    import fresco_amd
+    import synth
+
+    proc = fresco_amd.FRESCOAttnProcessor2_0.__new__(fresco_amd.FRESCOAttnProcessor2_0)  # no library needed here
+    attn = synth.FakeAttn(64, 8)
+    B, Lk = 3, 10
+    add = torch.zeros(B, Lk)
+    add[:, -2:] = -10000.0
+    for m in (add, add[:, None, :], add[:, None, None, :].expand(B, 8, 1, Lk)[:, 0]):
+        b = proc._mask_bias(attn, m, Lk, B)
+        assert b.shape == (B, 8, Lk) and b.dtype == torch.float32
+        assert torch.equal(b[:, 3], add)
+    keep = torch.ones(B, Lk, dtype=torch.bool)
+    keep[:, 0] = False
+    b = proc._mask_bias(attn, keep, Lk, B)
+    assert float(b[0, 0, 0]) == -6.0e4 and float(b[0, 0, 1]) == 0.0
+    assert float(proc._mask_bias(attn, torch.full((B, Lk), float("-inf")), Lk, B).min()) == -6.0e4  # kept inside fp16 range
+    with pytest.raises(NotImplementedError):
+        proc._mask_bias(attn, torch.zeros(B, 7, Lk), Lk, B)  # one row per query
+    q = torch.zeros(B, 5, 64)
+    with pytest.raises(ValueError):
+        proc._masked_attention(q, torch.zeros(B, Lk + 1, 64), torch.zeros(B, Lk + 1, 64), 8, 0.3, b)  # Lk mismatch
+    with pytest.raises(NotImplementedError):  # head dim 128: no larger kernel head dim to pad into
+        proc._masked_attention(torch.zeros(B, 5, 1024), torch.zeros(B, Lk, 1024), torch.zeros(B, Lk, 1024), 8, 0.1, b)
