@@ -32,6 +32,9 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// true while fresco_prof_enable() is in effect (kernels that would otherwise overlap on two streams then run on one)
+bool prof_active();
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

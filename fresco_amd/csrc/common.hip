@@ -18,6 +18,8 @@ static ProfRec* g_prof = nullptr;
 static int g_prof_cap = 0, g_prof_n = 0;
 static bool g_prof_on = false;
 
+bool prof_active() { return g_prof_on; }
+
 ProfScope::ProfScope(int tag, int a, int b, int c, int d, hipStream_t s) : on(false), st(s) {
     if (!g_prof_on || g_prof_n >= g_prof_cap) return;
     ProfRec& r = g_prof[g_prof_n];

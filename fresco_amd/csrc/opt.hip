@@ -22,55 +22,12 @@
 //   (fp16-split forms, the ones the SD-1.5 shapes run: gram16w / gram16 and sv16b / sv16 further down -- three resp. two
 //   v_mfma_f32_32x32x16_f16 per fp32-accurate product, operands by LDS-DMA from pre-tiled copies, 16 waves per CU)
 //   adam_update    temporal gradient + norm backward + Adam step, fused, fp32 state
-#include "common.h"
-#include <math.h>
+#include "opt_shared.h"
 #include <stdlib.h>
 
 namespace fresco {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// ------------------------------------------------------------------------------------------------
-// shared bilinear tap helper (same arithmetic as warp.hip: geometry.py:50-55,65-72)
-// ------------------------------------------------------------------------------------------------
-struct OTaps {
-    int idx[4];
-    float w[4];
-};
-
-__device__ __forceinline__ OTaps otaps(float fx, float fy, int x, int y, int h, int w) {
-    const float gx = 2.f * ((float)x + fx) / (float)(w - 1) - 1.f;
-    const float gy = 2.f * ((float)y + fy) / (float)(h - 1) - 1.f;
-    const float ix = ((gx + 1.f) / 2.f) * (float)(w - 1);
-    const float iy = ((gy + 1.f) / 2.f) * (float)(h - 1);
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const float tx = ix - x0f, ty = iy - y0f;
-    const float x0c = fminf(fmaxf(x0f, -2.f), (float)w + 1.f);
-    const float y0c = fminf(fmaxf(y0f, -2.f), (float)h + 1.f);
-    const int x0 = (int)x0c, y0 = (int)y0c, x1 = x0 + 1, y1 = y0 + 1;
-    const bool vx0 = x0 >= 0 && x0 < w && x0f == x0c, vx1 = x1 >= 0 && x1 < w && x0f == x0c;
-    const bool vy0 = y0 >= 0 && y0 < h && y0f == y0c, vy1 = y1 >= 0 && y1 < h && y0f == y0c;
-    const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
-    const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
-    OTaps t;
-    t.idx[0] = cy0 * w + cx0;
-    t.idx[1] = cy0 * w + cx1;
-    t.idx[2] = cy1 * w + cx0;
-    t.idx[3] = cy1 * w + cx1;
-    t.w[0] = (vx0 && vy0) ? (1.f - tx) * (1.f - ty) : 0.f;
-    t.w[1] = (vx1 && vy0) ? tx * (1.f - ty) : 0.f;
-    t.w[2] = (vx0 && vy1) ? (1.f - tx) * ty : 0.f;
-    t.w[3] = (vx1 && vy1) ? tx * ty : 0.f;
-    return t;
-}
-
-__device__ __forceinline__ float osample(const float* __restrict__ plane, const OTaps& t) {
-    return plane[t.idx[0]] * t.w[0] + plane[t.idx[1]] * t.w[1] + plane[t.idx[2]] * t.w[2] +
-           plane[t.idx[3]] * t.w[3];
-}
-
-__device__ __forceinline__ int sgn(float x) { return (x > 0.f) - (x < 0.f); }
 
 // ------------------------------------------------------------------------------------------------
 // CSR of W^T.  grid (N, 2): blockIdx.y = 0 -> bwd flow (samples c1), 1 -> fwd flow (samples c2).
@@ -161,26 +118,6 @@ __global__ __launch_bounds__(1024) void csr_build_kernel(const float* __restrict
     }
 }
 
-constexpr int OCPT = 8;  // channels per thread in the temporal kernels
-
-// Frame layout of the temporal term.  Single GPU: the n_loc = N frames of a CFG half form a ring,
-// pair j = (frame j, frame (j+1) % N), n_pairs = N.  Frame-sharded (multi-GPU): the rank owns n_loc
-// consecutive frames and receives the frame before (halo_l) and after (halo_r) them each iteration;
-// slots 0 .. n_loc+1 = halo_l, local frames, halo_r; pair j = (slot j, slot j+1), n_pairs = n_loc + 1
-// (the pair straddling the left boundary is evaluated redundantly by both neighbours).
-struct TLayout {
-    int n_loc, n_pairs, circular;
-    const float* halo_l;  // (chunk, C, hw)
-    const float* halo_r;
-};
-
-__device__ __forceinline__ const float* frame_plane(const float* cs, const TLayout& L, int ck, int slot, int c, int C,
-                                                    int hw) {
-    if (L.circular) return cs + ((int64_t)(ck * L.n_loc + slot) * C + c) * hw;
-    if (slot == 0) return L.halo_l + ((int64_t)ck * C + c) * hw;
-    if (slot == L.n_loc + 1) return L.halo_r + ((int64_t)ck * C + c) * hw;
-    return cs + ((int64_t)(ck * L.n_loc + slot - 1) * C + c) * hw;
-}
 
 // grid (ceil(hw/256), ceil(C/OCPT), chunk*n_pairs).  sgn1/sgn2: (chunk*n_pairs, C, hw) int8; flows / occs
 // are indexed by pair.  loss (optional): loss[0] += sum |r1| + |r2|  (unscaled; circular layout only)
@@ -224,98 +161,6 @@ __global__ __launch_bounds__(256) void temporal_sign_kernel(
     }
 }
 
-// For local frame fl with pairs  jf = the pair whose FIRST frame it is, jp = the pair whose SECOND:
-// grad[fl][c][p] = k mf[jf][p] sgn2[jf] + k mb[jp][p] sgn1[jp] - sum_rowB[jf][p] w*sgn1[jf][src]
-//                                                           - sum_rowF[jp][p] w*sgn2[jp][src]
-// The two CSR rows of a pixel are shared by all channels: their first TG_MAXE entries are held in
-// registers (a smooth flow gives ~4 entries per row), longer rows continue from memory.
-constexpr int TG_MAXE = 6;
-
-// Per-thread state of the temporal gradient of pixel p of local frame (ck, fl): everything that is shared by the
-// channels (pair indices, occlusion factors, the register-cached heads of the two CSR rows).
-struct TGradArgs {
-    const int8_t* sgn1;
-    const int8_t* sgn2;
-    const float* bwd_occ;
-    const float* fwd_occ;
-    const int* rowptr;
-    const int* src;
-    const float* wgt;
-    TLayout L;
-    float kscale;
-};
-
-struct TGradPixel {
-    int bf, bp, bB, eB, bF, eF;
-    float a1, a2;
-    const int *sB, *sF;
-    const float *wB, *wF;
-    int iB[TG_MAXE], iF[TG_MAXE];
-    float vB[TG_MAXE], vF[TG_MAXE];
-
-    __device__ __forceinline__ void init(const TGradArgs& t, int b, int p, int hw) {
-        const TLayout& L = t.L;
-        const int ck = b / L.n_loc, fl = b % L.n_loc;
-        const int NP = L.n_pairs;
-        const int jf = L.circular ? fl : fl + 1;
-        const int jp = L.circular ? (fl + L.n_loc - 1) % L.n_loc : fl;
-        bf = ck * NP + jf;
-        bp = ck * NP + jp;
-        a2 = t.kscale * (1.f - t.fwd_occ[(int64_t)jf * hw + p]);
-        a1 = t.kscale * (1.f - t.bwd_occ[(int64_t)jp * hw + p]);
-        const int* rpB = t.rowptr + (int64_t)(0 * NP + jf) * (hw + 1);
-        const int* rpF = t.rowptr + (int64_t)(1 * NP + jp) * (hw + 1);
-        bB = rpB[p], eB = rpB[p + 1];
-        bF = rpF[p], eF = rpF[p + 1];
-        sB = t.src + (int64_t)(0 * NP + jf) * 4 * hw;
-        wB = t.wgt + (int64_t)(0 * NP + jf) * 4 * hw;
-        sF = t.src + (int64_t)(1 * NP + jp) * 4 * hw;
-        wF = t.wgt + (int64_t)(1 * NP + jp) * 4 * hw;
-#pragma unroll
-        for (int e = 0; e < TG_MAXE; ++e) {
-            const bool okB = bB + e < eB, okF = bF + e < eF;
-            iB[e] = okB ? sB[bB + e] : 0;  // weight 0 -> the (valid) index 0 contributes nothing
-            vB[e] = okB ? wB[bB + e] : 0.f;
-            iF[e] = okF ? sF[bF + e] : 0;
-            vF[e] = okF ? wF[bF + e] : 0.f;
-        }
-    }
-    // gradients of the 8 channels of octet c8 at the pixel (signs: [pair][C/8][hw][8] bytes, one 8-byte word per load)
-    __device__ __forceinline__ void values(const TGradArgs& t, int c8, int p, int C8, int hw, float (&out)[8]) const {
-        const uint64_t* s1f = reinterpret_cast<const uint64_t*>(t.sgn1) + ((int64_t)bf * C8 + c8) * hw;
-        const uint64_t* s2f = reinterpret_cast<const uint64_t*>(t.sgn2) + ((int64_t)bf * C8 + c8) * hw;
-        const uint64_t* s1p = reinterpret_cast<const uint64_t*>(t.sgn1) + ((int64_t)bp * C8 + c8) * hw;
-        const uint64_t* s2p = reinterpret_cast<const uint64_t*>(t.sgn2) + ((int64_t)bp * C8 + c8) * hw;
-        auto sg = [](uint64_t w, int k) { return (float)(int8_t)(uint8_t)(w >> (8 * k)); };
-        const uint64_t d2 = s2f[p], d1 = s1p[p];
-        uint64_t gB[TG_MAXE], gF[TG_MAXE];
-#pragma unroll
-        for (int e = 0; e < TG_MAXE; ++e) {
-            gB[e] = s1f[iB[e]];
-            gF[e] = s2p[iF[e]];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float adj = 0.f, adj2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < TG_MAXE; ++e) {
-                adj = fmaf(vB[e], sg(gB[e], k), adj);
-                adj2 = fmaf(vF[e], sg(gF[e], k), adj2);
-            }
-            out[k] = a2 * sg(d2, k) + a1 * sg(d1, k) - adj - adj2;
-        }
-        for (int e = bB + TG_MAXE; e < eB; ++e) {  // rows longer than the register cache (rare)
-            const uint64_t g = s1f[sB[e]];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) out[k] -= wB[e] * sg(g, k);
-        }
-        for (int e = bF + TG_MAXE; e < eF; ++e) {
-            const uint64_t g = s2p[sF[e]];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) out[k] -= wF[e] * sg(g, k);
-        }
-    }
-};
 
 // ------------------------------------------------------------------------------------------------
 // Per-pixel reductions over channels, in two deterministic steps so that small planes (8x8 .. 32x32)
@@ -482,13 +327,6 @@ __device__ __forceinline__ void tile_prefetch(TilePre& t, const float* __restric
 // Epilogue shared by the fp32 and the fp16-split Gram kernels: MODE 0 writes sign(G - T) (and, for an
 // off-diagonal tile, the transposed tile to the mirror position, staged through `tr` = >= 18 KB of LDS
 // that is free once the main loop is done); MODE 1 writes G.
-// sign(G - T) is stored as ONE BYTE = the high byte of the fp16 value of the sign (0x3C: +1, 0xBC: -1, 0x00: 0), so
-// that the fp16-MFMA kernel expands four of them to packed halfs with two v_perm_b32 (a plain int8 sign costs ~4 VALU
-// operations per value there, enough to make the S V kernel issue-bound next to its MFMAs).
-__device__ __forceinline__ int8_t sign_byte(float d) { return (int8_t)(d > 0.f ? 0x3C : (d < 0.f ? 0xBC : 0)); }
-__device__ __forceinline__ float sign_from_byte(uint32_t b) {
-    return (float)__builtin_bit_cast(_Float16, (uint16_t)((b & 0xffu) << 8));
-}
 
 template <int MODE, bool PRE>
 __device__ __forceinline__ void gram_epilogue(const GemmAcc& acc, int8_t* tr, const float* __restrict__ target,
@@ -744,11 +582,6 @@ __global__ __launch_bounds__(256) void sv_kernel(const float* __restrict__ vt,
 // waits in registers), rows of 64 B + 16 B pad (conflict-free ds_read_b128).
 // Upper-triangular tiles + mirrored sign tile (gram_epilogue<0>).  Requires C % 8 == 0.
 // ------------------------------------------------------------------------------------------------
-// (the condition under which the 8-wave Gram kernel runs and the pixel-major operand copies are stored pre-tiled)
-__host__ __device__ __forceinline__ bool gram_tiled_layout(int hw, int C) { return hw % 128 == 0 && C % 32 == 0 && C >= 64; }
-// (the condition under which sv16b_kernel runs: its operands -- vh / vl and the sign bytes -- are then stored pre-tiled too:
-// V as [plane][channel tile of 128][pixel chunk of 32][128][32] halfs, S as [plane][pixel tile of 256][chunk of 32][256][32] bytes)
-__host__ __device__ __forceinline__ bool sv_tiled_layout(int hw, int C) { return hw % 256 == 0 && C % 128 == 0; }
 
 // Normalisation for the fp16-split GEMMs, one pass over x (same arithmetic and summation order as normalize_kernel): the 64 x 64
 // tile of normalised values is written channel-major (vt fp32, vh / vl halfs: operands of S V) straight from the
@@ -762,12 +595,6 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
     __shared__ float tile[64][65];
     __shared__ float nn[64];
     const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    // pixel-major copies: plain (B, hw, C), or -- when the plane is whole 128-pixel tiles and C % 32 == 0, i.e. when
-    // gram16w_kernel reads them -- pre-tiled [plane][pixel tile][channel chunk of 32][128 pixels][32 channels]: the 8 KB
-    // block a DMA'd K chunk of an operand row block needs is then contiguous (contiguous LDS-DMA sources cost far fewer
-    // L2 requests than 64-byte row segments a row apart)
-    const bool tiled = gram_tiled_layout(hw, C);
-    const bool sv_tiled = sv_tiled_layout(hw, C);
     if (threadIdx.x < 64) {
         const int p = p0 + threadIdx.x;
         float ss = 0.f;
@@ -786,10 +613,8 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
             val = cs[o] / nn[p];
             if (vt) vt[o] = val;
             const half_t hi16 = (half_t)val;
-            const int cc = c0 + c, pp = p0 + p;
-            const int64_t ov = sv_tiled ? ((((int64_t)b * (C / 128) + cc / 128) * (hw / 32) + pp / 32) * 128 + cc % 128) * 32 + pp % 32 : o;
-            vh[ov] = hi16;
-            vl[ov] = (half_t)(val - (float)hi16);
+            vh[o] = hi16;
+            vl[o] = (half_t)(val - (float)hi16);
         }
         tile[c][p] = val;
     }
@@ -799,9 +624,7 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
         if (p0 + p < hw && c0 + c < C) {
             const float val = tile[c][p];
             const half_t hi16 = (half_t)val;
-            const int pp = p0 + p, cc = c0 + c;
-            const int64_t o = tiled ? ((((int64_t)b * (hw / GT) + pp / GT) * (C / 32) + cc / 32) * GT + pp % GT) * 32 + cc % 32
-                                    : ((int64_t)b * hw + pp) * C + cc;
+            const int64_t o = ((int64_t)b * hw + p0 + p) * C + c0 + c;
             vph[o] = hi16;
             vpl[o] = (half_t)(val - (float)hi16);
         }
@@ -906,480 +729,12 @@ __global__ __launch_bounds__(256) void gram16_kernel(const half_t* __restrict__ 
                            tj, hw, tid, pre);
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same Gram step for the big planes (hw % 128 == 0, hw > 1024, C % 32 == 0) with 16 resident waves per CU:
-// 8 waves per 128 x 128 tile (wave tile 64 x 32: 32 accumulators + 32 prefetched target values per lane, ~120
-// registers), operands by LDS-DMA into a 2-slot ring (no staging registers / ds_write / VALU), two workgroups per CU.
-// The register-staged 4-wave kernel above sits at 8 waves per CU (64 + 64 values per lane) and loses 43 % of its
-// time to the staging chain (profiles/r02_attn_experiments.txt section 5); what helped the S V kernel -- DMA AND
-// twice the resident waves -- is applied here.  A slot is 4 arrays (Ah, Al, Bh, Bl) x 128 rows x 80 B = 40 pieces of
-// 1 KiB; wave w issues pieces w, w + 8, ...; rows of 5 chunks (4 data + the pad chunk, which re-reads chunk 0).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void gram16w_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
-                                                         const float* __restrict__ target,
-                                                         int8_t* __restrict__ sgn_out, float* __restrict__ loss,
-                                                         int C, int hw) {
-    constexpr int GK16 = 32, GROW = GK16 * 2 + 16, ARR = GT * GROW, SLOT = 4 * ARR, NPA = ARR / 1024, NPW = 4 * NPA / 8;
-    constexpr int TRS = GT + 16;
-    __shared__ __attribute__((aligned(16))) char lds2[2][SLOT];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int l31 = lane & 31, hi = lane >> 5;
-    // XCD-aware order (see sv16b_kernel): every XCD works through a contiguous range of the (plane, tile) list, so
-    // that the A rows shared by the tiles of one tile row stay in ONE L2
-    int lin = blockIdx.x + gridDim.x * blockIdx.z;
-    const int total = gridDim.x * gridDim.z;
-    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
-    const int b = lin / gridDim.x;
-    int ti, tj;
-    {
-        // ... and inside a plane the upper triangle is walked in 8 x 8 super-tiles (when the tile count allows): the ~64
-        // tiles an XCD has in flight then share 8 + 8 operand row blocks (5 MB) instead of streaming ~32 of them
-        const int nt = hw / GT;
-        int idx = lin % gridDim.x;
-        if (nt % 8 == 0) {
-            const int ns = nt / 8;
-            int si = 0, sj = 0;
-            for (;; ++si) {  // super-row si: its diagonal block (36 tiles), then ns - 1 - si full blocks (64 tiles)
-                const int row_tiles = 36 + 64 * (ns - 1 - si);
-                if (idx < row_tiles) break;
-                idx -= row_tiles;
-            }
-            if (idx < 36) {
-                sj = si;
-                int r = 0;
-                while (idx >= 8 - r) {
-                    idx -= 8 - r;
-                    ++r;
-                }
-                ti = si * 8 + r;
-                tj = sj * 8 + r + idx;
-            } else {
-                idx -= 36;
-                sj = si + 1 + idx / 64;
-                ti = si * 8 + (idx % 64) / 8;
-                tj = sj * 8 + idx % 8;
-            }
-        } else {
-            tri_tile(idx, nt, ti, tj);
-        }
-    }
-    const int p0 = ti * GT, q0 = tj * GT;
-    // operands are pre-tiled (normalize_split_kernel): [plane][pixel tile][chunk][128][32] halfs, 8 KB per (tile, chunk)
-    const int nkc = C / GK16;
-    const char* srcA_h = reinterpret_cast<const char*>(vph + (((int64_t)b * (hw / GT) + ti) * nkc) * GT * GK16);
-    const char* srcA_l = reinterpret_cast<const char*>(vpl + (((int64_t)b * (hw / GT) + ti) * nkc) * GT * GK16);
-    const int64_t dB = ((int64_t)tj - ti) * nkc * GT * GK16 * 2;  // B row block relative to the A row block
-    const uint32_t lds0 =
-        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)&lds2[0][0]);
-
-    // this lane's 32 target values in accumulator order (half at the top, half before the last chunk)
-    float pre[2][16];
-    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 32 + l31;
-    auto prefetch = [&](int mi) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pre[mi][r] = tgt[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * hw];
-    };
-    prefetch(0);
-
-    uint32_t doff[NPW];
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int o = ((wave + 8 * i) % NPA) * 1024 + lane * 16;
-        const int row = o / GROW, cc = (o % GROW) / 16;
-        doff[i] = (uint32_t)(row * GK16 * 2 + (cc < GK16 / 8 ? cc * 16 : 0));
-    }
-    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            const int pc = wave + 8 * i;  // 0 .. 39
-            const int arr = pc / NPA;     // Ah, Al, Bh, Bl
-            const char* src = ((arr & 1) ? srcA_l : srcA_h) + (int64_t)(arr >> 1) * dB + (int64_t)kc * GT * GK16 * 2;
-            const uint32_t m0v = lds0 + (uint32_t)(slot * SLOT + pc * 1024);
-            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(doff[i]), "s"(src), "s"(m0v)
-                         : "memory");
-        }
-    };
-
-    floatx16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    const int nk = C / GK16;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 1 < nk) stage(kc + 1, (kc + 1) & 1);
-        const char* L = &lds2[kc & 1][0];
-#pragma unroll
-        for (int ks = 0; ks < GK16 / 16; ++ks) {
-            half8_t ah[2], al[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int oa = (wm * 64 + i * 32 + l31) * GROW + ks * 32 + hi * 16;
-                ah[i] = *reinterpret_cast<const half8_t*>(L + oa);
-                al[i] = *reinterpret_cast<const half8_t*>(L + ARR + oa);
-            }
-            const int ob = (wn * 32 + l31) * GROW + ks * 32 + hi * 16;
-            const half8_t bh = *reinterpret_cast<const half8_t*>(L + 2 * ARR + ob);
-            const half8_t bl = *reinterpret_cast<const half8_t*>(L + 3 * ARR + ob);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i], 0, 0, 0);
-            }
-        }
-        // (the wait also covers the target prefetch issued before the last chunk: it is consumed right after the loop)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kc + 2 == nk) prefetch(1);
-    }
-
-    // ---- epilogue: sign(G - T) bytes, tile and (off the diagonal) mirrored tile as 16-byte rows through LDS ----
-    int8_t* tr = reinterpret_cast<int8_t*>(&lds2[0][0]);
-    const bool mirror = ti != tj;
-    const bool s_tiled = sv_tiled_layout(hw, C);  // the S V kernel that reads the signs wants them pre-tiled
-    float lsum = 0.f;
-    int8_t sg[2][16];
-    const int cl = wn * 32 + l31;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float d = acc[mi][r] - pre[mi][r];
-            const int8_t v8 = sign_byte(d);
-            lsum += fabsf(d);
-            sg[mi][r] = v8;
-            tr[rl * TRS + cl] = v8;
-        }
-    auto flush = [&](int r0, int c0) {
-        __syncthreads();
-        for (int i = tid; i < GT * (GT / 16); i += 512) {
-            const int rl = i / (GT / 16), ch = i % (GT / 16);
-            const int gp = r0 + rl, gq = c0 + ch * 16;
-            const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
-                                       : ((int64_t)b * hw + gp) * hw + gq;
-            *reinterpret_cast<uint4*>(sgn_out + so) = *reinterpret_cast<const uint4*>(tr + rl * TRS + ch * 16);
-        }
-    };
-    flush(p0, q0);
-    if (mirror) {
-        __syncthreads();
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                tr[cl * TRS + rl] = sg[mi][r];
-            }
-        flush(q0, p0);
-    }
-    if (loss) {
-        float* red = reinterpret_cast<float*>(tr + GT * TRS);  // behind the sign tile
-        const float tot = wave_sum(mirror ? 2.f * lsum : lsum);
-        __syncthreads();
-        if (lane == 0) red[wave] = tot;
-        __syncthreads();
-        if (tid == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// dV^T = alpha * V^T S on fp16 MFMA with V split into two halfs:  V = Vh + Vl,  |V| <= 1, so the pair
-// carries V to an absolute 2^-25 -- fp32 class -- and S in {-1,0,1} is exact in fp16; every product
-// is exact in the fp32 accumulator.  2 x v_mfma_f32_32x32x16_f16 replace 8 x v_mfma_f32_32x32x2_f32:
-// 1/8 of the matrix-pipe time of sv_kernel.  Both operands are read k-contiguous: A = rows c of
-// V^T (k = pixel q), B = rows p of the SYMMETRIC sign matrix (S[q][p] = S[p][q]).
-// Block tile 128 (c) x 128 (p), K chunk 32, LDS rows of 64 B + 16 B pad (conflict-free ds_read_b128).
-// Requires hw % 16 == 0 (16-byte aligned rows); other sizes use sv_kernel.
-// ------------------------------------------------------------------------------------------------
-constexpr int SK = 32;             // K chunk (pixels)
-constexpr int SROW = SK * 2 + 16;  // LDS bytes per tile row
-
-__global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
-                                                    const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
-                                                    int C, int hw, float alpha) {
-    __shared__ __attribute__((aligned(16))) char lds[2][3][GT * SROW];  // [stage][Vh, Vl, S][row]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z;
-    const int c0 = blockIdx.y * GT, p0 = blockIdx.x * GT;
-    const half_t* vhb = vh + (int64_t)b * C * hw;
-    const half_t* vlb = vl + (int64_t)b * C * hw;
-    const int8_t* sb = sgn_in + (int64_t)b * hw * hw;
-
-    // staging: V tiles 128 rows x 4 chunks of 8 halfs -> 2 chunks per thread and array; S tile 128 rows x
-    // 2 chunks of 16 int8 -> 1 chunk per thread, widened to 16 halfs when written to LDS
-    uint4 rvh[2], rvl[2], rs;
-    auto load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ch = tid + i * 256;
-            const int row = ch >> 2, kc = ch & 3;
-            const int c = c0 + row, k = k0 + kc * 8;
-            uint4 a = make_uint4(0, 0, 0, 0), l = a;
-            if (c < C && k < hw) {
-                a = *reinterpret_cast<const uint4*>(vhb + (int64_t)c * hw + k);
-                l = *reinterpret_cast<const uint4*>(vlb + (int64_t)c * hw + k);
-            }
-            rvh[i] = a;
-            rvl[i] = l;
-        }
-        const int row = tid >> 1, kc = tid & 1;
-        const int p = p0 + row, k = k0 + kc * 16;
-        rs = make_uint4(0, 0, 0, 0);
-        if (p < hw && k < hw) rs = *reinterpret_cast<const uint4*>(sb + (int64_t)p * hw + k);
-    };
-    auto store = [&](int st) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ch = tid + i * 256;
-            const int row = ch >> 2, kc = ch & 3;
-            *reinterpret_cast<uint4*>(&lds[st][0][row * SROW + kc * 16]) = rvh[i];
-            *reinterpret_cast<uint4*>(&lds[st][1][row * SROW + kc * 16]) = rvl[i];
-        }
-        const int row = tid >> 1, kc = tid & 1;
-        // 16 sign bytes -> 16 halfs: each byte IS the high byte of its fp16 value (sign_byte): two v_perm_b32 per dword
-        const unsigned w4[4] = {rs.x, rs.y, rs.z, rs.w};
-        u32x4 h0, h1;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            h0[2 * e] = __builtin_amdgcn_perm(0u, w4[e], 0x010c000cu);          // [b1 0 b0 0]
-            h0[2 * e + 1] = __builtin_amdgcn_perm(0u, w4[e], 0x030c020cu);      // [b3 0 b2 0]
-            h1[2 * e] = __builtin_amdgcn_perm(0u, w4[2 + e], 0x010c000cu);
-            h1[2 * e + 1] = __builtin_amdgcn_perm(0u, w4[2 + e], 0x030c020cu);
-        }
-        *reinterpret_cast<u32x4*>(&lds[st][2][row * SROW + kc * 32]) = h0;
-        *reinterpret_cast<u32x4*>(&lds[st][2][row * SROW + kc * 32 + 16]) = h1;
-    };
-
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = (hw + SK - 1) / SK;
-    load(0);
-    store(0);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int st = kc & 1;
-        if (kc + 1 < nk) load((kc + 1) * SK);
-        const char* ah = &lds[st][0][0];
-        const char* al = &lds[st][1][0];
-        const char* bs = &lds[st][2][0];
-#pragma unroll
-        for (int ks = 0; ks < SK / 16; ++ks) {
-            half8_t fa[2][2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = (wm * 64 + i * 32 + l31) * SROW + ks * 32 + hi * 16;
-                fa[i][0] = *reinterpret_cast<const half8_t*>(ah + off);
-                fa[i][1] = *reinterpret_cast<const half8_t*>(al + off);
-                fb[i] = *reinterpret_cast<const half8_t*>(bs + (wn * 64 + i * 32 + l31) * SROW + ks * 32 + hi * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kc + 1 < nk) store(st ^ 1);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = p0 + wn * 64 + ni * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = c0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row < C && col < hw) dvt[((int64_t)b * C + row) * hw + col] = acc[mi][ni][r] * alpha;
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same product for the big planes (hw % 256 == 0, C % 128 == 0): 128 (c) x 256 (p) workgroup tiles, 8 waves of
-// 64 x 64, two workgroups per CU.  Ablation of sv16_kernel (profiles/r02_attn_experiments.txt section 5): 45 % of its
-// time is the staging work itself -- each thread pays 5 global loads + 6 ds_write_b128 (with the sign expansion) per 16
-// MFMAs, and two chunks of register look-ahead do not help.  Here
-//   * operands arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no VALU) into a ring of slots behind
-//     counted vmcnt waits and one barrier per chunk (the protocol of proj.hip / attn.hip); with the registers that
-//     frees (108) two workgroups share a CU, so a 2-slot ring (one chunk ahead) is enough: while one workgroup waits
-//     for its chunk the other multiplies;
-//   * S stays ONE BYTE per sign in LDS (the fp16 high byte, sign_byte): half the LDS bytes of the widened form, expanded
-//     to packed halfs after the ds_read_b64 with two v_perm_b32 per dword.
-// LDS rows: V 64 B + 16 B pad, S 32 B + 16 B pad (odd multiples of 16: conflict-free fragment reads); the pad chunks
-// are DMA'd too (they re-read chunk 0) so that a slot is a linear sequence of 1 KiB pieces.
-// ------------------------------------------------------------------------------------------------
-constexpr int SB_TC = 128, SB_K = 32;
-constexpr int SB_VROW = SB_K * 2 + 16, SB_SROW = SB_K + 16;
-constexpr int SB_VARR = SB_TC * SB_VROW;          // one V array (hi or lo) of a slot: 10 pieces
-constexpr int SB_NSLOT = 2;
-template <int TP>                                 // pixels per workgroup tile (waves of 64 x TP/4)
-struct SbCfg {
-    static constexpr int NJ = TP / 128;               // 32-column blocks per wave
-    static constexpr int SARR = TP * SB_SROW;         // the S rows of a slot
-    static constexpr int SLOT = 2 * SB_VARR + SARR;   // 44 KiB (TP = 512) / 32 KiB
-    static constexpr int NP = SLOT / 1024;            // 1 KiB pieces per slot
-    static constexpr int NPW = (NP + 7) / 8;          // pieces per wave and slot (the last waves one fewer)
-};
-
-template <int N_>
-__device__ __forceinline__ void sb_wait_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
-}
-
-template <int TP, int NS>
-__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
-                                                       const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
-                                                       int C, int hw, float alpha) {
-    using Cfg = SbCfg<TP>;
-    constexpr int SB_TP = TP, SB_SLOT = Cfg::SLOT, SB_NP = Cfg::NP, SB_NPW = Cfg::NPW, NJ = Cfg::NJ;
-    extern __shared__ __attribute__((aligned(16))) char sb_smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int l31 = lane & 31, hi = lane >> 5;
-    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8), each with its own L2: give every XCD a
-    // CONTIGUOUS range of the (plane, pixel tile, channel block) list, so that workgroups sharing operand rows run on
-    // the same L2.
-    int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int total = gridDim.x * gridDim.y * gridDim.z;
-    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
-    const int b = lin / (gridDim.x * gridDim.y);
-    // (channel block fastest: neighbours in the range share their S rows, 1 MB per pixel tile; measured against pixel
-    // tile fastest -- shared V tile, 2 MB --: 536 / 98 us instead of 547 / 107 at 64^2 / 32^2)
-    const int c0 = (lin % gridDim.y) * SB_TC, p0 = ((lin / gridDim.y) % gridDim.x) * SB_TP;
-    // operands are pre-tiled (sv_tiled_layout): per (channel tile, pixel chunk) 128 x 32 halfs, per (pixel tile, chunk) 256 x 32 bytes
-    static_assert(SB_TC == 128 && SB_K == 32 && TP == 256, "tiled operand layout");
-    const char* vhb = reinterpret_cast<const char*>(vh + ((int64_t)b * (C / 128) + c0 / 128) * hw * 128);
-    const char* vlb = reinterpret_cast<const char*>(vl + ((int64_t)b * (C / 128) + c0 / 128) * hw * 128);
-    const char* sbp = reinterpret_cast<const char*>(sgn_in + ((int64_t)b * (hw / 256) + p0 / 256) * hw * 256);
-    const uint32_t lds0 =
-        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sb_smem);
-
-    // DMA: wave w issues pieces w, w + 8, ... of a slot; per-lane source offset inside its array, computed once
-    uint32_t doff[SB_NPW];
-#pragma unroll
-    for (int i = 0; i < SB_NPW; ++i) {
-        const int pc = wave + 8 * i;
-        if (pc < 2 * (SB_VARR / 1024)) {  // a V array: rows of 5 chunks (4 data + pad)
-            const int o = (pc % (SB_VARR / 1024)) * 1024 + lane * 16;
-            const int row = o / SB_VROW, cc = (o % SB_VROW) / 16;
-            doff[i] = (uint32_t)(row * SB_K * 2 + (cc < 4 ? cc * 16 : 0));
-        } else {  // S: rows of 3 chunks (2 data + pad)
-            const int o = (pc - 2 * (SB_VARR / 1024)) * 1024 + lane * 16;
-            const int row = o / SB_SROW, cc = (o % SB_SROW) / 16;
-            doff[i] = (uint32_t)(row * SB_K + (cc < 2 ? cc * 16 : 0));
-        }
-    }
-    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < SB_NPW; ++i) {
-            const int pc = wave + 8 * i;
-            if (pc < SB_NP) {
-                const int arr = pc / (SB_VARR / 1024);  // 0: Vh, 1: Vl, >= 2: S
-                const char* src = arr == 0 ? vhb + (int64_t)kc * (128 * SB_K * 2)
-                                           : (arr == 1 ? vlb + (int64_t)kc * (128 * SB_K * 2) : sbp + (int64_t)kc * (256 * SB_K));
-                const uint32_t m0v = lds0 + (uint32_t)(slot * SB_SLOT + pc * 1024);
-                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(doff[i]), "s"(src), "s"(m0v)
-                             : "memory");
-            }
-        }
-    };
-    const int many = wave < SB_NP - 8 * (SB_NPW - 1) ? 1 : 0;  // this wave issues SB_NPW pieces per slot (else one fewer)
-    auto wait_barrier = [&](int keep) __attribute__((always_inline)) {  // keep = newer slots that may stay in flight
-        if (keep == 0)
-            sb_wait_barrier<0>();
-        else if (many)
-            sb_wait_barrier<SB_NPW>();
-        else
-            sb_wait_barrier<SB_NPW - 1>();
-    };
-
-    floatx16 acc[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = hw / SB_K;
-    stage(0, 0);
-    if (NS > 2 && nk > 1) stage(1, 1);
-    wait_barrier(NS > 2 && nk > 1 ? 1 : 0);
-    int slot = 0;
-    for (int kc = 0; kc < nk; ++kc) {
-        // the slot of chunk kc - 1 takes chunk kc + NS - 1
-        if (kc + NS - 1 < nk) stage(kc + NS - 1, slot >= 1 ? slot - 1 : NS - 1);
-        const char* base = sb_smem + slot * SB_SLOT;
-#pragma unroll
-        for (int ks = 0; ks < SB_K / 16; ++ks) {
-            half8_t fa[2][2], fb[NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = (wm * 64 + i * 32 + l31) * SB_VROW + ks * 32 + hi * 16;
-                fa[i][0] = *reinterpret_cast<const half8_t*>(base + off);
-                fa[i][1] = *reinterpret_cast<const half8_t*>(base + SB_VARR + off);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const u32x2 raw = *reinterpret_cast<const u32x2*>(base + 2 * SB_VARR +
-                                                                  (wn * (32 * NJ) + j * 32 + l31) * SB_SROW + ks * 16 + hi * 8);
-                u32x4 w;
-                w[0] = __builtin_amdgcn_perm(0u, raw[0], 0x010c000cu);
-                w[1] = __builtin_amdgcn_perm(0u, raw[0], 0x030c020cu);
-                w[2] = __builtin_amdgcn_perm(0u, raw[1], 0x010c000cu);
-                w[3] = __builtin_amdgcn_perm(0u, raw[1], 0x030c020cu);
-                fb[j] = __builtin_bit_cast(half8_t, w);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kc + 1 < nk) wait_barrier(NS == 2 ? 0 : (kc + 2 < nk ? 1 : 0));
-        slot = slot == NS - 1 ? 0 : slot + 1;
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NJ; ++ni) {
-            const int col = p0 + wn * (32 * NJ) + ni * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = c0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                dvt[((int64_t)b * C + row) * hw + col] = acc[mi][ni][r] * alpha;
-            }
-        }
-}
 
 // ------------------------------------------------------------------------------------------------
 // norm backward + Adam, elementwise.  grid (ceil(hw/256), ceil(C/ECPT), B)
 //   g = grad_t (if has_t) + (dV - V <V,dV>)/|X| (if has_s);  <V,dV>[b][p] = sum of the S partials
 // mode 0: Adam update of cs, m, v;  mode 1: write g to gout (loss_grad entry)
 // ------------------------------------------------------------------------------------------------
-struct AdamArgs {
-    float beta1, beta2, step_size, bc2_sqrt, eps;
-};
-
 __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs, float* __restrict__ m,
                                                            float* __restrict__ v2, TGradArgs tg,
                                                            const float* __restrict__ vt,
@@ -1425,13 +780,6 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ cs
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-struct OptWs {
-    float *grad, *m, *v, *vt, *dvt, *nrm, *wgt, *part;
-    half_t *vh, *vl, *vph, *vpl;
-    int8_t *sgn1, *sgn2, *ssign;
-    int *rowptr, *cursor, *src;
-};
-
 static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int h, int wd, int has_t,
                             int has_s, int n_pairs = 0) {
     // N = frames owned per CFG half; n_pairs = temporal pairs evaluated (N for the single-GPU ring)
@@ -1455,6 +803,7 @@ static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int 
     tmp.dvt = has_s ? carve<float>(p, E) : nullptr;
     tmp.nrm = has_s ? carve<float>(p, B * hw) : nullptr;
     tmp.part = has_s ? carve<float>(p, B * 32 * hw) : nullptr;
+    tmp.dotp = has_s ? carve<float>(p, B * 32 * hw) : nullptr;  // <V, dV> partials per 128-channel tile (opt_fast.hip)
     tmp.vh = has_s ? carve<half_t>(p, E) : nullptr;
     tmp.vl = has_s ? carve<half_t>(p, E) : nullptr;
     tmp.vph = has_s ? carve<half_t>(p, E) : nullptr;
@@ -1510,15 +859,7 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         {
             ProfScope ps(FRESCO_PROF_OPT_GRAM, B, C, hw, 0, st);
             if (f16_sv && C % 8 == 0) {
-                if (gram_tiled_layout(hw, C))  // every whole-tile plane (measured 16^2 .. 64^2: 46 / 139 / 730 -> 37 / 109 / 604 us)
-                    hipLaunchKernelGGL(gram16w_kernel, dim3(nt * (nt + 1) / 2, 1, B), dim3(512), 0, st, w.vph, w.vpl,
-                                       target, w.ssign, loss ? loss + 1 : nullptr, C, hw);
-                else if (hw <= 1024)
-                    hipLaunchKernelGGL(gram16_kernel<64>, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vph, w.vpl,
-                                       target, w.ssign, loss ? loss + 1 : nullptr, C, hw);
-                else
-                    hipLaunchKernelGGL(gram16_kernel<32>, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vph, w.vpl,
-                                       target, w.ssign, loss ? loss + 1 : nullptr, C, hw);
+                launch_gram16_plain(w.vph, w.vpl, target, w.ssign, loss ? loss + 1 : nullptr, B, C, hw, st);
             } else
                 hipLaunchKernelGGL((gram_kernel<0>), dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, w.vt, target,
                                    w.ssign, (float*)nullptr, loss ? loss + 1 : nullptr, C, hw);
@@ -1526,17 +867,8 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         const float coef = intra_weight / ((float)Bg * (float)hw * (float)hw);
         {
             ProfScope ps(FRESCO_PROF_OPT_SV, B, C, hw, 0, st);
-            if (f16_sv && sv_tiled_layout(hw, C) && gram_tiled_layout(hw, C)) {
-                // measured at (640, 64^2): 128 x 512 tiles / 3-slot ring / one workgroup per CU 617-629 us;
-                // 128 x 256 / 3 slots 619; 128 x 256 / 2 slots / two workgroups per CU (108 registers) 532
-                constexpr int lds = SB_NSLOT * SbCfg<256>::SLOT;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<256, SB_NSLOT>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL((sv16b_kernel<256, SB_NSLOT>), dim3(hw / 256, C / SB_TC, B), dim3(512), lds, st, w.vh,
-                                   w.vl, w.ssign, w.dvt, C, hw, 2.f * coef);
-            } else if (f16_sv)
-                hipLaunchKernelGGL(sv16_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vh, w.vl,
-                                   w.ssign, w.dvt, C, hw, 2.f * coef);
+            if (f16_sv)
+                launch_sv16_plain(w.vh, w.vl, w.ssign, w.dvt, nullptr, B, C, hw, 2.f * coef, st);
             else
                 hipLaunchKernelGGL(sv_kernel, dim3(nt, (C + GT - 1) / GT, B), dim3(256), 0, st, w.vt, w.ssign,
                                    w.dvt, C, hw, 2.f * coef);
@@ -1557,6 +889,17 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
     hipLaunchKernelGGL(adam_update_kernel, egrid, dim3(256), 0, st, cs, w.m, w.v, tg,
                        v_stored ? w.vt : (const float*)nullptr, w.dvt, w.nrm, w.part, gout, C, hw, S, has_t, has_s, mode,
                        a);
+}
+
+void launch_gram16_plain(const half_t* vph, const half_t* vpl, const float* target, int8_t* ssign, float* loss, int B,
+                         int C, int hw, hipStream_t st) {
+    const int nt = (hw + GT - 1) / GT;
+    if (hw <= 1024)
+        hipLaunchKernelGGL(gram16_kernel<64>, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, vph, vpl, target, ssign, loss,
+                           C, hw);
+    else
+        hipLaunchKernelGGL(gram16_kernel<32>, dim3(nt * (nt + 1) / 2, 1, B), dim3(256), 0, st, vph, vpl, target, ssign, loss,
+                           C, hw);
 }
 
 // loss[0], loss[1] hold raw sums after opt_closure; scale them to the reference's means
@@ -1613,6 +956,66 @@ static AdamArgs adam_args(int it, float lr, float beta1, float beta2, float eps)
     return a;
 }
 
+// ---- the four-launch pipeline of opt_fast.hip: dispatch, CFG-half views, optional two-stream form ------------------
+// The slice of the workspace that belongs to CFG halves ck0, ck0 + 1, ...: every per-plane array is plane-major and
+// the pair-indexed sign arrays are (half, pair)-major, so a half is one contiguous range of each.  The CSR of the warp
+// adjoints is indexed by pair only and shared.
+static OptWs ws_half(const OptWs& w, int ck0, int N, int NP, int C, int hw) {
+    OptWs o = w;
+    const size_t pl = (size_t)ck0 * N, E = pl * C * hw;
+    o.m += E;
+    o.v += E;
+    if (o.vt) {
+        o.vt += E;
+        o.dvt += E;
+        o.nrm += pl * hw;
+        o.part += pl * 32 * hw;
+        o.dotp += pl * 32 * hw;
+        o.vh += E;
+        o.vl += E;
+        o.vph += E;
+        o.vpl += E;
+        o.ssign += pl * hw * hw;
+    }
+    if (o.sgn1) {
+        const size_t e8 = (size_t)ck0 * NP * ((C + 7) / 8) * 8 * hw;
+        o.sgn1 += e8;
+        o.sgn2 += e8;
+    }
+    return o;
+}
+
+// The two CFG halves of a batch are INDEPENDENT problems (the temporal term couples the frames of one half, the Gram
+// term is per plane, Adam is elementwise): with chunk == 2 they can run as two pipelines on two streams, the second
+// one started half an iteration late, so that the HBM-bound launches of one half (prep, adam) run beside the
+// MFMA-bound ones of the other (gram, S V) and the partial last rounds of one kernel are filled by the next.
+// FRESCO_OPT_SPLIT = 0: one stream; 1: two streams, same start; 2: second half starts behind the first half's Gram launch.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
+};
+static SideStream* side_stream() {
+    static SideStream tab[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    SideStream& t = tab[dev];
+    if (!t.s) {
+        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        (void)hipEventCreateWithFlags(&t.fork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&t.mid, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&t.join, hipEventDisableTiming);
+    }
+    return &t;
+}
+static int opt_split_mode(int planes_hw) {
+    static const int env = [] {
+        const char* e = getenv("FRESCO_OPT_SPLIT");
+        return e ? atoi(e) : -1;
+    }();
+    if (env >= 0) return env;
+    return planes_hw >= 8 * 1024 ? 2 : 0;  // small planes are launch-bound: twice the launches would not pay
+}
+
 extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
                               const float* bwd_occ, const float* target, void* workspace,
                               size_t workspace_bytes, int chunk, int N, int C, int h, int w,
@@ -1631,6 +1034,35 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
     (void)hipMemsetAsync(ws.v, 0, E * sizeof(float), st);
     opt_prepare(ws, fwd_flow, bwd_flow, fwd_occ, bwd_occ, N, chunk * N, C, h, w, has_t, st);
     const TLayout L = {N, N, 1, nullptr, nullptr};
+    if (opt_fast_ok(C, h, w, has_s)) {
+        const int hw = h * w;
+        SideStream* sd = (chunk == 2 && !prof_active() && iters > 0) ? side_stream() : nullptr;
+        const int split = sd ? opt_split_mode(N * hw) : 0;
+        if (!split) {
+            opt_fast_begin(ws, cs, chunk * N, C, hw, st);
+            for (int it = 1; it <= iters; ++it)
+                opt_fast_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, C, h, w, intra_weight,
+                                 has_t, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N);
+        } else {
+            const OptWs w1 = ws_half(ws, 1, N, N, C, hw);
+            float* cs1 = cs + (size_t)N * C * hw;
+            const float* tg1 = target + (size_t)N * hw * hw;
+            (void)hipEventRecord(sd->fork, st);  // (memsets + CSR are behind this)
+            (void)hipStreamWaitEvent(sd->s, split == 2 ? sd->mid : sd->fork, 0);
+            opt_fast_begin(ws, cs, N, C, hw, st);
+            for (int it = 1; it <= iters; ++it) {
+                const AdamArgs a = adam_args(it, lr, beta1, beta2, eps);
+                opt_fast_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, 1, C, h, w, intra_weight, has_t, 0,
+                                 nullptr, nullptr, a, st, L, chunk * N, (it == 1 && split == 2) ? sd->mid : nullptr);
+                if (it == 1) opt_fast_begin(w1, cs1, N, C, hw, sd->s);
+                opt_fast_closure(w1, cs1, fwd_flow, bwd_flow, fwd_occ, bwd_occ, tg1, 1, C, h, w, intra_weight, has_t, 0,
+                                 nullptr, nullptr, a, sd->s, L, chunk * N);
+            }
+            (void)hipEventRecord(sd->join, sd->s);
+            (void)hipStreamWaitEvent(st, sd->join, 0);
+        }
+        return check_launch();
+    }
     for (int it = 1; it <= iters; ++it)
         opt_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, N, C, h, w, intra_weight,
                     has_t, has_s, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N);
@@ -1654,8 +1086,13 @@ extern "C" int fresco_opt_loss_grad(const float* cs, const float* fwd_flow, cons
     if (loss) (void)hipMemsetAsync(loss, 0, 2 * sizeof(float), st);
     AdamArgs a = {0.f, 0.f, 0.f, 1.f, 0.f};
     const TLayout L = {N, N, 1, nullptr, nullptr};
-    opt_closure(ws, const_cast<float*>(cs), fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, N, C, h, w,
-                intra_weight, has_t, has_s, 1, grad, loss, a, st, L, chunk * N);
+    if (opt_fast_ok(C, h, w, has_s)) {
+        opt_fast_begin(ws, cs, chunk * N, C, h * w, st);
+        opt_fast_closure(ws, const_cast<float*>(cs), fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, C, h, w,
+                         intra_weight, has_t, 1, grad, loss, a, st, L, chunk * N);
+    } else
+        opt_closure(ws, const_cast<float*>(cs), fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, N, C, h, w,
+                    intra_weight, has_t, has_s, 1, grad, loss, a, st, L, chunk * N);
     if (loss) {
         const double B = (double)chunk * N, hw = (double)h * w;
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, loss, (float)(2.0 / (B * C * hw)),
@@ -1713,8 +1150,13 @@ extern "C" int fresco_opt_sharded_step(float* cs, const float* halo_l, const flo
     OptWs ws;
     opt_ws_layout(&ws, static_cast<char*>(workspace), chunk, n_loc, C, h, w, has_t, has_s, n_loc + 1);
     const TLayout L = {n_loc, n_loc + 1, 0, halo_l, halo_r};
-    opt_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, n_loc, C, h, w, intra_weight, has_t,
-                has_s, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N_total);
+    if (opt_fast_ok(C, h, w, has_s)) {
+        if (it == 1) opt_fast_begin(ws, cs, chunk * n_loc, C, h * w, st);
+        opt_fast_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, C, h, w, intra_weight, has_t, 0,
+                         nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N_total);
+    } else
+        opt_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, n_loc, C, h, w, intra_weight, has_t,
+                    has_s, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N_total);
     return check_launch();
 }
 

@@ -1,0 +1,1085 @@
+// FRESCO feature optimisation (reference: src/diffusion_hacked.py:416-488): the pipeline the SD-1.5 shapes run.
+// Everything here assumes hw % 64 == 0, C % 8 == 0 and a Gram target (opt_fast_ok); other shapes take the generic
+// kernels of opt.hip.  One Adam iteration is FOUR launches, each reading and writing every tensor once:
+//
+//   prep   opt_prep_kernel   thread = (pixel, slice of 8K channels, temporal pair): |x[p]| from the partial sums of squares
+//                            the previous Adam launch left behind; V = x/|x| written as fp16 hi + lo in both orientations
+//                            (channel-major for S V, pixel-major for the Gram product, each in the tiling its reader's
+//                            LDS-DMA wants); and, with the same x in registers, the int8 residual signs of the temporal term
+//                            (4-tap gathers of the neighbouring frame).  Replaces temporal_sign + chan_partial + normalize_split.
+//   gram   gram16x_kernel    sign(V V^T - T): 256 x 128 workgroup tiles (wave tiles 64 x 64: every LDS fragment feeds two
+//                            MFMAs), operands by LDS-DMA into a 3-slot ring of 48 KB slots, swizzled 64-byte rows (no pad
+//                            bytes in the stream), upper triangle + mirrored tile.  gram16s_kernel for planes <= 256 pixels
+//                            (64 x 64 tiles, wave-level split K, operands straight from L2 into registers).
+//   sv     sv16b / sv16      dV^T = 2c V^T S, and in the epilogue the partial sums of <V, dV> per pixel over the workgroup's
+//                            128 channels (the norm backward needs the full sum: one more pass over x and dV before).
+//   adam   opt_adam_kernel   temporal gradient from the signs + CSR rows, norm backward, Adam, and the partial sums of
+//                            squares of the UPDATED features for the next prep.
+//
+// All reductions have a fixed order: results are bit-reproducible run to run.
+#include "opt_shared.h"
+#include <stdlib.h>
+
+namespace fresco {
+
+constexpr int FAST_MAX_PART = 32;  // slices of the workspace's `part` / `dotp` arrays
+
+bool opt_fast_ok(int C, int h, int w, int has_s) {
+    static const int off = [] {
+        const char* e = getenv("FRESCO_OPT_GENERIC");
+        return (e && e[0] == '1') ? 1 : 0;
+    }();
+    const int hw = h * w;
+    return !off && has_s && hw % 64 == 0 && C % 8 == 0 && (C + 127) / 128 <= FAST_MAX_PART;
+}
+
+// channel octets per thread (K) and number of channel slices (NPART) of prep / adam
+static void fast_slices(int C, int* K, int* NPART) {
+    const int C8 = C / 8;
+    int k = 5;
+    while ((C8 + k - 1) / k > FAST_MAX_PART) ++k;
+    *K = k;
+    *NPART = (C8 + k - 1) / k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// part[b][j][p] = sum of x^2 over channel slice j (first iteration only).  grid (hw/64, ceil(NPART/4), B)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ cs, float* __restrict__ part, int C,
+                                                             int hw, int K, int NPART) {
+    const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + px, j = blockIdx.y * 4 + sl, b = blockIdx.z;
+    if (j >= NPART) return;
+    const int cb = j * 8 * K, ce = min(cb + 8 * K, C);
+    float acc = 0.f;
+    for (int c = cb; c < ce; ++c) {
+        const float x = cs[((int64_t)b * C + c) * hw + p];
+        acc = fmaf(x, x, acc);
+    }
+    part[((int64_t)b * NPART + j) * hw + p] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: grid (hw/64, ceil(NPART/4), nck * (has_t ? n_pairs : n_loc)), 256 threads = 64 pixels x 4 channel slices.
+// The thread of (pixel p, slice j, pair pj) owns channels [8 K j, 8 K (j+1)) of pixel p of the pair's FIRST frame: it
+// normalises them (when that frame is local) and evaluates both residual signs of the pair for them.
+// ------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const float* cs;
+    const float* part;
+    float* nrm;
+    half_t *vh, *vl, *vph, *vpl;
+    const float *bwd_flow, *fwd_flow, *bwd_occ, *fwd_occ;
+    int8_t *sgn1, *sgn2;
+    float* loss;
+    TLayout L;
+    int C, h, w, K, NPART, has_t, pm_tiled, cm_tiled;
+};
+
+__global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
+    const int hw = a.h * a.w, C = a.C, C8 = C >> 3;
+    const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + px;
+    const int j = blockIdx.y * 4 + sl;
+    const TLayout& L = a.L;
+    const int NPZ = a.has_t ? L.n_pairs : L.n_loc;
+    const int bz = blockIdx.z, ck = bz / NPZ, pj = bz % NPZ;
+    const int fn = (L.circular || !a.has_t) ? pj : pj - 1;  // the local frame this thread normalises (-1: a halo frame)
+    const int sa = pj, sb = L.circular ? (pj + 1) % L.n_loc : pj + 1;
+    float lsum = 0.f;
+    if (j < a.NPART) {
+        const bool do_norm = fn >= 0;
+        const int64_t bn = (int64_t)ck * L.n_loc + fn;
+        float n = 1.f;
+        if (do_norm) {
+            float ss = 0.f;
+            for (int s = 0; s < a.NPART; ++s) ss += a.part[(bn * a.NPART + s) * hw + p];  // same order in every thread
+            n = sqrtf(ss);
+            if (j == 0) a.nrm[bn * hw + p] = n;
+        }
+        OTaps tb, tf;
+        float mb = 0.f, mf = 0.f;
+        if (a.has_t) {
+            const float* fb = a.bwd_flow + (int64_t)pj * 2 * hw;
+            const float* ff = a.fwd_flow + (int64_t)pj * 2 * hw;
+            tb = otaps(fb[p], fb[hw + p], p % a.w, p / a.w, a.h, a.w);
+            tf = otaps(ff[p], ff[hw + p], p % a.w, p / a.w, a.h, a.w);
+            mb = 1.f - a.bwd_occ[(int64_t)pj * hw + p];
+            mf = 1.f - a.fwd_occ[(int64_t)pj * hw + p];
+        }
+        const int o_end = min((j + 1) * a.K, C8);
+        for (int o = j * a.K; o < o_end; ++o) {
+            const int c0 = o * 8;
+            const float* c1p = frame_plane(a.cs, L, ck, sa, c0, C, hw);
+            float x1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x1[k] = c1p[(int64_t)k * hw + p];
+            if (a.has_t) {
+                const float* c2p = frame_plane(a.cs, L, ck, sb, c0, C, hw);
+                uint64_t w1 = 0, w2 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float* q1 = c1p + (int64_t)k * hw;
+                    const float* q2 = c2p + (int64_t)k * hw;
+                    const float r1 = (q2[p] - osample(q1, tb)) * mb;
+                    const float r2 = (x1[k] - osample(q2, tf)) * mf;
+                    w1 |= (uint64_t)(uint8_t)(int8_t)sgn(r1) << (8 * k);
+                    w2 |= (uint64_t)(uint8_t)(int8_t)sgn(r2) << (8 * k);
+                    lsum += fabsf(r1) + fabsf(r2);
+                }
+                const int64_t so = ((int64_t)bz * C8 + o) * hw + p;  // signs: [pair][C/8][hw][8] bytes
+                reinterpret_cast<uint64_t*>(a.sgn1)[so] = w1;
+                reinterpret_cast<uint64_t*>(a.sgn2)[so] = w2;
+            }
+            if (do_norm) {
+                half8_t h8, l8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float val = x1[k] / n;
+                    const half_t hi16 = (half_t)val;
+                    const half_t lo16 = (half_t)(val - (float)hi16);
+                    h8[k] = hi16;
+                    l8[k] = lo16;
+                    const int c = c0 + k;
+                    const int64_t ov = a.cm_tiled ? ((((int64_t)bn * (C / 128) + c / 128) * (hw / 32) + p / 32) * 128 + c % 128) * 32 + p % 32
+                                                  : ((int64_t)bn * C + c) * hw + p;
+                    a.vh[ov] = hi16;
+                    a.vl[ov] = lo16;
+                }
+                // pixel-major: the octet is one 16-byte unit of the pixel's row
+                const int64_t op = a.pm_tiled ? ((((int64_t)bn * (hw / 128) + p / 128) * (C / 32) + c0 / 32) * 128 + p % 128) * 32 +
+                                                    ((((c0 % 32) >> 3) ^ ((p >> 2) & 3)) << 3)
+                                              : ((int64_t)bn * hw + p) * C + c0;
+                *reinterpret_cast<half8_t*>(a.vph + op) = h8;
+                *reinterpret_cast<half8_t*>(a.vpl + op) = l8;
+            }
+        }
+    }
+    if (a.loss) {
+        __shared__ float red[4];
+        const float tot = block_sum_256(lsum, red);
+        if (threadIdx.x == 0) atomicAdd(a.loss, tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adam: grid (hw/64, ceil(NPART/4), planes), 256 threads = 64 pixels x 4 channel slices.
+//   g = grad_t (if has_t) + (dV - V <V,dV>)/|X| (if has_s);  <V,dV>[b][p] = sum of the NCT partials of the S V epilogue
+// mode 0: Adam update of cs, m, v + partial sum of squares of the new cs;  mode 1: write g to gout (loss_grad entry)
+// ------------------------------------------------------------------------------------------------
+struct AdamKArgs {
+    float *cs, *m, *v2;
+    TGradArgs tg;
+    const float *dvt, *nrm, *dotp;
+    float *part, *gout;
+    int C, hw, K, NPART, NCT, has_t, has_s, mode;
+    AdamArgs a;
+};
+
+__global__ __launch_bounds__(256) void opt_adam_kernel(AdamKArgs k) {
+    const int hw = k.hw, C = k.C, C8 = C >> 3;
+    const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + px, j = blockIdx.y * 4 + sl, b = blockIdx.z;
+    if (j >= k.NPART) return;
+    float dot = 0.f, inv_n = 0.f, n = 1.f;
+    if (k.has_s) {
+        for (int s = 0; s < k.NCT; ++s) dot += k.dotp[((int64_t)b * k.NCT + s) * hw + p];
+        n = k.nrm[(int64_t)b * hw + p];
+        inv_n = 1.f / n;
+    }
+    TGradPixel tp;
+    if (k.has_t) tp.init(k.tg, b, p, hw);
+    const AdamArgs a = k.a;
+    float ss = 0.f;
+    const int o_end = min((j + 1) * k.K, C8);
+    for (int o = j * k.K; o < o_end; ++o) {
+        float tgv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (k.has_t) tp.values(k.tg, o, p, C8, hw, tgv);
+        const int64_t o0 = ((int64_t)b * C + o * 8) * hw + p;
+        float x[8], dv[8], mo[8], vo[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            x[q] = k.cs[o0 + (int64_t)q * hw];
+            dv[q] = k.has_s ? k.dvt[o0 + (int64_t)q * hw] : 0.f;
+            if (k.mode == 0) {
+                mo[q] = k.m[o0 + (int64_t)q * hw];
+                vo[q] = k.v2[o0 + (int64_t)q * hw];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float g = tgv[q];
+            if (k.has_s) g += (dv[q] - (x[q] / n) * dot) * inv_n;  // V = X/|X| rebuilt: the quotient prep rounded
+            if (k.mode == 1) {
+                k.gout[o0 + (int64_t)q * hw] = g;
+            } else {
+                const float mm = a.beta1 * mo[q] + (1.f - a.beta1) * g;
+                const float vv = a.beta2 * vo[q] + (1.f - a.beta2) * g * g;
+                k.m[o0 + (int64_t)q * hw] = mm;
+                k.v2[o0 + (int64_t)q * hw] = vv;
+                const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
+                const float xn = x[q] - a.step_size * (mm / denom);
+                k.cs[o0 + (int64_t)q * hw] = xn;
+                ss = fmaf(xn, xn, ss);
+            }
+        }
+    }
+    if (k.mode == 0 && k.has_s) k.part[((int64_t)b * k.NPART + j) * hw + p] = ss;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gram step for planes of <= 256 pixels (the 8 x 8 and 16 x 16 inputs of up_blocks.0 / 1): few tiles, long K
+// (C = 1280), so the launch is a latency chain, not a throughput problem.  64 x 64 tiles, ALL nt x nt of them (no
+// mirroring); the NW waves of a workgroup split K (wave w takes the k16 steps w, w + NW, ...), each computing the whole
+// tile with operands loaded straight from L2 into MFMA fragments (plain pixel-major layout, 16 bytes per lane, next
+// step's loads in flight during the 12 MFMAs of the current one); the NW partial tiles are summed in wave order through
+// LDS.  grid (nt*nt, 1, B), NW*64 threads, dynamic LDS NW*64*68*4 bytes.
+// ------------------------------------------------------------------------------------------------
+constexpr int GS_RS = 68;  // floats per LDS row of a partial tile (64 + 4: conflict-free 16-byte reads)
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gram16s_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
+                                                          const float* __restrict__ target, int8_t* __restrict__ sgn_out,
+                                                          float* __restrict__ loss, int C, int hw, int s_tiled) {
+    extern __shared__ __attribute__((aligned(16))) float gs_red[];  // [NW][64][GS_RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nt = hw / 64;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt, b = blockIdx.z;
+    const int p0 = ti * 64, q0 = tj * 64;
+    const half_t* hb = vph + (int64_t)b * hw * C;
+    const half_t* lb = vpl + (int64_t)b * hw * C;
+    const int64_t ra0 = (int64_t)(p0 + l31) * C + hi * 8, ra1 = ra0 + (int64_t)32 * C;
+    const int64_t rb0 = (int64_t)(q0 + l31) * C + hi * 8, rb1 = rb0 + (int64_t)32 * C;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    struct Frag {
+        half8_t ah[2], al[2], bh[2], bl[2];
+    };
+    auto loadf = [&](int ks, Frag& f) __attribute__((always_inline)) {
+        const int k = ks * 16;
+        f.ah[0] = *reinterpret_cast<const half8_t*>(hb + ra0 + k);
+        f.ah[1] = *reinterpret_cast<const half8_t*>(hb + ra1 + k);
+        f.al[0] = *reinterpret_cast<const half8_t*>(lb + ra0 + k);
+        f.al[1] = *reinterpret_cast<const half8_t*>(lb + ra1 + k);
+        f.bh[0] = *reinterpret_cast<const half8_t*>(hb + rb0 + k);
+        f.bh[1] = *reinterpret_cast<const half8_t*>(hb + rb1 + k);
+        f.bl[0] = *reinterpret_cast<const half8_t*>(lb + rb0 + k);
+        f.bl[1] = *reinterpret_cast<const half8_t*>(lb + rb1 + k);
+    };
+    auto compute = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[jj], acc[i][jj], 0, 0, 0);
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[jj], acc[i][jj], 0, 0, 0);
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[jj], acc[i][jj], 0, 0, 0);
+            }
+    };
+    const int nks = C / 16;
+    Frag f0, f1;
+    int ks = wave;
+    if (ks < nks) loadf(ks, f0);
+    while (ks < nks) {
+        if (ks + NW < nks) loadf(ks + NW, f1);
+        compute(f0);
+        ks += NW;
+        if (ks >= nks) break;
+        if (ks + NW < nks) loadf(ks + NW, f0);
+        compute(f1);
+        ks += NW;
+    }
+
+    float* mine = gs_red + (size_t)wave * 64 * GS_RS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * GS_RS + jj * 32 + l31] = acc[i][jj][r];
+    __syncthreads();
+    float lsum = 0.f;
+    if (tid < 256) {  // 256 pieces of 16 consecutive entries of one row
+        const int row = tid >> 2, cq = (tid & 3) * 16;
+        float g[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) g[e] = 0.f;
+        for (int w = 0; w < NW; ++w) {  // fixed order
+            const float* src = gs_red + ((size_t)w * 64 + row) * GS_RS + cq;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const floatx4 t = *reinterpret_cast<const floatx4*>(src + e4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e4 * 4 + e] += t[e];
+            }
+        }
+        const int gp = p0 + row, gq = q0 + cq;
+        const float* tg = target + ((int64_t)b * hw + gp) * hw + gq;
+        u32x4 packed;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const floatx4 t = *reinterpret_cast<const floatx4*>(tg + e4 * 4);
+            uint32_t wv = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = g[e4 * 4 + e] - t[e];
+                lsum += fabsf(d);
+                wv |= (uint32_t)(uint8_t)sign_byte(d) << (8 * e);
+            }
+            packed[e4] = wv;
+        }
+        const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
+                                   : ((int64_t)b * hw + gp) * hw + gq;
+        *reinterpret_cast<u32x4*>(sgn_out + so) = packed;
+    }
+    if (loss) {
+        const float tot = wave_sum(lsum);
+        __syncthreads();
+        if (lane == 0) gs_red[wave] = tot;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += gs_red[w];
+            atomicAdd(loss, t);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gram step for the big planes (hw % 256 == 0, hw >= 512, C % 32 == 0).
+//   * workgroup tile 256 (A pixels) x 128 (B pixels), 8 waves as 4 x 2 with wave tiles 64 x 64: per k16 step a wave reads
+//     4 + 4 fragments for 12 MFMAs (the 128 x 128 / 64 x 32 form this replaces: 6 for 6), and a workgroup streams 48 KB per
+//     K chunk for 192 MFMAs per wave-set instead of 40 KB for 96 -- the L2 -> LDS stream per MFMA, the measured bound of the
+//     old kernel, is 0.6 of what it was;
+//   * operands pre-tiled by prep: [plane][128-pixel tile][32-channel chunk][128][32] halfs, 16-byte units XOR-swizzled with
+//     (row >> 2) & 3, so a slot is SIX linear 8 KB DMA copies (A hi / lo of two pixel tiles, B hi / lo) and fragment reads
+//     of the unpadded 64-byte rows are conflict-free;
+//   * 3-slot ring (144 KB, one workgroup per CU), chunks two ahead behind counted vmcnt waits, one barrier per chunk;
+//   * the lane's 64 target values are fetched in two halves behind the first DMA chunks (counted in the same waits);
+//   * tiles (ti, tj) with tj >= 2 ti in units of 128 pixels; the 128-row half of a tile that lies BELOW the diagonal
+//     (only when tj == 2 ti) is the mirror image of its neighbour's upper half and is not written; halves above the
+//     diagonal are also written transposed to their mirror position; XCD-contiguous walk in 1024 x 1024 super-tiles.
+// grid (tiles per plane, 1, B), 512 threads, dynamic LDS 3 * 48 KB.
+// ------------------------------------------------------------------------------------------------
+constexpr int GX_BLK = 128 * 64;       // one (pixel tile, chunk) block of one array: 8 KB
+constexpr int GX_SLOT = 6 * GX_BLK;    // Ah0 Ah1 Al0 Al1 Bh Bl
+constexpr int GX_NS = 3;
+constexpr int GX_TRS = 128 + 16;       // staged sign tile: bytes per row
+constexpr int GX_TRS2 = 256 + 16;      // ... of the transposed tile
+
+static int gx_tiles_per_plane(int hw) {
+    const int n128 = hw / 128, n256 = hw / 256;
+    return n256 * n128 - n256 * (n256 - 1);
+}
+
+__device__ __forceinline__ void gx_tile(int idx, int hw, int& ti, int& tj) {
+    if (hw % 1024 == 0) {
+        const int ns = hw / 1024;
+        int si = 0;
+        for (;; ++si) {  // super-row si: its diagonal block (20 tiles), then ns - 1 - si full blocks (4 x 8 tiles)
+            const int row_tiles = 20 + 32 * (ns - 1 - si);
+            if (idx < row_tiles) break;
+            idx -= row_tiles;
+        }
+        if (idx < 20) {
+            int r = 0;
+            while (idx >= 8 - 2 * r) {
+                idx -= 8 - 2 * r;
+                ++r;
+            }
+            ti = si * 4 + r;
+            tj = si * 8 + 2 * r + idx;
+        } else {
+            idx -= 20;
+            const int sj = si + 1 + idx / 32;
+            ti = si * 4 + (idx % 32) / 8;
+            tj = sj * 8 + idx % 8;
+        }
+    } else {
+        const int n128 = hw / 128;
+        ti = 0;
+        while (idx >= n128 - 2 * ti) {
+            idx -= n128 - 2 * ti;
+            ++ti;
+        }
+        tj = 2 * ti + idx;
+    }
+}
+
+template <int N_>
+__device__ __forceinline__ void gx_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
+                                                         const float* __restrict__ target, int8_t* __restrict__ sgn_out,
+                                                         float* __restrict__ loss, int C, int hw, int s_tiled) {
+    extern __shared__ __attribute__((aligned(16))) char gx_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs; give every XCD a contiguous range of the
+    // (plane, tile) list so that the operand row blocks its tiles share stay in ONE L2
+    int lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const int total = gridDim.x * gridDim.z;
+    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
+    const int b = lin / gridDim.x;
+    int ti, tj;
+    gx_tile(lin % gridDim.x, hw, ti, tj);
+    const int p0 = ti * 256, q0 = tj * 128;
+    const int nk = C / 32;
+    // this wave's rows lie in the 128-row half `wm >> 1` of the tile = pixel tile a_sub of the plane
+    const int a_sub = 2 * ti + (wm >> 1);
+    const int wgt = a_sub > tj ? 0 : (a_sub < tj ? 2 : 1);  // 0: below the diagonal (not written), 2: also mirrored
+
+    const char* baseH = reinterpret_cast<const char*>(vph) + (int64_t)b * hw * C * 2;
+    const char* baseL = reinterpret_cast<const char*>(vpl) + (int64_t)b * hw * C * 2;
+    const int64_t oA = (int64_t)(2 * ti) * nk * GX_BLK, oB = (int64_t)tj * nk * GX_BLK;
+    const int64_t wv = (int64_t)wave * 1024;
+    const char* src0 = baseH + oA + wv;                            // Ah, pixel tile 2 ti
+    const char* src1 = baseH + oA + (int64_t)nk * GX_BLK + wv;     // Ah, pixel tile 2 ti + 1
+    const char* src2 = baseL + oA + wv;
+    const char* src3 = baseL + oA + (int64_t)nk * GX_BLK + wv;
+    const char* src4 = baseH + oB + wv;
+    const char* src5 = baseL + oB + wv;
+    const uint32_t lds0 =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)gx_smem);
+    const uint32_t voff = (uint32_t)lane * 16;
+    // wave w copies the w-th KiB of each of the six blocks of a slot
+    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
+        const int64_t ko = (int64_t)kc * GX_BLK;
+        const uint32_t m0b = lds0 + (uint32_t)(slot * GX_SLOT + wave * 1024);
+#define GX_PIECE(I, SRC)                                                                                         \
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"((SRC) + ko),             \
+                 "s"(m0b + (uint32_t)((I)*GX_BLK))                                                                 \
+                 : "memory")
+        GX_PIECE(0, src0);
+        GX_PIECE(1, src1);
+        GX_PIECE(2, src2);
+        GX_PIECE(3, src3);
+        GX_PIECE(4, src4);
+        GX_PIECE(5, src5);
+#undef GX_PIECE
+    };
+
+    // this lane's 64 target values in accumulator order: pre[i][jj][r] = T[p0 + wm*64 + i*32 + (r&3) + 8(r>>2) + 4hi][q0 + wn*64 + jj*32 + l31]
+    float pre[2][2][16];
+    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
+    auto prefetch = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                pre[i][jj][r] = wgt ? tgt[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32] : 0.f;
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    // fragment offsets inside a slot (bytes): unit (ks*2 + hi) of row R sits at ((ks*2 + hi) ^ ((R >> 2) & 3))
+    const int sw = (l31 >> 2) & 3;
+    const int rA = (wm * 64 + l31) * 64, rB = 4 * GX_BLK + (wn * 64 + l31) * 64;
+    const int u0 = ((0 + hi) ^ sw) * 16, u1 = ((2 + hi) ^ sw) * 16;
+
+    // `deep`: the counted schedule below (32 target loads ride behind chunks 1 and 3); short K loops drain everything
+    const bool deep = nk >= 6;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    prefetch(0);
+    if (!deep) prefetch(1);
+    if (deep)
+        gx_wait_barrier<38>();  // younger than chunk 0: chunk 1 (6 pieces) + 32 target loads
+    else
+        gx_wait_barrier<0>();
+    int slot = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : GX_NS - 1);  // the slot chunk kc - 1 was read from
+        if (deep && kc == 1) prefetch(1);
+        const char* Ls = gx_smem + slot * GX_SLOT;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int u = ks ? u1 : u0;
+            half8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const half8_t*>(Ls + rA + i * 2048 + u);
+                al[i] = *reinterpret_cast<const half8_t*>(Ls + 2 * GX_BLK + rA + i * 2048 + u);
+                bh[i] = *reinterpret_cast<const half8_t*>(Ls + rB + i * 2048 + u);
+                bl[i] = *reinterpret_cast<const half8_t*>(Ls + GX_BLK + rB + i * 2048 + u);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+                }
+        }
+        // wait for chunk kc + 1; what may stay in flight is everything issued after it
+        if (kc + 1 < nk) {
+            if (!deep || kc + 2 >= nk)
+                gx_wait_barrier<0>();
+            else if (kc <= 2)
+                gx_wait_barrier<38>();  // kc 0: targets(32) + chunk 2;  kc 1: chunk 3 + targets(32);  kc 2: targets + chunk 4
+            else
+                gx_wait_barrier<6>();
+        }
+        slot = slot == GX_NS - 1 ? 0 : slot + 1;
+    }
+    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
+
+    // ---- epilogue: sign(G - T) bytes as 16-byte rows through LDS: the tile, then (halves above the diagonal) its transpose
+    int8_t* tr = reinterpret_cast<int8_t*>(gx_smem);
+    float lsum = 0.f;
+    uint32_t sg[2][2][4];  // this lane's 64 signs, 4 per dword (kept for the transposed tile)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int cl = wn * 64 + jj * 32 + l31;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                uint32_t wv4 = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = r4 * 4 + e;
+                    const int rl = wm * 64 + i * 32 + e + 8 * r4 + 4 * hi;
+                    const float d = acc[i][jj][r] - pre[i][jj][r];
+                    const int8_t v8 = sign_byte(d);
+                    lsum += fabsf(d);
+                    tr[rl * GX_TRS + cl] = v8;
+                    wv4 |= (uint32_t)(uint8_t)v8 << (8 * e);
+                }
+                sg[i][jj][r4] = wv4;
+            }
+        }
+    __syncthreads();
+    for (int idx = tid; idx < 256 * 8; idx += 512) {
+        const int rl = idx >> 3, ch = idx & 7;
+        const int a = 2 * ti + (rl >> 7);
+        if (a > tj) continue;
+        const int gp = p0 + rl, gq = q0 + ch * 16;
+        const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
+                                   : ((int64_t)b * hw + gp) * hw + gq;
+        *reinterpret_cast<uint4*>(sgn_out + so) = *reinterpret_cast<const uint4*>(tr + rl * GX_TRS + ch * 16);
+    }
+    if (2 * ti < tj) {  // at least the upper half is above the diagonal: transposed copy
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int cl = wn * 64 + jj * 32 + l31;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;  // 4 consecutive rows: one dword of the transposed row
+                    *reinterpret_cast<uint32_t*>(tr + cl * GX_TRS2 + rl) = sg[i][jj][r4];
+                }
+            }
+        __syncthreads();
+        for (int idx = tid; idx < 128 * 16; idx += 512) {
+            const int rl = idx >> 4, ch = idx & 15;  // row = B pixel, 16 consecutive A pixels
+            const int a = 2 * ti + (ch >> 3);
+            if (a >= tj) continue;
+            const int gp = q0 + rl, gq = p0 + ch * 16;
+            const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
+                                       : ((int64_t)b * hw + gp) * hw + gq;
+            *reinterpret_cast<uint4*>(sgn_out + so) = *reinterpret_cast<const uint4*>(tr + rl * GX_TRS2 + ch * 16);
+        }
+    }
+    if (loss) {
+        float* red = reinterpret_cast<float*>(gx_smem + GX_SLOT);  // behind both staging areas
+        const float tot = wave_sum((float)wgt * lsum);
+        __syncthreads();
+        if (lane == 0) red[wave] = tot;
+        __syncthreads();
+        if (tid == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dV^T = alpha * V^T S on fp16 MFMA with V split into two halfs:  V = Vh + Vl,  |V| <= 1, so the pair
+// carries V to an absolute 2^-25 -- fp32 class -- and S in {-1,0,1} is exact in fp16; every product
+// is exact in the fp32 accumulator.  2 x v_mfma_f32_32x32x16_f16 replace 8 x v_mfma_f32_32x32x2_f32:
+// 1/8 of the matrix-pipe time of sv_kernel.  Both operands are read k-contiguous: A = rows c of
+// V^T (k = pixel q), B = rows p of the SYMMETRIC sign matrix (S[q][p] = S[p][q]).
+// Block tile 128 (c) x 128 (p), K chunk 32, LDS rows of 64 B + 16 B pad (conflict-free ds_read_b128).
+// Requires hw % 16 == 0 (16-byte aligned rows); other sizes use sv_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int SV_GT = 128;         // block tile of sv16_kernel
+constexpr int SK = 32;             // K chunk (pixels)
+constexpr int SROW = SK * 2 + 16;  // LDS bytes per tile row
+
+__global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
+                                                    const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
+                                                    float* __restrict__ dotp, int C, int hw, float alpha) {
+    __shared__ __attribute__((aligned(16))) char lds[2][3][SV_GT * SROW];  // [stage][Vh, Vl, S][row]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * SV_GT, p0 = blockIdx.x * SV_GT;
+    const half_t* vhb = vh + (int64_t)b * C * hw;
+    const half_t* vlb = vl + (int64_t)b * C * hw;
+    const int8_t* sb = sgn_in + (int64_t)b * hw * hw;
+
+    // staging: V tiles 128 rows x 4 chunks of 8 halfs -> 2 chunks per thread and array; S tile 128 rows x
+    // 2 chunks of 16 int8 -> 1 chunk per thread, widened to 16 halfs when written to LDS
+    uint4 rvh[2], rvl[2], rs;
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + i * 256;
+            const int row = ch >> 2, kc = ch & 3;
+            const int c = c0 + row, k = k0 + kc * 8;
+            uint4 a = make_uint4(0, 0, 0, 0), l = a;
+            if (c < C && k < hw) {
+                a = *reinterpret_cast<const uint4*>(vhb + (int64_t)c * hw + k);
+                l = *reinterpret_cast<const uint4*>(vlb + (int64_t)c * hw + k);
+            }
+            rvh[i] = a;
+            rvl[i] = l;
+        }
+        const int row = tid >> 1, kc = tid & 1;
+        const int p = p0 + row, k = k0 + kc * 16;
+        rs = make_uint4(0, 0, 0, 0);
+        if (p < hw && k < hw) rs = *reinterpret_cast<const uint4*>(sb + (int64_t)p * hw + k);
+    };
+    auto store = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + i * 256;
+            const int row = ch >> 2, kc = ch & 3;
+            *reinterpret_cast<uint4*>(&lds[st][0][row * SROW + kc * 16]) = rvh[i];
+            *reinterpret_cast<uint4*>(&lds[st][1][row * SROW + kc * 16]) = rvl[i];
+        }
+        const int row = tid >> 1, kc = tid & 1;
+        // 16 sign bytes -> 16 halfs: each byte IS the high byte of its fp16 value (sign_byte): two v_perm_b32 per dword
+        const unsigned w4[4] = {rs.x, rs.y, rs.z, rs.w};
+        u32x4 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            h0[2 * e] = __builtin_amdgcn_perm(0u, w4[e], 0x010c000cu);          // [b1 0 b0 0]
+            h0[2 * e + 1] = __builtin_amdgcn_perm(0u, w4[e], 0x030c020cu);      // [b3 0 b2 0]
+            h1[2 * e] = __builtin_amdgcn_perm(0u, w4[2 + e], 0x010c000cu);
+            h1[2 * e + 1] = __builtin_amdgcn_perm(0u, w4[2 + e], 0x030c020cu);
+        }
+        *reinterpret_cast<u32x4*>(&lds[st][2][row * SROW + kc * 32]) = h0;
+        *reinterpret_cast<u32x4*>(&lds[st][2][row * SROW + kc * 32 + 16]) = h1;
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (hw + SK - 1) / SK;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int st = kc & 1;
+        if (kc + 1 < nk) load((kc + 1) * SK);
+        const char* ah = &lds[st][0][0];
+        const char* al = &lds[st][1][0];
+        const char* bs = &lds[st][2][0];
+#pragma unroll
+        for (int ks = 0; ks < SK / 16; ++ks) {
+            half8_t fa[2][2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + l31) * SROW + ks * 32 + hi * 16;
+                fa[i][0] = *reinterpret_cast<const half8_t*>(ah + off);
+                fa[i][1] = *reinterpret_cast<const half8_t*>(al + off);
+                fb[i] = *reinterpret_cast<const half8_t*>(bs + (wn * 64 + i * 32 + l31) * SROW + ks * 32 + hi * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < nk) store(st ^ 1);
+        __syncthreads();
+    }
+    // epilogue: dV^T, and (dotp) this workgroup's share of <V, dV> per pixel: the sum over its 128 channels
+    float dsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = p0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < C && col < hw) {
+                    const int64_t o = ((int64_t)b * C + row) * hw + col;
+                    const float val = acc[mi][ni][r] * alpha;
+                    dvt[o] = val;
+                    if (dotp) dsum[ni] = fmaf(val, (float)vhb[(int64_t)row * hw + col] + (float)vlb[(int64_t)row * hw + col], dsum[ni]);
+                }
+            }
+        }
+    if (dotp) {
+        float* red = reinterpret_cast<float*>(&lds[0][0][0]);  // [2][128]; the last chunk's reads are behind the loop's barrier
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            float s = dsum[ni];
+            s += __shfl_xor(s, 32, 64);
+            if (hi == 0) red[wm * 128 + wn * 64 + ni * 32 + l31] = s;
+        }
+        __syncthreads();
+        if (tid < 128 && p0 + tid < hw) dotp[((int64_t)b * gridDim.y + blockIdx.y) * hw + p0 + tid] = red[tid] + red[128 + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same product for the big planes (hw % 256 == 0, C % 128 == 0): 128 (c) x 256 (p) workgroup tiles, 8 waves of
+// 64 x 64, two workgroups per CU.  Ablation of sv16_kernel (profiles/r02_attn_experiments.txt section 5): 45 % of its
+// time is the staging work itself -- each thread pays 5 global loads + 6 ds_write_b128 (with the sign expansion) per 16
+// MFMAs, and two chunks of register look-ahead do not help.  Here
+//   * operands arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no VALU) into a ring of slots behind
+//     counted vmcnt waits and one barrier per chunk (the protocol of proj.hip / attn.hip); with the registers that
+//     frees (108) two workgroups share a CU, so a 2-slot ring (one chunk ahead) is enough: while one workgroup waits
+//     for its chunk the other multiplies;
+//   * S stays ONE BYTE per sign in LDS (the fp16 high byte, sign_byte): half the LDS bytes of the widened form, expanded
+//     to packed halfs after the ds_read_b64 with two v_perm_b32 per dword.
+// LDS rows: V 64 B + 16 B pad, S 32 B + 16 B pad (odd multiples of 16: conflict-free fragment reads); the pad chunks
+// are DMA'd too (they re-read chunk 0) so that a slot is a linear sequence of 1 KiB pieces.
+// ------------------------------------------------------------------------------------------------
+constexpr int SB_TC = 128, SB_K = 32;
+constexpr int SB_VROW = SB_K * 2 + 16, SB_SROW = SB_K + 16;
+constexpr int SB_VARR = SB_TC * SB_VROW;          // one V array (hi or lo) of a slot: 10 pieces
+constexpr int SB_NSLOT = 2;
+template <int TP>                                 // pixels per workgroup tile (waves of 64 x TP/4)
+struct SbCfg {
+    static constexpr int NJ = TP / 128;               // 32-column blocks per wave
+    static constexpr int SARR = TP * SB_SROW;         // the S rows of a slot
+    static constexpr int SLOT = 2 * SB_VARR + SARR;   // 44 KiB (TP = 512) / 32 KiB
+    static constexpr int NP = SLOT / 1024;            // 1 KiB pieces per slot
+    static constexpr int NPW = (NP + 7) / 8;          // pieces per wave and slot (the last waves one fewer)
+};
+
+template <int N_>
+__device__ __forceinline__ void sb_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
+}
+
+template <int TP, int NS>
+__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
+                                                       const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
+                                                       float* __restrict__ dotp, int C, int hw, float alpha) {
+    using Cfg = SbCfg<TP>;
+    constexpr int SB_TP = TP, SB_SLOT = Cfg::SLOT, SB_NP = Cfg::NP, SB_NPW = Cfg::NPW, NJ = Cfg::NJ;
+    extern __shared__ __attribute__((aligned(16))) char sb_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8), each with its own L2: give every XCD a
+    // CONTIGUOUS range of the (plane, pixel tile, channel block) list, so that workgroups sharing operand rows run on
+    // the same L2.
+    int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
+    const int b = lin / (gridDim.x * gridDim.y);
+    // (channel block fastest: neighbours in the range share their S rows, 1 MB per pixel tile; measured against pixel
+    // tile fastest -- shared V tile, 2 MB --: 536 / 98 us instead of 547 / 107 at 64^2 / 32^2)
+    const int c0 = (lin % gridDim.y) * SB_TC, p0 = ((lin / gridDim.y) % gridDim.x) * SB_TP;
+    // operands are pre-tiled (sv_tiled_layout): per (channel tile, pixel chunk) 128 x 32 halfs, per (pixel tile, chunk) 256 x 32 bytes
+    static_assert(SB_TC == 128 && SB_K == 32 && TP == 256, "tiled operand layout");
+    const char* vhb = reinterpret_cast<const char*>(vh + ((int64_t)b * (C / 128) + c0 / 128) * hw * 128);
+    const char* vlb = reinterpret_cast<const char*>(vl + ((int64_t)b * (C / 128) + c0 / 128) * hw * 128);
+    const char* sbp = reinterpret_cast<const char*>(sgn_in + ((int64_t)b * (hw / 256) + p0 / 256) * hw * 256);
+    const uint32_t lds0 =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sb_smem);
+
+    // DMA: wave w issues pieces w, w + 8, ... of a slot; per-lane source offset inside its array, computed once
+    uint32_t doff[SB_NPW];
+#pragma unroll
+    for (int i = 0; i < SB_NPW; ++i) {
+        const int pc = wave + 8 * i;
+        if (pc < 2 * (SB_VARR / 1024)) {  // a V array: rows of 5 chunks (4 data + pad)
+            const int o = (pc % (SB_VARR / 1024)) * 1024 + lane * 16;
+            const int row = o / SB_VROW, cc = (o % SB_VROW) / 16;
+            doff[i] = (uint32_t)(row * SB_K * 2 + (cc < 4 ? cc * 16 : 0));
+        } else {  // S: rows of 3 chunks (2 data + pad)
+            const int o = (pc - 2 * (SB_VARR / 1024)) * 1024 + lane * 16;
+            const int row = o / SB_SROW, cc = (o % SB_SROW) / 16;
+            doff[i] = (uint32_t)(row * SB_K + (cc < 2 ? cc * 16 : 0));
+        }
+    }
+    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SB_NPW; ++i) {
+            const int pc = wave + 8 * i;
+            if (pc < SB_NP) {
+                const int arr = pc / (SB_VARR / 1024);  // 0: Vh, 1: Vl, >= 2: S
+                const char* src = arr == 0 ? vhb + (int64_t)kc * (128 * SB_K * 2)
+                                           : (arr == 1 ? vlb + (int64_t)kc * (128 * SB_K * 2) : sbp + (int64_t)kc * (256 * SB_K));
+                const uint32_t m0v = lds0 + (uint32_t)(slot * SB_SLOT + pc * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(doff[i]), "s"(src), "s"(m0v)
+                             : "memory");
+            }
+        }
+    };
+    const int many = wave < SB_NP - 8 * (SB_NPW - 1) ? 1 : 0;  // this wave issues SB_NPW pieces per slot (else one fewer)
+    auto wait_barrier = [&](int keep) __attribute__((always_inline)) {  // keep = newer slots that may stay in flight
+        if (keep == 0)
+            sb_wait_barrier<0>();
+        else if (many)
+            sb_wait_barrier<SB_NPW>();
+        else
+            sb_wait_barrier<SB_NPW - 1>();
+    };
+
+    floatx16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = hw / SB_K;
+    stage(0, 0);
+    if (NS > 2 && nk > 1) stage(1, 1);
+    wait_barrier(NS > 2 && nk > 1 ? 1 : 0);
+    int slot = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        // the slot of chunk kc - 1 takes chunk kc + NS - 1
+        if (kc + NS - 1 < nk) stage(kc + NS - 1, slot >= 1 ? slot - 1 : NS - 1);
+        const char* base = sb_smem + slot * SB_SLOT;
+#pragma unroll
+        for (int ks = 0; ks < SB_K / 16; ++ks) {
+            half8_t fa[2][2], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + l31) * SB_VROW + ks * 32 + hi * 16;
+                fa[i][0] = *reinterpret_cast<const half8_t*>(base + off);
+                fa[i][1] = *reinterpret_cast<const half8_t*>(base + SB_VARR + off);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(base + 2 * SB_VARR +
+                                                                  (wn * (32 * NJ) + j * 32 + l31) * SB_SROW + ks * 16 + hi * 8);
+                u32x4 w;
+                w[0] = __builtin_amdgcn_perm(0u, raw[0], 0x010c000cu);
+                w[1] = __builtin_amdgcn_perm(0u, raw[0], 0x030c020cu);
+                w[2] = __builtin_amdgcn_perm(0u, raw[1], 0x010c000cu);
+                w[3] = __builtin_amdgcn_perm(0u, raw[1], 0x030c020cu);
+                fb[j] = __builtin_bit_cast(half8_t, w);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < nk) wait_barrier(NS == 2 ? 0 : (kc + 2 < nk ? 1 : 0));
+        slot = slot == NS - 1 ? 0 : slot + 1;
+    }
+    // epilogue: dV^T, and (dotp) this workgroup's share of <V, dV> per pixel: the sum over its 128 channels, V = Vh + Vl
+    // re-read from the tiled copies (L2-resident: this workgroup has just streamed them)
+    float dsum[NJ];
+    const half_t* vht = reinterpret_cast<const half_t*>(vhb);
+    const half_t* vlt = reinterpret_cast<const half_t*>(vlb);
+#pragma unroll
+    for (int ni = 0; ni < NJ; ++ni) dsum[ni] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NJ; ++ni) {
+            const int col = p0 + wn * (32 * NJ) + ni * 32 + l31;
+            const int64_t vt0 = (int64_t)(col >> 5) * (128 * 32) + l31;  // tiled V: [pixel chunk of 32][128 channels][32 pixels]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float val = acc[mi][ni][r] * alpha;
+                dvt[((int64_t)b * C + c0 + rl) * hw + col] = val;
+                if (dotp) dsum[ni] = fmaf(val, (float)vht[vt0 + rl * 32] + (float)vlt[vt0 + rl * 32], dsum[ni]);
+            }
+        }
+    if (dotp) {
+        __syncthreads();  // the ring is free
+        float* red = reinterpret_cast<float*>(sb_smem);  // [2][TP]
+#pragma unroll
+        for (int ni = 0; ni < NJ; ++ni) {
+            float s = dsum[ni];
+            s += __shfl_xor(s, 32, 64);
+            if (hi == 0) red[wm * TP + wn * (32 * NJ) + ni * 32 + l31] = s;
+        }
+        __syncthreads();
+        if (tid < TP) dotp[((int64_t)b * (C / SB_TC) + c0 / SB_TC) * hw + p0 + tid] = red[tid] + red[TP + tid];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+void launch_sv16_plain(const half_t* vh, const half_t* vl, const int8_t* ssign, float* dvt, float* dotp, int B, int C,
+                       int hw, float alpha, hipStream_t st) {
+    const int nt = (hw + SV_GT - 1) / SV_GT;
+    hipLaunchKernelGGL(sv16_kernel, dim3(nt, (C + SV_GT - 1) / SV_GT, B), dim3(256), 0, st, vh, vl, ssign, dvt, dotp, C,
+                       hw, alpha);
+}
+
+void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, hipStream_t st) {
+    int K, NPART;
+    fast_slices(C, &K, &NPART);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(hw / 64, (NPART + 3) / 4, planes), dim3(256), 0, st, cs, w.part, C, hw,
+                       K, NPART);
+}
+
+void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                      const float* bwd_occ, const float* target, int nck, int C, int h, int wd, float intra_weight,
+                      int has_t, int mode, float* gout, float* loss, AdamArgs a, hipStream_t st, const TLayout& Lin,
+                      int Bg, hipEvent_t after_gram) {
+    const int hw = h * wd;
+    TLayout L = Lin;
+    if (!has_t) L = TLayout{Lin.n_loc, Lin.n_loc, 1, nullptr, nullptr};
+    const int planes = nck * L.n_loc;
+    int K, NPART;
+    fast_slices(C, &K, &NPART);
+    const int NCT = (C + 127) / 128;
+    const bool cm_tiled = sv_tiled_layout(hw, C);
+    const bool small = hw <= 256 && C % 32 == 0;
+    const bool big = gram_x_layout(hw, C);
+    const float kscale = 2.f / ((float)Bg * (float)C * (float)hw);
+    {
+        ProfScope ps(FRESCO_PROF_OPT_TSIGN, planes, C, hw, 0, st);
+        PrepArgs pa;
+        pa.cs = cs;
+        pa.part = w.part;
+        pa.nrm = w.nrm;
+        pa.vh = w.vh;
+        pa.vl = w.vl;
+        pa.vph = w.vph;
+        pa.vpl = w.vpl;
+        pa.bwd_flow = bwd_flow;
+        pa.fwd_flow = fwd_flow;
+        pa.bwd_occ = bwd_occ;
+        pa.fwd_occ = fwd_occ;
+        pa.sgn1 = w.sgn1;
+        pa.sgn2 = w.sgn2;
+        pa.loss = loss;
+        pa.L = L;
+        pa.C = C;
+        pa.h = h;
+        pa.w = wd;
+        pa.K = K;
+        pa.NPART = NPART;
+        pa.has_t = has_t;
+        pa.pm_tiled = big ? 1 : 0;
+        pa.cm_tiled = cm_tiled ? 1 : 0;
+        const int nz = nck * (has_t ? L.n_pairs : L.n_loc);
+        hipLaunchKernelGGL(opt_prep_kernel, dim3(hw / 64, (NPART + 3) / 4, nz), dim3(256), 0, st, pa);
+    }
+    float* gloss = loss ? loss + 1 : nullptr;
+    {
+        ProfScope ps(FRESCO_PROF_OPT_GRAM, planes, C, hw, 0, st);
+        if (big) {
+            constexpr int lds = GX_NS * GX_SLOT;
+            static const bool once = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16x_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                return true;
+            }();
+            (void)once;
+            hipLaunchKernelGGL(gram16x_kernel, dim3(gx_tiles_per_plane(hw), 1, planes), dim3(512), lds, st, w.vph, w.vpl,
+                               target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
+        } else if (small) {
+            const int nt = hw / 64;
+            if (nt * nt * planes < 128) {
+                constexpr int lds = 8 * 64 * GS_RS * 4;
+                static const bool once = [] {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16s_kernel<8>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    return true;
+                }();
+                (void)once;
+                hipLaunchKernelGGL(gram16s_kernel<8>, dim3(nt * nt, 1, planes), dim3(512), lds, st, w.vph, w.vpl, target,
+                                   w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
+            } else {
+                constexpr int lds = 4 * 64 * GS_RS * 4;
+                static const bool once = [] {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16s_kernel<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    return true;
+                }();
+                (void)once;
+                hipLaunchKernelGGL(gram16s_kernel<4>, dim3(nt * nt, 1, planes), dim3(256), lds, st, w.vph, w.vpl, target,
+                                   w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
+            }
+        } else {
+            launch_gram16_plain(w.vph, w.vpl, target, w.ssign, gloss, planes, C, hw, st);
+        }
+    }
+    if (after_gram) (void)hipEventRecord(after_gram, st);
+    const float coef = intra_weight / ((float)Bg * (float)hw * (float)hw);
+    {
+        ProfScope ps(FRESCO_PROF_OPT_SV, planes, C, hw, 0, st);
+        if (cm_tiled) {
+            constexpr int lds = SB_NSLOT * SbCfg<256>::SLOT;
+            static const bool once = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<256, SB_NSLOT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                return true;
+            }();
+            (void)once;
+            hipLaunchKernelGGL((sv16b_kernel<256, SB_NSLOT>), dim3(hw / 256, C / SB_TC, planes), dim3(512), lds, st, w.vh,
+                               w.vl, w.ssign, w.dvt, w.dotp, C, hw, 2.f * coef);
+        } else {
+            launch_sv16_plain(w.vh, w.vl, w.ssign, w.dvt, w.dotp, planes, C, hw, 2.f * coef, st);
+        }
+    }
+    {
+        ProfScope ps(FRESCO_PROF_OPT_ADAM, planes, C, hw, 0, st);
+        AdamKArgs ka;
+        ka.cs = cs;
+        ka.m = w.m;
+        ka.v2 = w.v;
+        ka.tg = TGradArgs{w.sgn1, w.sgn2, bwd_occ, fwd_occ, w.rowptr, w.src, w.wgt, L, kscale};
+        ka.dvt = w.dvt;
+        ka.nrm = w.nrm;
+        ka.dotp = w.dotp;
+        ka.part = w.part;
+        ka.gout = gout;
+        ka.C = C;
+        ka.hw = hw;
+        ka.K = K;
+        ka.NPART = NPART;
+        ka.NCT = NCT;
+        ka.has_t = has_t;
+        ka.has_s = 1;
+        ka.mode = mode;
+        ka.a = a;
+        hipLaunchKernelGGL(opt_adam_kernel, dim3(hw / 64, (NPART + 3) / 4, planes), dim3(256), 0, st, ka);
+    }
+}
+
+}  // namespace fresco

@@ -101,11 +101,13 @@ def test_closure_odd_plane_sizes(h, w):
     _grad_agree(gr, go, float(go.abs().max()), max_bad=int(2e-4 * go.numel()) + 4)
 
 
-@pytest.mark.parametrize("C,h,w", [(128, 16, 16), (128, 16, 32), (96, 16, 24)])
+@pytest.mark.parametrize("C,h,w", [(128, 16, 16), (128, 16, 32), (96, 16, 24), (256, 24, 32), (64, 8, 16)])
 def test_closure_whole_tile_planes(C, h, w):
-    """planes made of whole 128-pixel Gram tiles with C % 32 == 0: the 8-wave DMA-staged Gram kernel on 2 x 2 / 4 x 4 /
-    3 x 3 tile triangles (the super-tile walk needs a multiple of 8 tiles per side: covered at the shipping shapes), the
-    128 x 256 S V kernel when C % 128 == 0 and hw % 256 == 0 (first two cases), the 128 x 128 one otherwise"""
+    """the four-launch pipeline (opt_fast.hip) on its kernel variants: hw = 256 -> gram16s (64 x 64 tiles, split K) +
+    the tiled 128 x 256 S V kernel; hw = 512, C = 128 -> gram16x (256 x 128 tiles, LDS-DMA ring) with a K loop too short
+    for its counted-wait schedule + tiled S V; hw = 384 -> the generic plain-layout Gram kernel + the 128 x 128 S V kernel;
+    hw = 768, C = 256 -> gram16x with the counted schedule on a plane that is not whole super-tiles; hw = 128 -> gram16s
+    with 8 waves (the super-tile walk and the full-size grids are covered at the shipping shapes, test_gpu_fullsize.py)"""
     import fresco_amd.ops as ops
     from fresco_amd.warp import _prep_flow_occ
     g = synth.gen(C + h * 100 + w)

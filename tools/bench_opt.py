@@ -6,7 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-NAMES = {4: "temporal_sign", 6: "colnorm", 7: "gram", 8: "sv", 9: "adam_update"}  # (5, the temporal gradient, lives in adam_update)
+NAMES = {4: "prep", 6: "colnorm", 7: "gram", 8: "sv", 9: "adam_update"}  # 4: residual signs + normalisation + fp16 splits (one launch); 6 only on the generic path
 LAYERS = ((1280, 8), (1280, 16), (1280, 32), (640, 64))
 
 
@@ -26,12 +26,12 @@ def _inputs(N, R, dev, g):
 def _dominant_roofline(kern):
     """roofline of cfg3's dominant kernel: the Gram product at the largest layer (C = 640, 64 x 64).  `achieved` counts
     the ALGORITHMIC flop of one G = V V^T (2 B hw^2 C, what the reference's bmm computes) against the dense fp16 MFMA
-    peak the kernel's instructions run at; `frac_executed` counts what it executes (upper triangle only, three
-    split-fp16 products per fp32-accurate product)."""
+    peak the kernel's instructions run at; `frac_executed` counts what it executes (upper triangle, three split-fp16
+    products per fp32-accurate product)."""
     k = kern.get("C640_h64", {}).get("gram_roofline")
     if not k:
         return None
-    return dict(bound="mfma", kernel="gram16w_kernel at (C 640, 64 x 64)", achieved=k["algorithmic_tflops"],
+    return dict(bound="mfma", kernel="gram16x_kernel at (C 640, 64 x 64)", achieved=k["algorithmic_tflops"],
                 peak=PEAK_F16_DENSE / 1e12, unit="TFLOP/s", frac=k["frac_algorithmic"], frac_executed=k["frac_executed"],
                 note="the Gram and S V products are fp32-accurate products built from 3 / 2 fp16 MFMAs on hi / lo halves "
                      "(exact to ~2^-22); per-kernel fractions of every launch, MFMA- and HBM-bound alike, are in "
@@ -83,15 +83,22 @@ def measure(iters=20, N=8, R=512, dev="cuda", verbose=False, baselines=True, rep
         for k in ("gram", "sv"):
             if k in agg:
                 t = sum(agg[k]) / len(agg[k]) * 1e-3
-                # fp16-split forms: gram = upper triangle x 3 products (hi.hi + hi.lo + lo.hi), sv = 2 products (S exact)
-                execd = one * (1.5 if k == "gram" else 2.0)
+                # fp16-split forms: gram = 3 products (hi.hi + hi.lo + lo.hi) over the tiles it computes (256 x 128 tiles with
+                # tj >= 2 ti: the upper triangle + one 128 x 128 block per 256 rows; ALL tiles for planes <= 256 pixels),
+                # sv = 2 products (S exact)
+                if k == "gram":
+                    n128, n256 = hw // 128, hw // 256
+                    execd = one * 3.0 * ((n256 * n128 - n256 * (n256 - 1)) * 2.0 / (n128 * n128) if hw >= 512 else 1.0)
+                else:
+                    execd = one * 2.0
                 kl[k + "_roofline"] = dict(bound="mfma", algorithmic_tflops=round(one / t / 1e12, 1),
                                            frac_algorithmic=round(one / t / PEAK_F16_DENSE, 3),
                                            executed_fp16_tflops=round(execd / t / 1e12, 1),
                                            frac_executed=round(execd / t / PEAK_F16_DENSE, 3))
         # the HBM-bound passes: algorithmic bytes per launch (fp32 tensors of B*C*hw elements; S V's dV^T counted with its reader)
         el = 4.0 * 2 * N * C * hw
-        for k, nbytes in (("temporal_sign", 2 * el + el / 2), ("colnorm", 2 * el + 2 * el), ("adam_update", 2 * el + 7 * el)):
+        # prep: x once, signs (2 x 1 byte) and four fp16 copies out; adam: x, m, v, dV in + signs, x, m, v out
+        for k, nbytes in (("prep", el + el / 2 + 2 * el), ("adam_update", 4 * el + el / 2 + 3 * el)):
             if k in agg:
                 t = sum(agg[k]) / len(agg[k]) * 1e-3
                 kl[k + "_roofline"] = dict(bound="hbm", algorithmic_gb=round(nbytes / 1e9, 3),
