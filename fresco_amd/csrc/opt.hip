@@ -989,10 +989,14 @@ static OptWs ws_half(const OptWs& w, int ck0, int N, int NP, int C, int hw) {
 // term is per plane, Adam is elementwise): with chunk == 2 they can run as two pipelines on two streams, the second
 // one started half an iteration late, so that the HBM-bound launches of one half (prep, adam) run beside the
 // MFMA-bound ones of the other (gram, S V) and the partial last rounds of one kernel are filled by the next.
-// FRESCO_OPT_SPLIT = 0: one stream; 1: two streams, same start; 2: second half starts behind the first half's Gram launch.
+// FRESCO_OPT_SPLIT = 0: one stream; 1: two streams, same start; 2: second half starts behind the first half's Gram launch;
+// 3: the MFMA-bound launches of the two halves strictly alternate (half 1's Gram waits for half 0's S V of the same
+// iteration, half 0's next Gram for half 1's S V), the HBM-bound launches float beside them -- without the events two
+// free-running pipelines fall back into lockstep within two iterations (profiles/r04_opt_trace_split.txt).
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
+    hipEvent_t sv_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][iteration parity]
 };
 static SideStream* side_stream() {
     static SideStream tab[32];
@@ -1004,6 +1008,7 @@ static SideStream* side_stream() {
         (void)hipEventCreateWithFlags(&t.fork, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&t.mid, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&t.join, hipEventDisableTiming);
+        for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&t.sv_done[i >> 1][i & 1], hipEventDisableTiming);
     }
     return &t;
 }
@@ -1048,15 +1053,25 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
             float* cs1 = cs + (size_t)N * C * hw;
             const float* tg1 = target + (size_t)N * hw * hw;
             (void)hipEventRecord(sd->fork, st);  // (memsets + CSR are behind this)
-            (void)hipStreamWaitEvent(sd->s, split == 2 ? sd->mid : sd->fork, 0);
+            (void)hipStreamWaitEvent(sd->s, sd->fork, 0);
             opt_fast_begin(ws, cs, N, C, hw, st);
             for (int it = 1; it <= iters; ++it) {
                 const AdamArgs a = adam_args(it, lr, beta1, beta2, eps);
+                const int par = it & 1;
+                FastSync y0, y1;
+                if (split == 3) {
+                    y0.wait_before_gram = it > 1 ? sd->sv_done[1][par ^ 1] : nullptr;
+                    y0.record_after_sv = sd->sv_done[0][par];
+                    y1.wait_before_gram = sd->sv_done[0][par];
+                    y1.record_after_sv = sd->sv_done[1][par];
+                }
+                if (it == 1 && split == 2) y0.record_after_gram = sd->mid;
                 opt_fast_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, 1, C, h, w, intra_weight, has_t, 0,
-                                 nullptr, nullptr, a, st, L, chunk * N, (it == 1 && split == 2) ? sd->mid : nullptr);
+                                 nullptr, nullptr, a, st, L, chunk * N, &y0);
+                if (it == 1 && split == 2) (void)hipStreamWaitEvent(sd->s, sd->mid, 0);  // (recorded by the call above)
                 if (it == 1) opt_fast_begin(w1, cs1, N, C, hw, sd->s);
                 opt_fast_closure(w1, cs1, fwd_flow, bwd_flow, fwd_occ, bwd_occ, tg1, 1, C, h, w, intra_weight, has_t, 0,
-                                 nullptr, nullptr, a, sd->s, L, chunk * N);
+                                 nullptr, nullptr, a, sd->s, L, chunk * N, &y1);
             }
             (void)hipEventRecord(sd->join, sd->s);
             (void)hipStreamWaitEvent(st, sd->join, 0);

@@ -33,6 +33,15 @@ bool opt_fast_ok(int C, int h, int w, int has_s) {
     return !off && has_s && hw % 64 == 0 && C % 8 == 0 && (C + 127) / 128 <= FAST_MAX_PART;
 }
 
+// experiment switch (timing ablations; results are WRONG when set): FRESCO_OPT_ABL = bit mask, see the kernels
+static int opt_abl() {
+    static const int v = [] {
+        const char* e = getenv("FRESCO_OPT_ABL");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 // channel octets per thread (K) and number of channel slices (NPART) of prep / adam
 static void fast_slices(int C, int* K, int* NPART) {
     const int C8 = C / 8;
@@ -73,7 +82,7 @@ struct PrepArgs {
     int8_t *sgn1, *sgn2;
     float* loss;
     TLayout L;
-    int C, h, w, K, NPART, has_t, pm_tiled, cm_tiled;
+    int C, h, w, K, NPART, has_t, pm_tiled, cm_tiled, abl;
 };
 
 __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
             float x1[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x1[k] = c1p[(int64_t)k * hw + p];
-            if (a.has_t) {
+            if (a.has_t && !(a.abl & 1)) {
                 const float* c2p = frame_plane(a.cs, L, ck, sb, c0, C, hw);
                 uint64_t w1 = 0, w2 = 0;
 #pragma unroll
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
                 reinterpret_cast<uint64_t*>(a.sgn1)[so] = w1;
                 reinterpret_cast<uint64_t*>(a.sgn2)[so] = w2;
             }
-            if (do_norm) {
+            if (do_norm && !(a.abl & 2)) {
                 half8_t h8, l8;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -143,15 +152,21 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
                     const int c = c0 + k;
                     const int64_t ov = a.cm_tiled ? ((((int64_t)bn * (C / 128) + c / 128) * (hw / 32) + p / 32) * 128 + c % 128) * 32 + p % 32
                                                   : ((int64_t)bn * C + c) * hw + p;
-                    a.vh[ov] = hi16;
-                    a.vl[ov] = lo16;
+                    if (!(a.abl & 4)) {
+                        a.vh[ov] = hi16;
+                        a.vl[ov] = lo16;
+                    }
                 }
                 // pixel-major: the octet is one 16-byte unit of the pixel's row
-                const int64_t op = a.pm_tiled ? ((((int64_t)bn * (hw / 128) + p / 128) * (C / 32) + c0 / 32) * 128 + p % 128) * 32 +
-                                                    ((((c0 % 32) >> 3) ^ ((p >> 2) & 3)) << 3)
-                                              : ((int64_t)bn * hw + p) * C + c0;
-                *reinterpret_cast<half8_t*>(a.vph + op) = h8;
-                *reinterpret_cast<half8_t*>(a.vpl + op) = l8;
+                const int64_t op = a.pm_tiled == 2 ? ((((int64_t)bn * (hw / 128) + p / 128) * (C / 16) + c0 / 16) * 128 + p % 128) * 16 +
+                                                         ((((c0 % 16) >> 3) ^ ((p >> 3) & 1)) << 3)
+                                   : a.pm_tiled   ? ((((int64_t)bn * (hw / 128) + p / 128) * (C / 32) + c0 / 32) * 128 + p % 128) * 32 +
+                                                         ((((c0 % 32) >> 3) ^ ((p >> 2) & 3)) << 3)
+                                                  : ((int64_t)bn * hw + p) * C + c0;
+                if (!(a.abl & 8)) {
+                    *reinterpret_cast<half8_t*>(a.vph + op) = h8;
+                    *reinterpret_cast<half8_t*>(a.vpl + op) = l8;
+                }
             }
         }
     }
@@ -422,7 +437,7 @@ __device__ __forceinline__ void gx_wait_barrier() {
 
 __global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
                                                          const float* __restrict__ target, int8_t* __restrict__ sgn_out,
-                                                         float* __restrict__ loss, int C, int hw, int s_tiled) {
+                                                         float* __restrict__ loss, int C, int hw, int s_tiled, int abl) {
     extern __shared__ __attribute__((aligned(16))) char gx_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -480,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restric
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                pre[i][jj][r] = wgt ? tgt[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32] : 0.f;
+                pre[i][jj][r] = (wgt && !(abl & 16)) ? tgt[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32] : 0.f;
     };
 
     floatx16 acc[2][2];
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restric
         gx_wait_barrier<0>();
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : GX_NS - 1);  // the slot chunk kc - 1 was read from
+        if (kc + 2 < nk && !(abl & 32)) stage(kc + 2, slot >= 1 ? slot - 1 : GX_NS - 1);  // the slot chunk kc - 1 was read from
         if (deep && kc == 1) prefetch(1);
         const char* Ls = gx_smem + slot * GX_SLOT;
 #pragma unroll
@@ -521,6 +536,11 @@ __global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restric
                 al[i] = *reinterpret_cast<const half8_t*>(Ls + 2 * GX_BLK + rA + i * 2048 + u);
                 bh[i] = *reinterpret_cast<const half8_t*>(Ls + rB + i * 2048 + u);
                 bl[i] = *reinterpret_cast<const half8_t*>(Ls + GX_BLK + rB + i * 2048 + u);
+            }
+            if (abl & 64) {  // (ablation: no MFMAs; keep the fragments alive)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
+                continue;
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -543,6 +563,10 @@ __global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restric
         slot = slot == GX_NS - 1 ? 0 : slot + 1;
     }
     __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
+    if (abl & 128) {  // (ablation: no epilogue)
+        if (acc[0][0][0] + acc[1][1][3] + pre[0][0][0] + pre[1][1][5] == 123.456f) sgn_out[0] = 1;
+        return;
+    }
 
     // ---- epilogue: sign(G - T) bytes as 16-byte rows through LDS: the tile, then (halves above the diagonal) its transpose
     int8_t* tr = reinterpret_cast<int8_t*>(gx_smem);
@@ -605,6 +629,206 @@ __global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restric
     }
     if (loss) {
         float* red = reinterpret_cast<float*>(gx_smem + GX_SLOT);  // behind both staging areas
+        const float tot = wave_sum((float)wgt * lsum);
+        __syncthreads();
+        if (lane == 0) red[wave] = tot;
+        __syncthreads();
+        if (tid == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same Gram step with TWO workgroups per CU (gram16x measured: matrix pipe busy 44 % -- its DMA waits, target
+// stream and 6 us sign / store epilogue do not overlap with anything when one workgroup owns the CU; ablations
+// profiles/r04_gram_ablation.txt).  Same 256 x 128 tile and 64 x 64 wave tiles, but
+//   * K chunks of 16 channels: a slot is six 4 KB blocks (24 KB), three slots = 72 KB per workgroup -> two per CU;
+//     operands pre-tiled by prep as [plane][128-pixel tile][16-channel chunk][128][2 x 16 B], the two units of pixel row r
+//     swapped when (r >> 3) & 1 (conflict-free ds_read_b128 on 32-byte rows);
+//   * <= 128 registers: the target values are NOT prefetched (64 registers); the epilogue loads them where it needs
+//     them and the other workgroup's MFMAs cover the latency;
+//   * sign bytes by arithmetic: med3(d * 2^64, -1, 1) -> cvt_pkrtz -> v_perm of the two high bytes (3.75 VALU per value
+//     instead of ~10 compares / selects); target loads and sign stores carry the non-temporal hint (streams that
+//     would otherwise evict the operand blocks the tiles of an XCD share in L2).
+// grid (tiles per plane, 1, B), 512 threads, dynamic LDS 3 * 24 KB.
+// ------------------------------------------------------------------------------------------------
+constexpr int GY_BLK = 128 * 32;       // one (pixel tile, chunk) block of one array: 4 KB
+constexpr int GY_SLOT = 6 * GY_BLK;    // Ah0 Ah1 Al0 Al1 Bh Bl
+constexpr int GY_NS = 3;
+
+template <bool LOSS>
+__global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
+                                                         const float* __restrict__ target, int8_t* __restrict__ sgn_out,
+                                                         float* __restrict__ loss, int C, int hw, int s_tiled, int abl) {
+    extern __shared__ __attribute__((aligned(16))) char gy_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const int total = gridDim.x * gridDim.z;
+    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;  // XCD-contiguous ranges (see gram16x_kernel)
+    const int b = lin / gridDim.x;
+    int ti, tj;
+    gx_tile(lin % gridDim.x, hw, ti, tj);
+    const int p0 = ti * 256, q0 = tj * 128;
+    const int nk = C / 16;
+    const int a_sub = 2 * ti + (wm >> 1);
+    const int wgt = a_sub > tj ? 0 : (a_sub < tj ? 2 : 1);  // 0: below the diagonal (not written), 2: also mirrored
+
+    const char* baseH = reinterpret_cast<const char*>(vph) + (int64_t)b * hw * C * 2;
+    const char* baseL = reinterpret_cast<const char*>(vpl) + (int64_t)b * hw * C * 2;
+    // wave w copies KiB (w & 3) of blocks (w >> 2), 2 + (w >> 2), 4 + (w >> 2): waves 0-3 -> Ah0, Al0, Bh; 4-7 -> Ah1, Al1, Bl
+    const int wq = wave >> 2;
+    const int64_t oA = ((int64_t)(2 * ti + wq) * nk) * GY_BLK + (wave & 3) * 1024;
+    const int64_t oB = ((int64_t)tj * nk) * GY_BLK + (wave & 3) * 1024;
+    const char* src0 = baseH + oA;
+    const char* src1 = baseL + oA;
+    const char* src2 = (wq ? baseL : baseH) + oB;
+    const uint32_t lds0 =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)gy_smem);
+    const uint32_t voff = (uint32_t)lane * 16;
+    const uint32_t pw = (uint32_t)(wq * GY_BLK + (wave & 3) * 1024);
+    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
+        const int64_t ko = (int64_t)kc * GY_BLK;
+        const uint32_t m0b = lds0 + (uint32_t)(slot * GY_SLOT) + pw;
+#define GY_PIECE(I, SRC)                                                                                         \
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"((SRC) + ko),             \
+                 "s"(m0b + (uint32_t)((I)*2 * GY_BLK))                                                             \
+                 : "memory")
+        GY_PIECE(0, src0);
+        GY_PIECE(1, src1);
+        GY_PIECE(2, src2);
+#undef GY_PIECE
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    // fragment offsets inside a slot: unit hi of row R sits at hi ^ ((R >> 3) & 1)
+    const int u = (hi ^ ((l31 >> 3) & 1)) * 16;
+    const int rA = (wm * 64 + l31) * 32 + u, rB = 4 * GY_BLK + (wn * 64 + l31) * 32 + u;
+
+    stage(0, 0);
+    if (nk > 1) {
+        stage(1, 1);
+        gx_wait_barrier<3>();
+    } else {
+        gx_wait_barrier<0>();
+    }
+    int slot = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 2 < nk && !(abl & 32)) stage(kc + 2, slot >= 1 ? slot - 1 : GY_NS - 1);  // the slot chunk kc - 1 was read from
+        const char* Ls = gy_smem + slot * GY_SLOT;
+        half8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const half8_t*>(Ls + rA + i * 1024);
+            al[i] = *reinterpret_cast<const half8_t*>(Ls + 2 * GY_BLK + rA + i * 1024);
+            bh[i] = *reinterpret_cast<const half8_t*>(Ls + rB + i * 1024);
+            bl[i] = *reinterpret_cast<const half8_t*>(Ls + GY_BLK + rB + i * 1024);
+        }
+        if (!(abl & 64)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
+        }
+        if (kc + 1 < nk) {
+            if (kc + 2 < nk && !(abl & 32))
+                gx_wait_barrier<3>();
+            else
+                gx_wait_barrier<0>();
+        }
+        slot = slot == GY_NS - 1 ? 0 : slot + 1;
+    }
+    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
+    if (abl & 128) {
+        if (acc[0][0][0] + acc[1][1][3] == 123.456f) sgn_out[0] = 1;
+        return;
+    }
+
+    // ---- epilogue ----
+    int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
+    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
+    float lsum = 0.f;
+    uint32_t sg[2][2][4];  // this lane's 64 signs, 4 per dword (rows e, e+1, e+2, e+3 of one column)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int cl = wn * 64 + jj * 32 + l31;
+            float tv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tv[r] = (wgt && !(abl & 16)) ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float s4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = acc[i][jj][r4 * 4 + e] - tv[r4 * 4 + e];
+                    if (LOSS) lsum += fabsf(d);
+                    s4[e] = __builtin_amdgcn_fmed3f(d * 0x1p126f, -1.f, 1.f);  // exactly -1, 0 or +1 for d = 0 and every normal d
+                }
+                const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[0], s4[1]));
+                const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[2], s4[3]));
+                const uint32_t wv4 = __builtin_amdgcn_perm(h23, h01, 0x07050301u);  // the four high bytes: 0x3C / 0xBC / 0x00
+                sg[i][jj][r4] = wv4;
+                const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
+                tr[(rl + 0) * GX_TRS + cl] = (int8_t)(wv4 & 0xff);
+                tr[(rl + 1) * GX_TRS + cl] = (int8_t)((wv4 >> 8) & 0xff);
+                tr[(rl + 2) * GX_TRS + cl] = (int8_t)((wv4 >> 16) & 0xff);
+                tr[(rl + 3) * GX_TRS + cl] = (int8_t)(wv4 >> 24);
+            }
+        }
+    __syncthreads();
+    for (int idx = tid; idx < 256 * 8; idx += 512) {
+        const int rl = idx >> 3, ch = idx & 7;
+        const int a = 2 * ti + (rl >> 7);
+        if (a > tj) continue;
+        const int gp = p0 + rl, gq = q0 + ch * 16;
+        const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
+                                   : ((int64_t)b * hw + gp) * hw + gq;
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), reinterpret_cast<u32x4*>(sgn_out + so));
+    }
+    if (2 * ti < tj) {  // at least the upper half is above the diagonal: transposed copy
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int cl = wn * 64 + jj * 32 + l31;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
+                    *reinterpret_cast<uint32_t*>(tr + cl * GX_TRS2 + rl) = sg[i][jj][r4];
+                }
+            }
+        __syncthreads();
+        for (int idx = tid; idx < 128 * 16; idx += 512) {
+            const int rl = idx >> 4, ch = idx & 15;
+            const int a = 2 * ti + (ch >> 3);
+            if (a >= tj) continue;
+            const int gp = q0 + rl, gq = p0 + ch * 16;
+            const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
+                                       : ((int64_t)b * hw + gp) * hw + gq;
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(tr + rl * GX_TRS2 + ch * 16), reinterpret_cast<u32x4*>(sgn_out + so));
+        }
+    }
+    if (LOSS) {
+        float* red = reinterpret_cast<float*>(gy_smem + 40960);  // behind both staging areas
         const float tot = wave_sum((float)wgt * lsum);
         __syncthreads();
         if (lane == 0) red[wave] = tot;
@@ -958,7 +1182,7 @@ void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, 
 void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
                       const float* bwd_occ, const float* target, int nck, int C, int h, int wd, float intra_weight,
                       int has_t, int mode, float* gout, float* loss, AdamArgs a, hipStream_t st, const TLayout& Lin,
-                      int Bg, hipEvent_t after_gram) {
+                      int Bg, const FastSync* sync) {
     const int hw = h * wd;
     TLayout L = Lin;
     if (!has_t) L = TLayout{Lin.n_loc, Lin.n_loc, 1, nullptr, nullptr};
@@ -969,6 +1193,10 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     const bool cm_tiled = sv_tiled_layout(hw, C);
     const bool small = hw <= 256 && C % 32 == 0;
     const bool big = gram_x_layout(hw, C);
+    static const int gram_y = [] {
+        const char* e = getenv("FRESCO_OPT_GRAM");
+        return (e && e[0] == 'x') ? 0 : 1;
+    }();
     const float kscale = 2.f / ((float)Bg * (float)C * (float)hw);
     {
         ProfScope ps(FRESCO_PROF_OPT_TSIGN, planes, C, hw, 0, st);
@@ -994,15 +1222,33 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         pa.K = K;
         pa.NPART = NPART;
         pa.has_t = has_t;
-        pa.pm_tiled = big ? 1 : 0;
+        pa.pm_tiled = big ? (gram_y ? 2 : 1) : 0;
         pa.cm_tiled = cm_tiled ? 1 : 0;
+        pa.abl = opt_abl() & 15;
         const int nz = nck * (has_t ? L.n_pairs : L.n_loc);
         hipLaunchKernelGGL(opt_prep_kernel, dim3(hw / 64, (NPART + 3) / 4, nz), dim3(256), 0, st, pa);
     }
     float* gloss = loss ? loss + 1 : nullptr;
+    if (sync && sync->wait_before_gram) (void)hipStreamWaitEvent(st, sync->wait_before_gram, 0);
     {
         ProfScope ps(FRESCO_PROF_OPT_GRAM, planes, C, hw, 0, st);
-        if (big) {
+        if (big && gram_y) {
+            constexpr int lds = GY_NS * GY_SLOT;
+            static const bool once = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                return true;
+            }();
+            (void)once;
+            if (gloss)
+                hipLaunchKernelGGL(gram16y_kernel<true>, dim3(gx_tiles_per_plane(hw), 1, planes), dim3(512), lds, st, w.vph,
+                                   w.vpl, target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0, opt_abl());
+            else
+                hipLaunchKernelGGL(gram16y_kernel<false>, dim3(gx_tiles_per_plane(hw), 1, planes), dim3(512), lds, st, w.vph,
+                                   w.vpl, target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0, opt_abl());
+        } else if (big) {
             constexpr int lds = GX_NS * GX_SLOT;
             static const bool once = [] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16x_kernel),
@@ -1011,7 +1257,7 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
             }();
             (void)once;
             hipLaunchKernelGGL(gram16x_kernel, dim3(gx_tiles_per_plane(hw), 1, planes), dim3(512), lds, st, w.vph, w.vpl,
-                               target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
+                               target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0, opt_abl());
         } else if (small) {
             const int nt = hw / 64;
             if (nt * nt * planes < 128) {
@@ -1039,7 +1285,7 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
             launch_gram16_plain(w.vph, w.vpl, target, w.ssign, gloss, planes, C, hw, st);
         }
     }
-    if (after_gram) (void)hipEventRecord(after_gram, st);
+    if (sync && sync->record_after_gram) (void)hipEventRecord(sync->record_after_gram, st);
     const float coef = intra_weight / ((float)Bg * (float)hw * (float)hw);
     {
         ProfScope ps(FRESCO_PROF_OPT_SV, planes, C, hw, 0, st);
@@ -1057,6 +1303,7 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
             launch_sv16_plain(w.vh, w.vl, w.ssign, w.dvt, w.dotp, planes, C, hw, 2.f * coef, st);
         }
     }
+    if (sync && sync->record_after_sv) (void)hipEventRecord(sync->record_after_sv, st);
     {
         ProfScope ps(FRESCO_PROF_OPT_ADAM, planes, C, hw, 0, st);
         AdamKArgs ka;

@@ -200,11 +200,14 @@ bool opt_fast_ok(int C, int h, int w, int has_s);
 void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, hipStream_t st);
 // one closure evaluation on `nck` CFG halves starting at the pointers given (w, cs, target already offset to the first
 // half); mode 0 = Adam step, mode 1 = write the gradient to gout.  Bg = global batch (normalises both loss terms);
-// after_gram (optional): recorded on `st` behind the Gram launch (where a second pipeline is started)
+// sync (optional): events that order this pipeline against a second one on another stream
+struct FastSync {
+    hipEvent_t wait_before_gram = nullptr, record_after_gram = nullptr, record_after_sv = nullptr;
+};
 void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
                       const float* bwd_occ, const float* target, int nck, int C, int h, int wd, float intra_weight,
                       int has_t, int mode, float* gout, float* loss, AdamArgs a, hipStream_t st, const TLayout& L,
-                      int Bg, hipEvent_t after_gram = nullptr);
+                      int Bg, const FastSync* sync = nullptr);
 // the S V product on split-fp16 MFMAs for plain (un-tiled) operand layouts; dotp (optional): per-(128-channel tile)
 // partial sums of <V, dV> per pixel
 void launch_sv16_plain(const half_t* vh, const half_t* vl, const int8_t* ssign, float* dvt, float* dotp, int B, int C,

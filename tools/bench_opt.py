@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 
 NAMES = {4: "prep", 6: "colnorm", 7: "gram", 8: "sv", 9: "adam_update"}  # 4: residual signs + normalisation + fp16 splits (one launch); 6 only on the generic path
 LAYERS = ((1280, 8), (1280, 16), (1280, 32), (640, 64))
+if os.environ.get("BENCH_OPT_LAYERS"):  # experiments: a subset, e.g. "3" or "2,3"
+    LAYERS = tuple(LAYERS[int(i)] for i in os.environ["BENCH_OPT_LAYERS"].split(","))
 
 
 PEAK_F16_DENSE = 2.5e15     # MI355X_MICROARCH.md: dense fp16 MFMA (the Gram / S V products run as split-fp16 MFMAs)

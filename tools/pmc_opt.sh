@@ -21,7 +21,8 @@ torch.cuda.synchronize()
 PY
 cd /tmp && export TMPDIR=/tmp
 i=0
-for P in "FETCH_SIZE" "WRITE_SIZE"; do
+export FRESCO_OPT_SPLIT=0
+for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python $OUT/run.py $REPO > $OUT/pass$i.log 2>&1
 done
@@ -41,4 +42,10 @@ with open(base + "/summary.csv", "w") as f:
         fe = d.get("FETCH_SIZE", 0) / max(n[(k, "FETCH_SIZE")], 1); wr = d.get("WRITE_SIZE", 0) / max(n[(k, "WRITE_SIZE")], 1)
         line = "%s,%d,%.0f,%.0f,%.1f" % (k, n[(k, "FETCH_SIZE")], fe, wr, (2 * fe + wr) * 1024 / 1e6)
         f.write(line + "\n"); print(line)
+    f.write("kernel,counter,per_launch\n")
+    for k, d in sorted(agg.items()):
+        for c, v in sorted(d.items()):
+            if c in ("FETCH_SIZE", "WRITE_SIZE"): continue
+            line = "%s,%s,%.4g" % (k, c, v / max(n[(k, c)], 1))
+            f.write(line + "\n"); print(line)
 PY
