@@ -992,11 +992,14 @@ static OptWs ws_half(const OptWs& w, int ck0, int N, int NP, int C, int hw) {
 // FRESCO_OPT_SPLIT = 0: one stream; 1: two streams, same start; 2: second half starts behind the first half's Gram launch;
 // 3: the MFMA-bound launches of the two halves strictly alternate (half 1's Gram waits for half 0's S V of the same
 // iteration, half 0's next Gram for half 1's S V), the HBM-bound launches float beside them -- without the events two
-// free-running pipelines fall back into lockstep within two iterations (profiles/r04_opt_trace_split.txt).
+// free-running pipelines fall back into lockstep within two iterations (profiles/r04_opt_trace_split.txt);
+// 4: as 3, and a half's adam (+ next prep) additionally waits for the OTHER half's Gram launch to finish, so that the
+// HBM-bound launches run beside the S V launch (the least memory-hungry one), never beside a Gram launch.
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
-    hipEvent_t sv_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][iteration parity]
+    hipEvent_t sv_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // [half][iteration parity]
+    hipEvent_t gram_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][iteration parity]
 };
 static SideStream* side_stream() {
     static SideStream tab[32];
@@ -1009,6 +1012,7 @@ static SideStream* side_stream() {
         (void)hipEventCreateWithFlags(&t.mid, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&t.join, hipEventDisableTiming);
         for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&t.sv_done[i >> 1][i & 1], hipEventDisableTiming);
+        for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&t.gram_done[i >> 1][i & 1], hipEventDisableTiming);
     }
     return &t;
 }
@@ -1018,7 +1022,7 @@ static int opt_split_mode(int planes_hw) {
         return e ? atoi(e) : -1;
     }();
     if (env >= 0) return env;
-    return planes_hw >= 8 * 1024 ? 2 : 0;  // small planes are launch-bound: twice the launches would not pay
+    return planes_hw >= 8 * 1024 ? 1 : 0;  // small planes are launch-bound: twice the launches would not pay
 }
 
 extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
@@ -1055,6 +1059,38 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
             (void)hipEventRecord(sd->fork, st);  // (memsets + CSR are behind this)
             (void)hipStreamWaitEvent(sd->s, sd->fork, 0);
             opt_fast_begin(ws, cs, N, C, hw, st);
+            if (split == 4) {
+                // host issue order: front0(1) front1(1) | back0(1) front0(2) | back1(1) front1(2) | back0(2) front0(3) | ...
+                auto issue = [&](int half, int it, int parts) {
+                    FastSync y;
+                    y.parts = parts;
+                    const int par = it & 1;
+                    if (parts & 1) {
+                        // Gram of half 0 waits for S V of half 1 of the previous iteration, Gram of half 1 for S V of half 0 of this one
+                        y.wait_before_gram = half == 0 ? (it > 1 ? sd->sv_done[1][par ^ 1] : nullptr) : sd->sv_done[0][par];
+                        y.record_after_gram = sd->gram_done[half][par];
+                        y.record_after_sv = sd->sv_done[half][par];
+                    }
+                    if (parts & 2)  // adam(it) of half 0 runs beside S V(it) of half 1, adam(it) of half 1 beside S V(it + 1) of half 0
+                        y.wait_before_adam = half == 0 ? sd->gram_done[1][par] : (it < iters ? sd->gram_done[0][par ^ 1] : nullptr);
+                    const AdamArgs a = adam_args(it, lr, beta1, beta2, eps);
+                    if (half == 0)
+                        opt_fast_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, 1, C, h, w, intra_weight, has_t,
+                                         0, nullptr, nullptr, a, st, L, chunk * N, &y);
+                    else
+                        opt_fast_closure(w1, cs1, fwd_flow, bwd_flow, fwd_occ, bwd_occ, tg1, 1, C, h, w, intra_weight, has_t, 0,
+                                         nullptr, nullptr, a, sd->s, L, chunk * N, &y);
+                };
+                opt_fast_begin(w1, cs1, N, C, hw, sd->s);
+                issue(0, 1, 1);
+                issue(1, 1, 1);
+                for (int it = 1; it <= iters; ++it) {
+                    issue(0, it, 2);
+                    if (it < iters) issue(0, it + 1, 1);
+                    issue(1, it, 2);
+                    if (it < iters) issue(1, it + 1, 1);
+                }
+            } else
             for (int it = 1; it <= iters; ++it) {
                 const AdamArgs a = adam_args(it, lr, beta1, beta2, eps);
                 const int par = it & 1;

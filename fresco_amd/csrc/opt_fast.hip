@@ -42,30 +42,43 @@ static int opt_abl() {
     return v;
 }
 
-// channel octets per thread (K) and number of channel slices (NPART) of prep / adam
-static void fast_slices(int C, int* K, int* NPART) {
+// Work split of prep / adam: a thread owns K channel octets of one pixel, a 256-thread block 64 pixels x 4 such slices.
+// NPART = slices per pixel, NPB = blocks per pixel = partial sums of squares per pixel (one per block, <= FAST_MAX_PART).
+// K = 5 on the big planes (taps / CSR rows are set up once per thread), fewer on planes too small to fill the chip
+// otherwise (8 x 8, 16 x 16: the launch is a latency chain of K dependent octet rounds).
+static void fast_slices(int C, int planes, int hw, int* K, int* NPART, int* NPB) {
     const int C8 = C / 8;
-    int k = 5;
-    while ((C8 + k - 1) / k > FAST_MAX_PART) ++k;
-    *K = k;
-    *NPART = (C8 + k - 1) / k;
+    int64_t k = (int64_t)planes * hw * C8 / 262144;
+    k = k < 1 ? 1 : (k > 5 ? 5 : k);
+    while (((C8 + k - 1) / k + 3) / 4 > FAST_MAX_PART) ++k;
+    *K = (int)k;
+    *NPART = (int)((C8 + k - 1) / k);
+    *NPB = (*NPART + 3) / 4;
+}
+
+// sum over the 4 slices of a block, in slice order; valid in the threads of slice 0
+__device__ __forceinline__ float slice_sum_4(float v, int px, int sl, float (*red)[64]) {
+    red[sl][px] = v;
+    __syncthreads();
+    return red[0][px] + red[1][px] + red[2][px] + red[3][px];
 }
 
 // ------------------------------------------------------------------------------------------------
-// part[b][j][p] = sum of x^2 over channel slice j (first iteration only).  grid (hw/64, ceil(NPART/4), B)
+// part[b][blockIdx.y][p] = sum of x^2 over the block's 4 channel slices (first iteration only).  grid (hw/64, NPB, B)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ cs, float* __restrict__ part, int C,
                                                              int hw, int K, int NPART) {
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + px, j = blockIdx.y * 4 + sl, b = blockIdx.z;
-    if (j >= NPART) return;
-    const int cb = j * 8 * K, ce = min(cb + 8 * K, C);
+    __shared__ float red[4][64];
+    const int cb = min(j * 8 * K, C), ce = min(cb + 8 * K, C);
     float acc = 0.f;
     for (int c = cb; c < ce; ++c) {
         const float x = cs[((int64_t)b * C + c) * hw + p];
         acc = fmaf(x, x, acc);
     }
-    part[((int64_t)b * NPART + j) * hw + p] = acc;
+    const float tot = slice_sum_4(acc, px, sl, red);
+    if (sl == 0) part[((int64_t)b * gridDim.y + blockIdx.y) * hw + p] = tot;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -82,7 +95,7 @@ struct PrepArgs {
     int8_t *sgn1, *sgn2;
     float* loss;
     TLayout L;
-    int C, h, w, K, NPART, has_t, pm_tiled, cm_tiled, abl;
+    int C, h, w, K, NPART, NPB, has_t, pm_tiled, cm_tiled, abl;
 };
 
 __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
         float n = 1.f;
         if (do_norm) {
             float ss = 0.f;
-            for (int s = 0; s < a.NPART; ++s) ss += a.part[(bn * a.NPART + s) * hw + p];  // same order in every thread
+            for (int s = 0; s < a.NPB; ++s) ss += a.part[(bn * a.NPB + s) * hw + p];  // same order in every thread
             n = sqrtf(ss);
             if (j == 0) a.nrm[bn * hw + p] = n;
         }
@@ -150,7 +163,8 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
                     h8[k] = hi16;
                     l8[k] = lo16;
                     const int c = c0 + k;
-                    const int64_t ov = a.cm_tiled ? ((((int64_t)bn * (C / 128) + c / 128) * (hw / 32) + p / 32) * 128 + c % 128) * 32 + p % 32
+                    const int64_t ov = a.cm_tiled ? ((((int64_t)bn * (C / 128) + c / 128) * (hw / 32) + p / 32) * 128 + c % 128) * 32 +
+                                                        (((((p & 31) >> 3) ^ (c >> 2)) & 3) << 3) + (p & 7)
                                                   : ((int64_t)bn * C + c) * hw + p;
                     if (!(a.abl & 4)) {
                         a.vh[ov] = hi16;
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(AdamKArgs k) {
     const int hw = k.hw, C = k.C, C8 = C >> 3;
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + px, j = blockIdx.y * 4 + sl, b = blockIdx.z;
-    if (j >= k.NPART) return;
+    __shared__ float red[4][64];
     float dot = 0.f, inv_n = 0.f, n = 1.f;
     if (k.has_s) {
         for (int s = 0; s < k.NCT; ++s) dot += k.dotp[((int64_t)b * k.NCT + s) * hw + p];
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(AdamKArgs k) {
     const AdamArgs a = k.a;
     float ss = 0.f;
     const int o_end = min((j + 1) * k.K, C8);
-    for (int o = j * k.K; o < o_end; ++o) {
+    for (int o = min(j * k.K, C8); o < o_end; ++o) {
         float tgv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (k.has_t) tp.values(k.tg, o, p, C8, hw, tgv);
         const int64_t o0 = ((int64_t)b * C + o * 8) * hw + p;
@@ -239,7 +253,25 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(AdamKArgs k) {
             }
         }
     }
-    if (k.mode == 0 && k.has_s) k.part[((int64_t)b * k.NPART + j) * hw + p] = ss;
+    if (k.mode == 0 && k.has_s) {  // (uniform: every thread of the block gets here)
+        const float tot = slice_sum_4(ss, px, sl, red);
+        if (sl == 0) k.part[((int64_t)b * gridDim.y + blockIdx.y) * hw + p] = tot;
+    }
+}
+
+// Where the 16-byte piece S[p][q .. q + 15] (q % 16 == 0) of the sign matrix goes.  Plain layout: row-major.  Tiled (what
+// sv16b_kernel streams): [plane][pixel tile of 256][chunk of 32 q][256 rows p][32 bytes], the four 8-byte units of a row
+// XOR-swizzled with (p >> 3) & 3: the piece lands in 16-byte half ((q >> 4) & 1) ^ (g >> 1) and its two units are swapped if g & 1.
+__device__ __forceinline__ void s_store_piece(int8_t* __restrict__ sgn_out, u32x4 v, int b, int p, int q, int hw, int s_tiled) {
+    int64_t so;
+    if (s_tiled) {
+        const int g = (p >> 3) & 3;
+        so = ((((int64_t)b * (hw / 256) + p / 256) * (hw / 32) + q / 32) * 256 + p % 256) * 32 + ((((q >> 4) & 1) ^ (g >> 1)) << 4);
+        if (g & 1) v = u32x4{v[2], v[3], v[0], v[1]};
+    } else {
+        so = ((int64_t)b * hw + p) * hw + q;
+    }
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(sgn_out + so));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,9 +384,7 @@ __global__ __launch_bounds__(NW * 64) void gram16s_kernel(const half_t* __restri
             }
             packed[e4] = wv;
         }
-        const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
-                                   : ((int64_t)b * hw + gp) * hw + gq;
-        *reinterpret_cast<u32x4*>(sgn_out + so) = packed;
+        s_store_piece(sgn_out, packed, b, gp, gq, hw, s_tiled);
     }
     if (loss) {
         const float tot = wave_sum(lsum);
@@ -599,9 +629,7 @@ __global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restric
         const int a = 2 * ti + (rl >> 7);
         if (a > tj) continue;
         const int gp = p0 + rl, gq = q0 + ch * 16;
-        const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
-                                   : ((int64_t)b * hw + gp) * hw + gq;
-        *reinterpret_cast<uint4*>(sgn_out + so) = *reinterpret_cast<const uint4*>(tr + rl * GX_TRS + ch * 16);
+        s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, gp, gq, hw, s_tiled);
     }
     if (2 * ti < tj) {  // at least the upper half is above the diagonal: transposed copy
         __syncthreads();
@@ -622,9 +650,7 @@ __global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restric
             const int a = 2 * ti + (ch >> 3);
             if (a >= tj) continue;
             const int gp = q0 + rl, gq = p0 + ch * 16;
-            const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
-                                       : ((int64_t)b * hw + gp) * hw + gq;
-            *reinterpret_cast<uint4*>(sgn_out + so) = *reinterpret_cast<const uint4*>(tr + rl * GX_TRS2 + ch * 16);
+            s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS2 + ch * 16), b, gp, gq, hw, s_tiled);
         }
     }
     if (loss) {
@@ -799,9 +825,7 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
         const int a = 2 * ti + (rl >> 7);
         if (a > tj) continue;
         const int gp = p0 + rl, gq = q0 + ch * 16;
-        const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
-                                   : ((int64_t)b * hw + gp) * hw + gq;
-        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), reinterpret_cast<u32x4*>(sgn_out + so));
+        s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, gp, gq, hw, s_tiled);
     }
     if (2 * ti < tj) {  // at least the upper half is above the diagonal: transposed copy
         __syncthreads();
@@ -822,9 +846,7 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
             const int a = 2 * ti + (ch >> 3);
             if (a >= tj) continue;
             const int gp = q0 + rl, gq = p0 + ch * 16;
-            const int64_t so = s_tiled ? ((((int64_t)b * (hw / 256) + gp / 256) * (hw / 32) + gq / 32) * 256 + gp % 256) * 32 + gq % 32
-                                       : ((int64_t)b * hw + gp) * hw + gq;
-            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(tr + rl * GX_TRS2 + ch * 16), reinterpret_cast<u32x4*>(sgn_out + so));
+            s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS2 + ch * 16), b, gp, gq, hw, s_tiled);
         }
     }
     if (LOSS) {
@@ -989,18 +1011,21 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
 //     for its chunk the other multiplies;
 //   * S stays ONE BYTE per sign in LDS (the fp16 high byte, sign_byte): half the LDS bytes of the widened form, expanded
 //     to packed halfs after the ds_read_b64 with two v_perm_b32 per dword.
-// LDS rows: V 64 B + 16 B pad, S 32 B + 16 B pad (odd multiples of 16: conflict-free fragment reads); the pad chunks
-// are DMA'd too (they re-read chunk 0) so that a slot is a linear sequence of 1 KiB pieces.
+// Round 4: LDS rows WITHOUT pad bytes (V 64 B, S 32 B): the producers store both operands swizzled -- 16-byte unit u
+// of V row c at u ^ ((c >> 2) & 3), 8-byte unit u of S row p at u ^ ((p >> 3) & 3) -- so a slot is 24 linear 1 KiB DMA
+// pieces (3 per wave; 32 with the pad chunks before: -25 % bytes and DMA issues per MFMA), fragment reads stay
+// conflict-free (the padded S rows had 2-way conflicts: 25 % of the LDS cycles, profiles/r04_pmc_opt_gram16x.csv), and
+// three slots (72 KB) fit twice per CU: chunks arrive two steps ahead.
 // ------------------------------------------------------------------------------------------------
 constexpr int SB_TC = 128, SB_K = 32;
-constexpr int SB_VROW = SB_K * 2 + 16, SB_SROW = SB_K + 16;
-constexpr int SB_VARR = SB_TC * SB_VROW;          // one V array (hi or lo) of a slot: 10 pieces
-constexpr int SB_NSLOT = 2;
+constexpr int SB_VROW = SB_K * 2, SB_SROW = SB_K;
+constexpr int SB_VARR = SB_TC * SB_VROW;          // one V array (hi or lo) of a slot: 8 pieces
+constexpr int SB_NSLOT = 3;
 template <int TP>                                 // pixels per workgroup tile (waves of 64 x TP/4)
 struct SbCfg {
     static constexpr int NJ = TP / 128;               // 32-column blocks per wave
     static constexpr int SARR = TP * SB_SROW;         // the S rows of a slot
-    static constexpr int SLOT = 2 * SB_VARR + SARR;   // 44 KiB (TP = 512) / 32 KiB
+    static constexpr int SLOT = 2 * SB_VARR + SARR;   // 24 KiB
     static constexpr int NP = SLOT / 1024;            // 1 KiB pieces per slot
     static constexpr int NPW = (NP + 7) / 8;          // pieces per wave and slot (the last waves one fewer)
 };
@@ -1011,7 +1036,7 @@ __device__ __forceinline__ void sb_wait_barrier() {
 }
 
 template <int TP, int NS>
-__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
+__global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
                                                        const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
                                                        float* __restrict__ dotp, int C, int hw, float alpha) {
     using Cfg = SbCfg<TP>;
@@ -1040,42 +1065,28 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_
         __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sb_smem);
 
     // DMA: wave w issues pieces w, w + 8, ... of a slot; per-lane source offset inside its array, computed once
-    uint32_t doff[SB_NPW];
-#pragma unroll
-    for (int i = 0; i < SB_NPW; ++i) {
-        const int pc = wave + 8 * i;
-        if (pc < 2 * (SB_VARR / 1024)) {  // a V array: rows of 5 chunks (4 data + pad)
-            const int o = (pc % (SB_VARR / 1024)) * 1024 + lane * 16;
-            const int row = o / SB_VROW, cc = (o % SB_VROW) / 16;
-            doff[i] = (uint32_t)(row * SB_K * 2 + (cc < 4 ? cc * 16 : 0));
-        } else {  // S: rows of 3 chunks (2 data + pad)
-            const int o = (pc - 2 * (SB_VARR / 1024)) * 1024 + lane * 16;
-            const int row = o / SB_SROW, cc = (o % SB_SROW) / 16;
-            doff[i] = (uint32_t)(row * SB_K + (cc < 2 ? cc * 16 : 0));
-        }
-    }
+    static_assert(SB_NP == 24 && SB_NPW == 3, "wave w copies KiB w of Vh, of Vl and of S");
+    const uint32_t voff = (uint32_t)lane * 16;
+    const char* s_vh = vhb + wave * 1024;
+    const char* s_vl = vlb + wave * 1024;
+    const char* s_s = sbp + wave * 1024;
     auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < SB_NPW; ++i) {
-            const int pc = wave + 8 * i;
-            if (pc < SB_NP) {
-                const int arr = pc / (SB_VARR / 1024);  // 0: Vh, 1: Vl, >= 2: S
-                const char* src = arr == 0 ? vhb + (int64_t)kc * (128 * SB_K * 2)
-                                           : (arr == 1 ? vlb + (int64_t)kc * (128 * SB_K * 2) : sbp + (int64_t)kc * (256 * SB_K));
-                const uint32_t m0v = lds0 + (uint32_t)(slot * SB_SLOT + pc * 1024);
-                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(doff[i]), "s"(src), "s"(m0v)
-                             : "memory");
-            }
-        }
+        const uint32_t m0b = lds0 + (uint32_t)(slot * SB_SLOT + wave * 1024);
+#define SB_PIECE(OFF, SRC)                                                                                        \
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(SRC), "s"(m0b + (uint32_t)(OFF)) \
+                 : "memory")
+        SB_PIECE(0, s_vh + (int64_t)kc * SB_VARR);
+        SB_PIECE(SB_VARR, s_vl + (int64_t)kc * SB_VARR);
+        SB_PIECE(2 * SB_VARR, s_s + (int64_t)kc * Cfg::SARR);
+#undef SB_PIECE
     };
-    const int many = wave < SB_NP - 8 * (SB_NPW - 1) ? 1 : 0;  // this wave issues SB_NPW pieces per slot (else one fewer)
     auto wait_barrier = [&](int keep) __attribute__((always_inline)) {  // keep = newer slots that may stay in flight
         if (keep == 0)
             sb_wait_barrier<0>();
-        else if (many)
+        else if (keep == 1)
             sb_wait_barrier<SB_NPW>();
         else
-            sb_wait_barrier<SB_NPW - 1>();
+            sb_wait_barrier<2 * SB_NPW>();
     };
 
     floatx16 acc[2][NJ];
@@ -1087,27 +1098,29 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = hw / SB_K;
+    static_assert(NS == 3, "ring protocol below: chunks two steps ahead");
     stage(0, 0);
-    if (NS > 2 && nk > 1) stage(1, 1);
-    wait_barrier(NS > 2 && nk > 1 ? 1 : 0);
+    if (nk > 1) stage(1, 1);
+    wait_barrier(nk > 1 ? 1 : 0);
+    // fragment addresses: V row R (64 B): unit (ks*2 + hi) at ^((R >> 2) & 3); S row P (32 B): 8-byte unit (ks*2 + hi) at ^((P >> 3) & 3)
+    const int swv = (l31 >> 2) & 3, sws = (l31 >> 3) & 3;
+    const int ra = (wm * 64 + l31) * SB_VROW, rs = 2 * SB_VARR + (wn * (32 * NJ) + l31) * SB_SROW;
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        // the slot of chunk kc - 1 takes chunk kc + NS - 1
-        if (kc + NS - 1 < nk) stage(kc + NS - 1, slot >= 1 ? slot - 1 : NS - 1);
+        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : NS - 1);  // the slot chunk kc - 1 was read from
         const char* base = sb_smem + slot * SB_SLOT;
 #pragma unroll
         for (int ks = 0; ks < SB_K / 16; ++ks) {
             half8_t fa[2][2], fb[NJ];
+            const int ua = ((ks * 2 + hi) ^ swv) * 16, us = ((ks * 2 + hi) ^ sws) * 8;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int off = (wm * 64 + i * 32 + l31) * SB_VROW + ks * 32 + hi * 16;
-                fa[i][0] = *reinterpret_cast<const half8_t*>(base + off);
-                fa[i][1] = *reinterpret_cast<const half8_t*>(base + SB_VARR + off);
+                fa[i][0] = *reinterpret_cast<const half8_t*>(base + ra + i * 32 * SB_VROW + ua);
+                fa[i][1] = *reinterpret_cast<const half8_t*>(base + SB_VARR + ra + i * 32 * SB_VROW + ua);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const u32x2 raw = *reinterpret_cast<const u32x2*>(base + 2 * SB_VARR +
-                                                                  (wn * (32 * NJ) + j * 32 + l31) * SB_SROW + ks * 16 + hi * 8);
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(base + rs + j * 32 * SB_SROW + us);
                 u32x4 w;
                 w[0] = __builtin_amdgcn_perm(0u, raw[0], 0x010c000cu);
                 w[1] = __builtin_amdgcn_perm(0u, raw[0], 0x030c020cu);
@@ -1123,7 +1136,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (kc + 1 < nk) wait_barrier(NS == 2 ? 0 : (kc + 2 < nk ? 1 : 0));
+        if (kc + 1 < nk) wait_barrier(kc + 2 < nk ? 1 : 0);
         slot = slot == NS - 1 ? 0 : slot + 1;
     }
     // epilogue: dV^T, and (dotp) this workgroup's share of <V, dV> per pixel: the sum over its 128 channels, V = Vh + Vl
@@ -1138,13 +1151,16 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void sv16b_kernel(const half_
 #pragma unroll
         for (int ni = 0; ni < NJ; ++ni) {
             const int col = p0 + wn * (32 * NJ) + ni * 32 + l31;
-            const int64_t vt0 = (int64_t)(col >> 5) * (128 * 32) + l31;  // tiled V: [pixel chunk of 32][128 channels][32 pixels]
+            const int64_t vt0 = (int64_t)(col >> 5) * (128 * 32) + (l31 & 7);  // tiled V: [pixel chunk of 32][128 channels][4 swizzled units of 8 pixels]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const float val = acc[mi][ni][r] * alpha;
                 dvt[((int64_t)b * C + c0 + rl) * hw + col] = val;
-                if (dotp) dsum[ni] = fmaf(val, (float)vht[vt0 + rl * 32] + (float)vlt[vt0 + rl * 32], dsum[ni]);
+                if (dotp) {
+                    const int64_t vi = vt0 + rl * 32 + ((((l31 >> 3) ^ (rl >> 2)) & 3) << 3);
+                    dsum[ni] = fmaf(val, (float)vht[vi] + (float)vlt[vi], dsum[ni]);
+                }
             }
         }
     if (dotp) {
@@ -1173,10 +1189,9 @@ void launch_sv16_plain(const half_t* vh, const half_t* vl, const int8_t* ssign, 
 }
 
 void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, hipStream_t st) {
-    int K, NPART;
-    fast_slices(C, &K, &NPART);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(hw / 64, (NPART + 3) / 4, planes), dim3(256), 0, st, cs, w.part, C, hw,
-                       K, NPART);
+    int K, NPART, NPB;
+    fast_slices(C, planes, hw, &K, &NPART, &NPB);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(hw / 64, NPB, planes), dim3(256), 0, st, cs, w.part, C, hw, K, NPART);
 }
 
 void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
@@ -1187,8 +1202,8 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     TLayout L = Lin;
     if (!has_t) L = TLayout{Lin.n_loc, Lin.n_loc, 1, nullptr, nullptr};
     const int planes = nck * L.n_loc;
-    int K, NPART;
-    fast_slices(C, &K, &NPART);
+    int K, NPART, NPB;
+    fast_slices(C, planes, hw, &K, &NPART, &NPB);
     const int NCT = (C + 127) / 128;
     const bool cm_tiled = sv_tiled_layout(hw, C);
     const bool small = hw <= 256 && C % 32 == 0;
@@ -1198,6 +1213,8 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         return (e && e[0] == 'x') ? 0 : 1;
     }();
     const float kscale = 2.f / ((float)Bg * (float)C * (float)hw);
+    const int parts = sync ? sync->parts : 3;
+    if (parts & 1) {
     {
         ProfScope ps(FRESCO_PROF_OPT_TSIGN, planes, C, hw, 0, st);
         PrepArgs pa;
@@ -1221,12 +1238,13 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         pa.w = wd;
         pa.K = K;
         pa.NPART = NPART;
+        pa.NPB = NPB;
         pa.has_t = has_t;
         pa.pm_tiled = big ? (gram_y ? 2 : 1) : 0;
         pa.cm_tiled = cm_tiled ? 1 : 0;
         pa.abl = opt_abl() & 15;
         const int nz = nck * (has_t ? L.n_pairs : L.n_loc);
-        hipLaunchKernelGGL(opt_prep_kernel, dim3(hw / 64, (NPART + 3) / 4, nz), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(opt_prep_kernel, dim3(hw / 64, NPB, nz), dim3(256), 0, st, pa);
     }
     float* gloss = loss ? loss + 1 : nullptr;
     if (sync && sync->wait_before_gram) (void)hipStreamWaitEvent(st, sync->wait_before_gram, 0);
@@ -1304,6 +1322,9 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         }
     }
     if (sync && sync->record_after_sv) (void)hipEventRecord(sync->record_after_sv, st);
+    }  // parts & 1
+    if (!(parts & 2)) return;
+    if (sync && sync->wait_before_adam) (void)hipStreamWaitEvent(st, sync->wait_before_adam, 0);
     {
         ProfScope ps(FRESCO_PROF_OPT_ADAM, planes, C, hw, 0, st);
         AdamKArgs ka;
@@ -1325,7 +1346,7 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         ka.has_s = 1;
         ka.mode = mode;
         ka.a = a;
-        hipLaunchKernelGGL(opt_adam_kernel, dim3(hw / 64, (NPART + 3) / 4, planes), dim3(256), 0, st, ka);
+        hipLaunchKernelGGL(opt_adam_kernel, dim3(hw / 64, NPB, planes), dim3(256), 0, st, ka);
     }
 }
 

@@ -173,7 +173,8 @@ __device__ __forceinline__ float sign_from_byte(uint32_t b) {
 }
 
 // (the condition under which sv16b_kernel runs: its operands -- vh / vl and the sign bytes -- are then stored pre-tiled:
-// V as [plane][channel tile of 128][pixel chunk of 32][128][32] halfs, S as [plane][pixel tile of 256][chunk of 32][256][32] bytes)
+// V as [plane][channel tile of 128][pixel chunk of 32][128][32] halfs, S as [plane][pixel tile of 256][chunk of 32][256][32] bytes,
+// both with XOR-swizzled units inside a row: see sv16b_kernel)
 __host__ __device__ __forceinline__ bool sv_tiled_layout(int hw, int C) { return hw % 256 == 0 && C % 128 == 0; }
 // (the condition under which gram16x_kernel runs: the pixel-major operand copies are then stored pre-tiled AND swizzled:
 // [plane][pixel tile of 128][channel chunk of 32][128 pixels][4 x 16-byte units], unit u of pixel row r at position
@@ -202,7 +203,8 @@ void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, 
 // half); mode 0 = Adam step, mode 1 = write the gradient to gout.  Bg = global batch (normalises both loss terms);
 // sync (optional): events that order this pipeline against a second one on another stream
 struct FastSync {
-    hipEvent_t wait_before_gram = nullptr, record_after_gram = nullptr, record_after_sv = nullptr;
+    hipEvent_t wait_before_gram = nullptr, record_after_gram = nullptr, record_after_sv = nullptr, wait_before_adam = nullptr;
+    int parts = 3;  // 1: prep + gram + S V, 2: adam (a closure may be issued in two host calls)
 };
 void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
                       const float* bwd_occ, const float* target, int nck, int C, int h, int wd, float intra_weight,

@@ -87,22 +87,26 @@ def make_attention_case(N, R, layer, seed=0, occ_mode="bernoulli", dtype=torch.f
                 bwd_map=bwd_map, tmask=tmask, cf_mask=cf_mask, N=N, HW=HW, C=C, heads=heads)
 
 
-def oracle_attention(case, mode, round_dtype=torch.float16):
-    """fp32 oracle output of one layer call for mode in {'plain','full','cf_temporal','cf','temporal'}."""
+def oracle_attention(case, mode, round_dtype=torch.float16, device=None, chunk=2):
+    """fp32 oracle output of one layer call for mode in {'plain','full','cf_temporal','cf','temporal'}.
+    device: where torch evaluates the oracle's (device-agnostic) tensor code -- None = CPU; the biggest configurations
+    pass "cuda" (the CPU needs minutes there); tests/test_gpu_fullsize.py checks that the device does not matter."""
     from oracle import fresco_oracle as O
 
+    dev = device or "cpu"
     a = case["attn"]
-    W = [w.detach().float() for w in a.weights()]
-    bo = a.to_out[0].bias.detach().float()
+    W = [w.detach().float().to(dev) for w in a.weights()]
+    bo = a.to_out[0].bias.detach().float().to(dev)
     kw = {}
     if mode in ("full", "cf_temporal", "cf"):
-        kw.update(use_cf=True, cf_mask=case["cf_mask"])
+        kw.update(use_cf=True, cf_mask=case["cf_mask"].to(dev))
     if mode in ("full", "cf_temporal", "temporal"):
-        kw.update(fwd_map=case["fwd_map"][:, 0], tmask=case["tmask"][:, 0])
+        kw.update(fwd_map=case["fwd_map"][:, 0].to(dev), tmask=case["tmask"][:, 0].to(dev))
     if mode == "full":
-        kw.update(ref=case["ref"].float())
-    return O.fresco_attention(case["hidden"].float(), W[0], W[1], W[2], W[3], bo, case["heads"],
-                              round_dtype=round_dtype, **kw)
+        kw.update(ref=case["ref"].float().to(dev))
+    out = O.fresco_attention(case["hidden"].float().to(dev), W[0], W[1], W[2], W[3], bo, case["heads"],
+                             round_dtype=round_dtype, chunk=chunk, **kw)
+    return out.cpu()
 
 
 def controller_for(case, mode, device, dtype=None):

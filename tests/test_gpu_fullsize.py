@@ -77,9 +77,57 @@ def test_processor_cfg2_block_occlusions(mode):
     print("cfg2 L3 blocks %-11s (M = %d): max err %.2e" % (mode, M, e))
 
 
+def test_oracle_on_the_gpu_is_the_same_oracle():
+    """The configurations below evaluate the oracle's tensor code with torch on the GPU (fp32; the CPU needs minutes for
+    32 frames x 768^2).  Same code, same arithmetic type: at config 2's up_blocks.2 the two devices agree to fp32
+    round-off, far below the 1e-3 bar they are used for."""
+    case = _case("L2", "bernoulli")
+    a = synth.oracle_attention(case, "full", round_dtype=None)
+    b = synth.oracle_attention(case, "full", round_dtype=None, device=DEV)
+    d = float((a - b).abs().max())
+    print("oracle cpu vs cuda (cfg2 L2 full): max |d| = %.2e" % d)
+    assert d < 2e-5
+
+
+@pytest.mark.parametrize("N,R,layer", [(4, 256, "L3"), (4, 256, "L2"), (16, 512, "L3"), (16, 512, "L2")])
+@pytest.mark.parametrize("mode", ["full", "cf_temporal", "cf"])
+def test_processor_cfg1_cfg4_every_element(N, R, layer, mode):
+    """Config 1's shapes (4 keyframes at 256^2: HW 1024 / 256) and config 4's (16 frames at 512^2: B = 32), every
+    element of the processor output vs the fp32 oracle (reference: src/diffusion_hacked.py:169-387)."""
+    case = synth.make_attention_case(N, R, layer, seed=7 + N, occ_mode="bernoulli")
+    out = _run_processor(case, mode)
+    ref = synth.oracle_attention(case, mode, round_dtype=None, device=DEV if N > 4 else None)
+    e = _check(out, ref, what="N=%d R=%d %s %s" % (N, R, layer, mode))
+    print("N=%d %dx%d %s %-11s: max |HIP - fp32 oracle| = %.2e over %d elements"
+          % (N, R, R, layer, mode, e, ref.numel()))
+
+
+@pytest.mark.parametrize("mode", ["cf_temporal", "cf"])
+def test_processor_cfg5_one_cfg_half(mode):
+    """Config 5's up_blocks.3 call (32 frames x 768^2: HW = 9216 per frame, ~10 300 cross-frame keys), ONE CFG half
+    (unet_chunk_size 1, B = 32): the shape the frame-parallel claim rests on."""
+    import fresco_amd
+    case = synth.make_attention_case(32, 768, "L3", seed=9, occ_mode="bernoulli")
+    half = dict(case)
+    half["hidden"] = case["hidden"][:32].contiguous()
+    M = int(case["cf_mask"].sum())
+    proc = fresco_amd.FRESCOAttnProcessor2_0(1, synth.controller_for(half, mode, DEV))
+    attn = copy.deepcopy(case["attn"]).to(DEV).half()
+    with torch.no_grad():
+        out = proc(attn, half["hidden"].to(DEV).half())
+    ref = synth.oracle_attention(half, mode, round_dtype=None, device=DEV, chunk=1)
+    e = _check(out, ref, what="cfg5 L3 %s" % mode)
+    print("cfg5 L3 %-11s (HW 9216, M = %d, B 32): max |HIP - fp32 oracle| = %.2e" % (mode, M, e))
+
+
+@pytest.mark.parametrize("vscale,atol", [(1.0, 2e-3), (0.4, 1e-3)])
 @pytest.mark.parametrize("N,R,layer", [(8, 512, "L3"), (32, 768, "L3"), (32, 768, "L2")])
-def test_temporal_kernel_at_real_sizes(N, R, layer):
-    """fresco_temporal_attn alone, fp16 inputs, vs the fp32 per-pixel restatement (oracle.temporal_attention)."""
+def test_temporal_kernel_at_real_sizes(N, R, layer, vscale, atol):
+    """fresco_temporal_attn alone, fp16 inputs, vs the fp32 per-pixel restatement (oracle.temporal_attention).
+    The contract is BASELINE.json's 1e-3: it holds on the pipeline's activations -- q, k, v are projections of
+    LayerNorm outputs, |v| <~ 2, where half an fp16 ulp of the OUTPUT is <= 4.9e-4 (vscale 0.4: |v| reaches ~2) --
+    and cannot hold for N(0,1) v (|v| reaches 4-5, half an output ulp there is 1.95e-3: the fp16 output grid itself):
+    that case keeps the 2e-3 bar and documents why."""
     import fresco_amd.ops as ops
     g = synth.gen(40 + N)
     C, down = (640, 16) if layer == "L2" else (320, 8)
@@ -90,15 +138,15 @@ def test_temporal_kernel_at_real_sizes(N, R, layer):
     imgs = torch.rand(N, 3, R, R, generator=g)
     fwd_map, _, tmask = O.mapping_ind(flows[1], occs[1], imgs, scale=float(down))
     assert tuple(fwd_map.shape) == (N, 1, HW) and tuple(tmask.shape) == (HW, 1, N, N)
-    q = torch.randn(2 * N, HW, C, generator=g).half()
-    k = torch.randn(2 * N, HW, C, generator=g).half()
-    v = torch.randn(2 * N, HW, C, generator=g).half()
+    q = (vscale * torch.randn(2 * N, HW, C, generator=g)).half()
+    k = (vscale * torch.randn(2 * N, HW, C, generator=g)).half()
+    v = (vscale * torch.randn(2 * N, HW, C, generator=g)).half()
     scale = 0.2 / math.sqrt(C // H)
     out = ops.temporal_attention(q.to(DEV), k.to(DEV), v.to(DEV), fwd_map.to(DEV), tmask.to(DEV), H, scale, 2)
     ref = O.temporal_attention(q.float(), k.float(), v.float(), fwd_map[:, 0], tmask[:, 0], H, scale, 2)
-    e = _check(out, ref, atol=2e-3, rtol=1e-3, what="temporal N=%d HW=%d" % (N, HW))  # |v| reaches 4-5: fp16 output grid
-    print("temporal N=%d HW=%d C=%d: max err %.2e, %.1f %% of the frame pairs masked"
-          % (N, HW, C, e, 100 * (1 - float(tmask.float().mean()))))
+    e = _check(out, ref, atol=atol, rtol=1e-3, what="temporal N=%d HW=%d" % (N, HW))
+    print("temporal N=%d HW=%d C=%d |v| max %.1f: max err %.2e (bar %.0e), %.1f %% of the frame pairs masked"
+          % (N, HW, C, float(v.abs().max()), e, atol, 100 * (1 - float(tmask.float().mean()))))
 
 
 @pytest.mark.parametrize("C,h", [(640, 64), (1280, 32), (1280, 16), (1280, 8)])
@@ -159,3 +207,63 @@ def test_opt_20_iterations_final_loss_at_a_shipping_shape():
           % (C, h, h, float(l_0), float(l_ours), float(l_ref), abs(float(l_ours) - float(l_ref)) / float(l_ref)))
     assert float(l_ours) < float(l_0)
     assert abs(float(l_ours) - float(l_ref)) < 0.01 * float(l_ref)
+
+
+@pytest.mark.parametrize("C,h", [(640, 64), (1280, 32)])
+def test_opt_20_iterations_final_loss_at_the_big_shapes(C, h):
+    """The same criterion at the two shapes that cost 89 % of the feature optimisation's time: up_blocks.3's input
+    (C = 640, 64 x 64) and up_blocks.2's (C = 1280, 32 x 32), 8 frames, CFG batch 16, 20 Adam iterations
+    (src/diffusion_hacked.py:432-485).  The oracle's loop (analytic gradients, fp32) is evaluated by torch on the GPU
+    -- the CPU needs ~4 minutes for it -- and both end points are scored by the oracle's fp64 loss.  These shapes run
+    the two-stream form (one pipeline per CFG half): two runs must still be bit-identical."""
+    import fresco_amd.ops as ops
+    from fresco_amd.warp import _prep_flow_occ
+    N, R = 8, 512
+    case = synth.make_opt_case(N, C, h, R, seed=43)
+    x, tgt = case["x"], case["target"]
+    fd, od, td = [f.to(DEV) for f in case["flows"]], [o.to(DEV) for o in case["occs"]], tgt.to(DEV)
+    prep = _prep_flow_occ(h, fd, od, with_dilate=False)
+    cs = x.to(DEV).clone()
+    ops.opt_run(cs, prep, td, 100.0, 20, 2)
+    cs2 = x.to(DEV).clone()
+    ops.opt_run(cs2, prep, td, 100.0, 20, 2)
+    assert torch.equal(cs, cs2)
+    ref = O.optimize_feature(x.to(DEV), fd, od, [td], iters=20, return_raw=True)
+    prep64 = O.opt_prepare(h, fd, od, 2, torch.float64)
+    l_ours = float(O.opt_loss_and_grad(cs.double(), prep64, td.double(), 100.0)[0])
+    l_ref = float(O.opt_loss_and_grad(ref.double(), prep64, td.double(), 100.0)[0])
+    l_0 = float(O.opt_loss_and_grad(x.to(DEV).double(), prep64, td.double(), 100.0)[0])
+    print("opt 20 iterations C=%d %dx%d: loss %.6f -> ours %.6f, oracle %.6f (rel diff %.2e)"
+          % (C, h, h, l_0, l_ours, l_ref, abs(l_ours - l_ref) / l_ref))
+    assert l_ours < l_0
+    assert abs(l_ours - l_ref) < 0.01 * l_ref
+
+
+@pytest.mark.parametrize("C,h", [(640, 64), (1280, 32)])
+def test_opt_gradient_deviation_vs_the_oracles_one_ulp_envelope(C, h):
+    """SURVEY section 7, hard part 1: the gradient is a sum of sign() terms, so ANY fp32 evaluation differs from the
+    exact one wherever a residual sits within rounding of zero.  The yardstick is the oracle itself: (a) its fp32
+    gradient vs its fp64 gradient, (b) its fp32 gradient at x vs at x moved by ONE ulp in every element.  The HIP
+    gradient's deviation from the fp64 oracle (elements off by more than 1e-3 of the gradient's scale) must stay within
+    twice the larger of the two -- i.e. it is rounding noise of the same size, not an error of the kernels."""
+    import fresco_amd.ops as ops
+    from fresco_amd.warp import _prep_flow_occ
+    N, R = 8, 512
+    case = synth.make_opt_case(N, C, h, R, seed=31)
+    x = case["x"].to(DEV)
+    fd, od, td = [f.to(DEV) for f in case["flows"]], [o.to(DEV) for o in case["occs"]], case["target"].to(DEV)
+    prep64 = O.opt_prepare(h, fd, od, 2, torch.float64)
+    prep32 = O.opt_prepare(h, fd, od, 2, torch.float32)
+    g64 = O.opt_loss_and_grad(x.double(), prep64, td.double(), 100.0)[1]
+    g32 = O.opt_loss_and_grad(x, prep32, td, 100.0)[1].double()
+    x1 = torch.nextafter(x, torch.full_like(x, float("inf")))
+    g32p = O.opt_loss_and_grad(x1, prep32, td, 100.0)[1].double()
+    prep = _prep_flow_occ(h, fd, od, with_dilate=False)
+    ghip = ops.opt_loss_grad(x, prep, td, 100.0, 2)[1].double()
+    scale = float(g64.abs().max())
+    frac = lambda a, b: float(((a - b).abs() > 1e-3 * scale).double().mean())
+    f_f32, f_env, f_hip = frac(g32, g64), frac(g32p, g32), frac(ghip, g64)
+    print("opt gradient C=%d %dx%d, elements off by > 1e-3 of scale: oracle fp32 vs fp64 %.2e | oracle fp32, input moved by "
+          "1 ulp %.2e | HIP vs fp64 oracle %.2e" % (C, h, h, f_f32, f_env, f_hip))
+    assert f_hip <= 2.0 * max(f_f32, f_env) + 1e-5
+
