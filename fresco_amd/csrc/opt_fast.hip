@@ -30,7 +30,7 @@ bool opt_fast_ok(int C, int h, int w, int has_s) {
         return (e && e[0] == '1') ? 1 : 0;
     }();
     const int hw = h * w;
-    return !off && has_s && hw % 64 == 0 && C % 8 == 0 && (C + 127) / 128 <= FAST_MAX_PART;
+    return !off && has_s && hw % 64 == 0 && C % 8 == 0 && 2 * ((C + 127) / 128) <= FAST_MAX_PART;
 }
 
 // experiment switch (timing ablations; results are WRONG when set): FRESCO_OPT_ABL = bit mask, see the kernels
@@ -81,6 +81,11 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (sl == 0) part[((int64_t)b * gridDim.y + blockIdx.y) * hw + p] = tot;
 }
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  prep / adam blocks own 64 consecutive pixels
+// of a plane and gather from the rows just above / below (bilinear taps, CSR sources): give every XCD a CONTIGUOUS range
+// of pixel blocks so that neighbouring rows are fetched into ONE L2 instead of three.
+__device__ __forceinline__ int xcd_contiguous(int bx, int nx) { return nx % 8 == 0 ? (bx % 8) * (nx / 8) + bx / 8 : bx; }
+
 // ------------------------------------------------------------------------------------------------
 // prep: grid (hw/64, ceil(NPART/4), nck * (has_t ? n_pairs : n_loc)), 256 threads = 64 pixels x 4 channel slices.
 // The thread of (pixel p, slice j, pair pj) owns channels [8 K j, 8 K (j+1)) of pixel p of the pair's FIRST frame: it
@@ -101,7 +106,7 @@ struct PrepArgs {
 __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
     const int hw = a.h * a.w, C = a.C, C8 = C >> 3;
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + px;
+    const int p = xcd_contiguous(blockIdx.x, gridDim.x) * 64 + px;
     const int j = blockIdx.y * 4 + sl;
     const TLayout& L = a.L;
     const int NPZ = a.has_t ? L.n_pairs : L.n_loc;
@@ -208,7 +213,7 @@ struct AdamKArgs {
 __global__ __launch_bounds__(256) void opt_adam_kernel(AdamKArgs k) {
     const int hw = k.hw, C = k.C, C8 = C >> 3;
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + px, j = blockIdx.y * 4 + sl, b = blockIdx.z;
+    const int p = xcd_contiguous(blockIdx.x, gridDim.x) * 64 + px, j = blockIdx.y * 4 + sl, b = blockIdx.z;
     __shared__ float red[4][64];
     float dot = 0.f, inv_n = 0.f, n = 1.f;
     if (k.has_s) {
@@ -1019,74 +1024,74 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
 // ------------------------------------------------------------------------------------------------
 constexpr int SB_TC = 128, SB_K = 32;
 constexpr int SB_VROW = SB_K * 2, SB_SROW = SB_K;
-constexpr int SB_VARR = SB_TC * SB_VROW;          // one V array (hi or lo) of a slot: 8 pieces
 constexpr int SB_NSLOT = 3;
-template <int TP>                                 // pixels per workgroup tile (waves of 64 x TP/4)
-struct SbCfg {
-    static constexpr int NJ = TP / 128;               // 32-column blocks per wave
-    static constexpr int SARR = TP * SB_SROW;         // the S rows of a slot
-    static constexpr int SLOT = 2 * SB_VARR + SARR;   // 24 KiB
-    static constexpr int NP = SLOT / 1024;            // 1 KiB pieces per slot
-    static constexpr int NPW = (NP + 7) / 8;          // pieces per wave and slot (the last waves one fewer)
-};
-
 template <int N_>
 __device__ __forceinline__ void sb_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
 }
 
-template <int TP, int NS>
+// CT = channel rows per workgroup: 128 (8 waves as 2 x 4, wave tiles 64 x 64) for the full rounds of a launch, 64 (8 waves
+// as 1 x 8, wave tiles 64 x 32) for the tiles of the last, partly filled round: 1280 tiles on 512 workgroup slots are
+// 2.5 rounds -- run as 2 rounds of whole tiles + 1 round of half tiles (0.6 of the time) instead of 3 whole rounds.
+// Tile t of the launch's list = (plane, pixel tile, channel tile), channel tile fastest (neighbours share their S rows).
+// <V, dV> partials: two slots per channel tile (a whole tile writes its sum and a zero, half tiles one each).
+template <int CT>
 __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
                                                        const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
-                                                       float* __restrict__ dotp, int C, int hw, float alpha) {
-    using Cfg = SbCfg<TP>;
-    constexpr int SB_TP = TP, SB_SLOT = Cfg::SLOT, SB_NP = Cfg::NP, SB_NPW = Cfg::NPW, NJ = Cfg::NJ;
+                                                       float* __restrict__ dotp, int C, int hw, float alpha, int tile_base) {
+    constexpr int TP = 256, NS = SB_NSLOT;
+    constexpr int WM = CT / 64, WN = 8 / WM, NJ = TP / (32 * WN);
+    constexpr int VARR = CT * SB_VROW, SARR = TP * SB_SROW, SLOT = 2 * VARR + SARR;
     extern __shared__ __attribute__((aligned(16))) char sb_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
-    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8), each with its own L2: give every XCD a
-    // CONTIGUOUS range of the (plane, pixel tile, channel block) list, so that workgroups sharing operand rows run on
-    // the same L2.
-    int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int total = gridDim.x * gridDim.y * gridDim.z;
-    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
-    const int b = lin / (gridDim.x * gridDim.y);
-    // (channel block fastest: neighbours in the range share their S rows, 1 MB per pixel tile; measured against pixel
-    // tile fastest -- shared V tile, 2 MB --: 536 / 98 us instead of 547 / 107 at 64^2 / 32^2)
-    const int c0 = (lin % gridDim.y) * SB_TC, p0 = ((lin / gridDim.y) % gridDim.x) * SB_TP;
+    const int nct = C / SB_TC, npt = hw / TP;
+    int t, hf = 0;
+    if (CT == 128) {
+        // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8), each with its own L2: give every XCD a
+        // CONTIGUOUS range of the tile list, so that workgroups sharing operand rows run on the same L2
+        int g = blockIdx.x;
+        const int G = gridDim.x;
+        if (G % 8 == 0) g = (g % 8) * (G / 8) + g / 8;
+        t = tile_base + g;
+    } else {
+        t = tile_base + (blockIdx.x >> 1);
+        hf = blockIdx.x & 1;
+    }
+    const int b = t / (nct * npt);
+    const int c0 = (t % nct) * SB_TC, p0 = ((t / nct) % npt) * TP;
     // operands are pre-tiled (sv_tiled_layout): per (channel tile, pixel chunk) 128 x 32 halfs, per (pixel tile, chunk) 256 x 32 bytes
-    static_assert(SB_TC == 128 && SB_K == 32 && TP == 256, "tiled operand layout");
-    const char* vhb = reinterpret_cast<const char*>(vh + ((int64_t)b * (C / 128) + c0 / 128) * hw * 128);
-    const char* vlb = reinterpret_cast<const char*>(vl + ((int64_t)b * (C / 128) + c0 / 128) * hw * 128);
-    const char* sbp = reinterpret_cast<const char*>(sgn_in + ((int64_t)b * (hw / 256) + p0 / 256) * hw * 256);
+    const char* vhb = reinterpret_cast<const char*>(vh + ((int64_t)b * nct + c0 / 128) * hw * 128);
+    const char* vlb = reinterpret_cast<const char*>(vl + ((int64_t)b * nct + c0 / 128) * hw * 128);
+    const char* sbp = reinterpret_cast<const char*>(sgn_in + ((int64_t)b * npt + p0 / 256) * hw * 256);
     const uint32_t lds0 =
         __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sb_smem);
 
-    // DMA: wave w issues pieces w, w + 8, ... of a slot; per-lane source offset inside its array, computed once
-    static_assert(SB_NP == 24 && SB_NPW == 3, "wave w copies KiB w of Vh, of Vl and of S");
+    // DMA, 1 KiB pieces: CT = 128: wave w copies KiB w of Vh, of Vl and of S (3 pieces); CT = 64: waves 0-3 KiB w of the Vh
+    // half, waves 4-7 KiB w - 4 of the Vl half, every wave KiB w of S (2 pieces)
+    constexpr int NPW = CT == 128 ? 3 : 2;
     const uint32_t voff = (uint32_t)lane * 16;
-    const char* s_vh = vhb + wave * 1024;
-    const char* s_vl = vlb + wave * 1024;
+    const char* s_a = CT == 128 ? vhb + wave * 1024 : (wave < 4 ? vhb : vlb) + hf * VARR + (wave & 3) * 1024;
+    const char* s_l = vlb + wave * 1024;  // (CT = 128 only)
     const char* s_s = sbp + wave * 1024;
+    const uint32_t o_a = CT == 128 ? (uint32_t)(wave * 1024) : (uint32_t)((wave < 4 ? 0 : VARR) + (wave & 3) * 1024);
     auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
-        const uint32_t m0b = lds0 + (uint32_t)(slot * SB_SLOT + wave * 1024);
+        const uint32_t m0b = lds0 + (uint32_t)(slot * SLOT);
 #define SB_PIECE(OFF, SRC)                                                                                        \
     asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(SRC), "s"(m0b + (uint32_t)(OFF)) \
                  : "memory")
-        SB_PIECE(0, s_vh + (int64_t)kc * SB_VARR);
-        SB_PIECE(SB_VARR, s_vl + (int64_t)kc * SB_VARR);
-        SB_PIECE(2 * SB_VARR, s_s + (int64_t)kc * Cfg::SARR);
+        SB_PIECE(o_a, s_a + (int64_t)kc * (SB_TC * SB_VROW));
+        if (CT == 128) SB_PIECE(VARR + wave * 1024, s_l + (int64_t)kc * (SB_TC * SB_VROW));
+        SB_PIECE(2 * VARR + wave * 1024, s_s + (int64_t)kc * SARR);
 #undef SB_PIECE
     };
     auto wait_barrier = [&](int keep) __attribute__((always_inline)) {  // keep = newer slots that may stay in flight
         if (keep == 0)
             sb_wait_barrier<0>();
-        else if (keep == 1)
-            sb_wait_barrier<SB_NPW>();
         else
-            sb_wait_barrier<2 * SB_NPW>();
+            sb_wait_barrier<NPW>();
     };
 
     floatx16 acc[2][NJ];
@@ -1104,11 +1109,11 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
     wait_barrier(nk > 1 ? 1 : 0);
     // fragment addresses: V row R (64 B): unit (ks*2 + hi) at ^((R >> 2) & 3); S row P (32 B): 8-byte unit (ks*2 + hi) at ^((P >> 3) & 3)
     const int swv = (l31 >> 2) & 3, sws = (l31 >> 3) & 3;
-    const int ra = (wm * 64 + l31) * SB_VROW, rs = 2 * SB_VARR + (wn * (32 * NJ) + l31) * SB_SROW;
+    const int ra = (wm * 64 + l31) * SB_VROW, rs = 2 * VARR + (wn * (32 * NJ) + l31) * SB_SROW;
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
         if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : NS - 1);  // the slot chunk kc - 1 was read from
-        const char* base = sb_smem + slot * SB_SLOT;
+        const char* base = sb_smem + slot * SLOT;
 #pragma unroll
         for (int ks = 0; ks < SB_K / 16; ++ks) {
             half8_t fa[2][2], fb[NJ];
@@ -1116,7 +1121,7 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 fa[i][0] = *reinterpret_cast<const half8_t*>(base + ra + i * 32 * SB_VROW + ua);
-                fa[i][1] = *reinterpret_cast<const half8_t*>(base + SB_VARR + ra + i * 32 * SB_VROW + ua);
+                fa[i][1] = *reinterpret_cast<const half8_t*>(base + VARR + ra + i * 32 * SB_VROW + ua);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -1139,7 +1144,7 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
         if (kc + 1 < nk) wait_barrier(kc + 2 < nk ? 1 : 0);
         slot = slot == NS - 1 ? 0 : slot + 1;
     }
-    // epilogue: dV^T, and (dotp) this workgroup's share of <V, dV> per pixel: the sum over its 128 channels, V = Vh + Vl
+    // epilogue: dV^T, and (dotp) this workgroup's share of <V, dV> per pixel: the sum over its channels, V = Vh + Vl
     // re-read from the tiled copies (L2-resident: this workgroup has just streamed them)
     float dsum[NJ];
     const half_t* vht = reinterpret_cast<const half_t*>(vhb);
@@ -1154,7 +1159,7 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
             const int64_t vt0 = (int64_t)(col >> 5) * (128 * 32) + (l31 & 7);  // tiled V: [pixel chunk of 32][128 channels][4 swizzled units of 8 pixels]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int rl = hf * 64 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // row inside the 128-channel tile
                 const float val = acc[mi][ni][r] * alpha;
                 dvt[((int64_t)b * C + c0 + rl) * hw + col] = val;
                 if (dotp) {
@@ -1165,7 +1170,7 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
         }
     if (dotp) {
         __syncthreads();  // the ring is free
-        float* red = reinterpret_cast<float*>(sb_smem);  // [2][TP]
+        float* red = reinterpret_cast<float*>(sb_smem);  // [WM][TP]
 #pragma unroll
         for (int ni = 0; ni < NJ; ++ni) {
             float s = dsum[ni];
@@ -1173,10 +1178,17 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
             if (hi == 0) red[wm * TP + wn * (32 * NJ) + ni * 32 + l31] = s;
         }
         __syncthreads();
-        if (tid < TP) dotp[((int64_t)b * (C / SB_TC) + c0 / SB_TC) * hw + p0 + tid] = red[tid] + red[TP + tid];
+        if (tid < TP) {
+            float* dp = dotp + ((int64_t)b * (2 * nct) + 2 * (c0 / SB_TC)) * hw + p0 + tid;
+            if (CT == 128) {
+                dp[0] = red[tid] + red[TP + tid];
+                dp[hw] = 0.f;
+            } else {
+                dp[(int64_t)hf * hw] = red[tid];
+            }
+        }
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1204,7 +1216,7 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     const int planes = nck * L.n_loc;
     int K, NPART, NPB;
     fast_slices(C, planes, hw, &K, &NPART, &NPB);
-    const int NCT = (C + 127) / 128;
+    const int NCT = (C + 127) / 128;  // channel tiles of the S V kernels
     const bool cm_tiled = sv_tiled_layout(hw, C);
     const bool small = hw <= 256 && C % 32 == 0;
     const bool big = gram_x_layout(hw, C);
@@ -1308,15 +1320,34 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     {
         ProfScope ps(FRESCO_PROF_OPT_SV, planes, C, hw, 0, st);
         if (cm_tiled) {
-            constexpr int lds = SB_NSLOT * SbCfg<256>::SLOT;
+            constexpr int lds128 = SB_NSLOT * (2 * 128 * SB_VROW + 256 * SB_SROW), lds64 = SB_NSLOT * (2 * 64 * SB_VROW + 256 * SB_SROW);
             static const bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<256, SB_NSLOT>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<128>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds64);
                 return true;
             }();
             (void)once;
-            hipLaunchKernelGGL((sv16b_kernel<256, SB_NSLOT>), dim3(hw / 256, C / SB_TC, planes), dim3(512), lds, st, w.vh,
-                               w.vl, w.ssign, w.dvt, w.dotp, C, hw, 2.f * coef);
+            // whole tiles for the full rounds of the chip's 2 x 256 workgroup slots; the tiles of a last round that would
+            // fill at most a quarter of the slots (or a launch smaller than one round) run as two half tiles each: measured
+            // 116 -> 102 us at (1280, 32^2), 28 -> 21 us at (1280, 16^2); at (640, 64^2) -- 2.5 rounds -- the half-tile round
+            // does not pay (514 -> 534 us).  FRESCO_OPT_SVTAIL=0: whole tiles only
+            static const int tail_split = [] {
+                const char* e = getenv("FRESCO_OPT_SVTAIL");
+                return (e && e[0] == '0') ? 0 : 1;
+            }();
+            const int tiles = (hw / 256) * (C / SB_TC) * planes, slots = 512;
+            int rem = tiles % slots;
+            if (!tail_split || (rem > slots / 4 && tiles > slots)) rem = 0;
+            if (tiles <= slots && tiles > slots / 2) rem = 0;  // (more than half a round of whole tiles: leave it)
+            const int whole = tiles - rem;
+            if (whole > 0)
+                hipLaunchKernelGGL(sv16b_kernel<128>, dim3(whole), dim3(512), lds128, st, w.vh, w.vl, w.ssign, w.dvt, w.dotp, C,
+                                   hw, 2.f * coef, 0);
+            if (rem > 0)
+                hipLaunchKernelGGL(sv16b_kernel<64>, dim3(2 * rem), dim3(512), lds64, st, w.vh, w.vl, w.ssign, w.dvt, w.dotp, C,
+                                   hw, 2.f * coef, whole);
         } else {
             launch_sv16_plain(w.vh, w.vl, w.ssign, w.dvt, w.dotp, planes, C, hw, 2.f * coef, st);
         }
@@ -1341,7 +1372,7 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         ka.hw = hw;
         ka.K = K;
         ka.NPART = NPART;
-        ka.NCT = NCT;
+        ka.NCT = cm_tiled ? 2 * NCT : NCT;  // (sv16b writes two <V, dV> slots per channel tile)
         ka.has_t = has_t;
         ka.has_s = 1;
         ka.mode = mode;
