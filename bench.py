@@ -517,6 +517,7 @@ def main():
             "roofline": roofline,
             "kernel_avg_us": kernels_us,
             "launch_mode": launch_mode,
+            "ms_per_step_by_mode": {"eager": round(1e3 * dt / args.steps, 4)},
         }
         if world > 1:
             M_rest = {}
@@ -547,6 +548,12 @@ def main():
 
             res["torch_gpu_baseline"] = torch_gpu_baseline(layers, params, N, device, ours)
             res["speedup_vs_torch_gpu"] = round(res["value"] / res["torch_gpu_baseline"]["value"], 2)
+            # BASELINE.md publishes no number for this metric (`published: {}`); the judge's round-3 instruction is to
+            # report the ratio against the reference's own op sequence on the same GPU here
+            res["vs_baseline"] = res["speedup_vs_torch_gpu"]
+            res["vs_baseline_note"] = ("value / torch_gpu_baseline.value: the reference's PyTorch op sequence (oracle/torch_path.py, "
+                                       "kind 'port', pinned against the reference's goldens) timed on this GPU in this run; "
+                                       "BASELINE.md holds no published number.  north_star target 10x: not met")
             res["speedup_vs_torch_gpu_lean_port"] = round(
                 res["value"] / res["torch_gpu_baseline"]["lean_port"]["value"], 2)
             res["cpu_baseline"] = cpu_baseline(layers, params, N)
@@ -555,6 +562,14 @@ def main():
             import bench_opt
 
             res["cfg3"] = bench_opt.measure(N=N, R=R, dev=device)
+            # the step of BASELINE.json's configs[2] (attention + feature optimisation + warp): what a denoising step costs
+            # on the 15 of 20 steps the pipeline optimises features on (run_fresco.py:232)
+            tot_ms = res["ms_per_step"] + res["cfg3"]["ms_per_step"]
+            res["cfg3_step"] = dict(metric="denoising-steps/sec with feature optimisation on (configs[2])",
+                                    value=round(1e3 / tot_ms, 3), ms_per_step=round(tot_ms, 3),
+                                    attention_ms=res["ms_per_step"], feature_opt_ms=res["cfg3"]["ms_per_step"],
+                                    vs_torch_gpu=round((1e3 / res["torch_gpu_baseline"]["value"] +
+                                                        res["cfg3"]["torch_gpu_baseline"]["ms_per_step"]) / tot_ms, 2))
         elif world == 1:
             res["cpu_baseline"] = None
     # ---- hipGraph replay (N > 1 by default; FRESCO_BENCH_GRAPH=0 / 1 overrides): one graph per attention mode, captured
@@ -563,17 +578,27 @@ def main():
     # GPU-bound, eager launches run ahead), hence off.  N > 1: host time (0.84 ms per step) exceeds a rank's share of the
     # kernels.  Capture with collectives inside could not be exercised on the single-GPU build boxes, so it is fenced: the
     # eager result is complete before it starts; a failure on ANY rank (agreed through an all-reduce) keeps the eager
-    # result; a HANG is cut by a watchdog that prints the eager line and exits.  `value` is the faster of the two modes,
-    # both timed over exactly K steps; `launch_mode` and `ms_per_step_by_mode` say what happened.
+    # result; a HANG is cut by a watchdog that prints the eager line and exits.  `value` / `ms_per_step` are ALWAYS the eager
+    # figures (the same launch mode at every world size, and the one the baselines are compared with); the replay time
+    # of the same K steps is reported beside them in `ms_per_step_by_mode` and `graph_replay`.
     want_graph = os.environ.get("FRESCO_BENCH_GRAPH", "1" if (world > 1 and backend == "nccl") else "0") == "1"
     if want_graph:
         import threading
 
+        out_lock = threading.Lock()  # the watchdog's line and the normal one are mutually exclusive
+        printed = [False]
+
+        def emit():
+            with out_lock:
+                if rank == 0 and not printed[0]:
+                    print(json.dumps(res), flush=True)
+                printed[0] = True
+
         def bail():
             if rank == 0:
-                res["launch_mode"] = "eager (graph capture / replay did not finish within the watchdog time)"
-                print(json.dumps(res), flush=True)
-            os._exit(0)
+                res["graph_replay"] = dict(status="capture / replay did not finish within the watchdog time")
+            emit()
+            os._exit(0)  # (a hung collective cannot be torn down from here; the eager result above is complete)
 
         dog = threading.Timer(float(os.environ.get("FRESCO_BENCH_GRAPH_TIMEOUT", "120")), bail)
         dog.daemon = True
@@ -606,15 +631,14 @@ def main():
             barrier()
             dt_g = max_over_ranks(time.perf_counter() - t0)
             if rank == 0:
-                res["ms_per_step_by_mode"] = {"eager": round(1e3 * dt / args.steps, 4), "graph": round(1e3 * dt_g / args.steps, 4)}
-                if dt_g < dt:
-                    res["value"] = round(args.steps / dt_g, 3)
-                    res["ms_per_step"] = round(1e3 * dt_g / args.steps, 4)
-                    res["launch_mode"] = "hipGraph replay (one graph per attention mode)"
+                res["ms_per_step_by_mode"]["graph"] = round(1e3 * dt_g / args.steps, 4)
+                res["graph_replay"] = dict(status="ok", value=round(args.steps / dt_g, 3), ms_per_step=round(1e3 * dt_g / args.steps, 4),
+                                           note="hipGraph replay of the same K steps, one graph per attention mode; not `value`")
         elif rank == 0:
-            res["launch_mode"] = "eager (graph capture failed on some rank%s)" % (": " + err if err else "")
+            res["graph_replay"] = dict(status="capture failed on some rank%s" % (": " + err if err else ""))
         dog.cancel()
-    if rank == 0:
+        emit()
+    elif rank == 0:
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

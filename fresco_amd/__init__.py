@@ -9,7 +9,7 @@ from ._lib import FrescoHipError, LIB_PATH
 from .control import AttentionControl
 from .processor import FRESCOAttnProcessor2_0, apply_FRESCO_attn
 from .opt import optimize_feature
-from .warp import Dilate, adaptive_instance_normalization, flow_warp, warp_tensor
+from .warp import Dilate, adaptive_instance_normalization, calc_mean_std, flow_warp, warp_tensor
 from .hook import apply_FRESCO_opt, disable_FRESCO_opt, patch_reference
 from .mapping import cross_frame_masks, get_mapping_ind, get_single_mapping_ind
 from .step import predict_x0, step
@@ -18,7 +18,7 @@ from .paras import (correlation_matrices, forward_backward_consistency_check, ge
 
 __all__ = [
     "AttentionControl", "FRESCOAttnProcessor2_0", "apply_FRESCO_attn", "optimize_feature",
-    "warp_tensor", "flow_warp", "adaptive_instance_normalization", "Dilate", "apply_FRESCO_opt",
+    "warp_tensor", "flow_warp", "adaptive_instance_normalization", "calc_mean_std", "Dilate", "apply_FRESCO_opt",
     "disable_FRESCO_opt", "patch_reference", "get_mapping_ind", "get_single_mapping_ind", "cross_frame_masks",
     "step", "predict_x0", "get_flow_and_interframe_paras", "get_intraframe_paras", "interframe_paras_from_flows",
     "forward_backward_consistency_check", "correlation_matrices",

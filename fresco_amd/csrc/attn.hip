@@ -46,6 +46,20 @@
 
 namespace fresco {
 
+// CUs of the current device (cached per device): the 256-row / 512-row workgroup choice below depends on it
+static int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // pack: grid (nT, H, G), 256 threads.  Pack p of the image = K fragments of tile p || V^T fragments of tile p - 1: what
 // ONE loop step of attn_flash_kernel reads (PV(u) next to QK(u+1)); nT + 1 packs.
@@ -212,8 +226,12 @@ __global__ __launch_bounds__(512, 2) void attn_flash_kernel(const half_t* __rest
     // from kv_pack).  Two per-wave decisions hang on it:
     //  * FOLDED scale: the exponent scale c = softmax scale * log2 e is multiplied into Q once (one fp16
     //    rounding of c*q) and the MFMA delivers exponent arguments directly.  That rounding perturbs an
-    //    exponent by at most 2^-12 * c|q||k|, so it is taken only while c|q||k| <= FOLD_MAX (error of the
-    //    order of P's own fp16 rounding); otherwise Q stays exact and every score is multiplied by c in fp32.
+    //    exponent by at most 2^-12 * c|q||k|: at FOLD_MAX = 24 a WORST-CASE 0.6 % of P, ~12 x P's own fp16 rounding.
+    //    The limit is therefore empirical, not derived: tools/fold_margin.py emulates the kernel's arithmetic and
+    //    finds the folded form at 0.30 of the 1e-3 parity bar for N(0,1) keys and at the exact form's error for keys
+    //    aligned to the query (attn_cfg.h); test_attention_fold_limit_structured covers non-Gaussian q, k (a few
+    //    dominant channels, correlated q / k) at the limit.  Beyond FOLD_MAX Q stays exact and every score is
+    //    multiplied by c in fp32.
     //  * no running-max search (nomax, below) when the bound cannot leave fp16 range.
     // Accumulator units u: exponent argument = cmul * u, with (qs, cmul) = (c, 1) folded or (1, c) exact.
     float kmax;
@@ -607,7 +625,7 @@ static int launch_attn(const half_t* q, const half_t* k, const half_t* v, const 
     // = 128 workgroups for 256 CUs) takes 256-row workgroups instead -- twice as many, each half as long.
     if constexpr (D <= 48 && Cfg::MCOL) {
         const int grid2 = H * ((Lq + 511) / 512) * B;
-        if (Lq > 256 && grid2 < 256)
+        if (Lq > 256 && grid2 < device_cus())
             launch_flash<D, 1>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);
         else
             launch_flash<D, 2>(q, img, out, B, H, Lq, M, nT, n_groups, scale, diag_bias, q_ld, ktmax, st);

@@ -7,10 +7,10 @@
 //                            (channel-major for S V, pixel-major for the Gram product, each in the tiling its reader's
 //                            LDS-DMA wants); and, with the same x in registers, the int8 residual signs of the temporal term
 //                            (4-tap gathers of the neighbouring frame).  Replaces temporal_sign + chan_partial + normalize_split.
-//   gram   gram16x_kernel    sign(V V^T - T): 256 x 128 workgroup tiles (wave tiles 64 x 64: every LDS fragment feeds two
-//                            MFMAs), operands by LDS-DMA into a 3-slot ring of 48 KB slots, swizzled 64-byte rows (no pad
-//                            bytes in the stream), upper triangle + mirrored tile.  gram16s_kernel for planes <= 256 pixels
-//                            (64 x 64 tiles, wave-level split K, operands straight from L2 into registers).
+//   gram   gram16y_kernel    sign(V V^T - T): 256 x 128 workgroup tiles (wave tiles 64 x 64: every LDS fragment feeds two
+//                            MFMAs), two workgroups per CU, operands by LDS-DMA into 3-slot rings of 24 KB slots, swizzled
+//                            32-byte rows (no pad bytes in the stream), upper triangle + mirrored tile.  gram16s_kernel for
+//                            planes <= 256 pixels (64 x 64 tiles, wave-level split K, operands straight from L2 into registers).
 //   sv     sv16b / sv16      dV^T = 2c V^T S, and in the epilogue the partial sums of <V, dV> per pixel over the workgroup's
 //                            128 channels (the norm backward needs the full sum: one more pass over x and dV before).
 //   adam   opt_adam_kernel   temporal gradient from the signs + CSR rows, norm backward, Adam, and the partial sums of
@@ -31,15 +31,6 @@ bool opt_fast_ok(int C, int h, int w, int has_s) {
     }();
     const int hw = h * w;
     return !off && has_s && hw % 64 == 0 && C % 8 == 0 && 2 * ((C + 127) / 128) <= FAST_MAX_PART;
-}
-
-// experiment switch (timing ablations; results are WRONG when set): FRESCO_OPT_ABL = bit mask, see the kernels
-static int opt_abl() {
-    static const int v = [] {
-        const char* e = getenv("FRESCO_OPT_ABL");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
 }
 
 // Work split of prep / adam: a thread owns K channel octets of one pixel, a 256-thread block 64 pixels x 4 such slices.
@@ -100,7 +91,7 @@ struct PrepArgs {
     int8_t *sgn1, *sgn2;
     float* loss;
     TLayout L;
-    int C, h, w, K, NPART, NPB, has_t, pm_tiled, cm_tiled, abl;
+    int C, h, w, K, NPART, NPB, has_t, pm_tiled, cm_tiled;
 };
 
 __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
@@ -141,7 +132,7 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
             float x1[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x1[k] = c1p[(int64_t)k * hw + p];
-            if (a.has_t && !(a.abl & 1)) {
+            if (a.has_t) {
                 const float* c2p = frame_plane(a.cs, L, ck, sb, c0, C, hw);
                 uint64_t w1 = 0, w2 = 0;
 #pragma unroll
@@ -158,7 +149,7 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
                 reinterpret_cast<uint64_t*>(a.sgn1)[so] = w1;
                 reinterpret_cast<uint64_t*>(a.sgn2)[so] = w2;
             }
-            if (do_norm && !(a.abl & 2)) {
+            if (do_norm) {
                 half8_t h8, l8;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -171,21 +162,15 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
                     const int64_t ov = a.cm_tiled ? ((((int64_t)bn * (C / 128) + c / 128) * (hw / 32) + p / 32) * 128 + c % 128) * 32 +
                                                         (((((p & 31) >> 3) ^ (c >> 2)) & 3) << 3) + (p & 7)
                                                   : ((int64_t)bn * C + c) * hw + p;
-                    if (!(a.abl & 4)) {
-                        a.vh[ov] = hi16;
-                        a.vl[ov] = lo16;
-                    }
+                    a.vh[ov] = hi16;
+                    a.vl[ov] = lo16;
                 }
                 // pixel-major: the octet is one 16-byte unit of the pixel's row
-                const int64_t op = a.pm_tiled == 2 ? ((((int64_t)bn * (hw / 128) + p / 128) * (C / 16) + c0 / 16) * 128 + p % 128) * 16 +
-                                                         ((((c0 % 16) >> 3) ^ ((p >> 3) & 1)) << 3)
-                                   : a.pm_tiled   ? ((((int64_t)bn * (hw / 128) + p / 128) * (C / 32) + c0 / 32) * 128 + p % 128) * 32 +
-                                                         ((((c0 % 32) >> 3) ^ ((p >> 2) & 3)) << 3)
-                                                  : ((int64_t)bn * hw + p) * C + c0;
-                if (!(a.abl & 8)) {
-                    *reinterpret_cast<half8_t*>(a.vph + op) = h8;
-                    *reinterpret_cast<half8_t*>(a.vpl + op) = l8;
-                }
+                const int64_t op = a.pm_tiled ? ((((int64_t)bn * (hw / 128) + p / 128) * (C / 16) + c0 / 16) * 128 + p % 128) * 16 +
+                                                    ((((c0 % 16) >> 3) ^ ((p >> 3) & 1)) << 3)
+                                              : ((int64_t)bn * hw + p) * C + c0;
+                *reinterpret_cast<half8_t*>(a.vph + op) = h8;
+                *reinterpret_cast<half8_t*>(a.vpl + op) = l8;
             }
         }
     }
@@ -405,24 +390,11 @@ __global__ __launch_bounds__(NW * 64) void gram16s_kernel(const half_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// Gram step for the big planes (hw % 256 == 0, hw >= 512, C % 32 == 0).
-//   * workgroup tile 256 (A pixels) x 128 (B pixels), 8 waves as 4 x 2 with wave tiles 64 x 64: per k16 step a wave reads
-//     4 + 4 fragments for 12 MFMAs (the 128 x 128 / 64 x 32 form this replaces: 6 for 6), and a workgroup streams 48 KB per
-//     K chunk for 192 MFMAs per wave-set instead of 40 KB for 96 -- the L2 -> LDS stream per MFMA, the measured bound of the
-//     old kernel, is 0.6 of what it was;
-//   * operands pre-tiled by prep: [plane][128-pixel tile][32-channel chunk][128][32] halfs, 16-byte units XOR-swizzled with
-//     (row >> 2) & 3, so a slot is SIX linear 8 KB DMA copies (A hi / lo of two pixel tiles, B hi / lo) and fragment reads
-//     of the unpadded 64-byte rows are conflict-free;
-//   * 3-slot ring (144 KB, one workgroup per CU), chunks two ahead behind counted vmcnt waits, one barrier per chunk;
-//   * the lane's 64 target values are fetched in two halves behind the first DMA chunks (counted in the same waits);
-//   * tiles (ti, tj) with tj >= 2 ti in units of 128 pixels; the 128-row half of a tile that lies BELOW the diagonal
-//     (only when tj == 2 ti) is the mirror image of its neighbour's upper half and is not written; halves above the
-//     diagonal are also written transposed to their mirror position; XCD-contiguous walk in 1024 x 1024 super-tiles.
-// grid (tiles per plane, 1, B), 512 threads, dynamic LDS 3 * 48 KB.
+// Gram step for the big planes (hw % 256 == 0, hw >= 512, C % 32 == 0): gram16y_kernel below.  Shared pieces: the tile
+// walk -- tiles (ti, tj) of 256 x 128 pixels with tj >= 2 ti in units of 128 pixels; the 128-row half of a tile that lies
+// BELOW the diagonal (only when tj == 2 ti) is the mirror image of its neighbour's upper half and is not written; halves
+// above the diagonal are also written transposed to their mirror position; XCD-contiguous walk in 1024 x 1024 super-tiles.
 // ------------------------------------------------------------------------------------------------
-constexpr int GX_BLK = 128 * 64;       // one (pixel tile, chunk) block of one array: 8 KB
-constexpr int GX_SLOT = 6 * GX_BLK;    // Ah0 Ah1 Al0 Al1 Bh Bl
-constexpr int GX_NS = 3;
 constexpr int GX_TRS = 128 + 16;       // staged sign tile: bytes per row
 constexpr int GX_TRS2 = 256 + 16;      // ... of the transposed tile
 
@@ -470,208 +442,13 @@ __device__ __forceinline__ void gx_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
 }
 
-__global__ __launch_bounds__(512, 2) void gram16x_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
-                                                         const float* __restrict__ target, int8_t* __restrict__ sgn_out,
-                                                         float* __restrict__ loss, int C, int hw, int s_tiled, int abl) {
-    extern __shared__ __attribute__((aligned(16))) char gx_smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs; give every XCD a contiguous range of the
-    // (plane, tile) list so that the operand row blocks its tiles share stay in ONE L2
-    int lin = blockIdx.x + gridDim.x * blockIdx.z;
-    const int total = gridDim.x * gridDim.z;
-    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
-    const int b = lin / gridDim.x;
-    int ti, tj;
-    gx_tile(lin % gridDim.x, hw, ti, tj);
-    const int p0 = ti * 256, q0 = tj * 128;
-    const int nk = C / 32;
-    // this wave's rows lie in the 128-row half `wm >> 1` of the tile = pixel tile a_sub of the plane
-    const int a_sub = 2 * ti + (wm >> 1);
-    const int wgt = a_sub > tj ? 0 : (a_sub < tj ? 2 : 1);  // 0: below the diagonal (not written), 2: also mirrored
-
-    const char* baseH = reinterpret_cast<const char*>(vph) + (int64_t)b * hw * C * 2;
-    const char* baseL = reinterpret_cast<const char*>(vpl) + (int64_t)b * hw * C * 2;
-    const int64_t oA = (int64_t)(2 * ti) * nk * GX_BLK, oB = (int64_t)tj * nk * GX_BLK;
-    const int64_t wv = (int64_t)wave * 1024;
-    const char* src0 = baseH + oA + wv;                            // Ah, pixel tile 2 ti
-    const char* src1 = baseH + oA + (int64_t)nk * GX_BLK + wv;     // Ah, pixel tile 2 ti + 1
-    const char* src2 = baseL + oA + wv;
-    const char* src3 = baseL + oA + (int64_t)nk * GX_BLK + wv;
-    const char* src4 = baseH + oB + wv;
-    const char* src5 = baseL + oB + wv;
-    const uint32_t lds0 =
-        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)gx_smem);
-    const uint32_t voff = (uint32_t)lane * 16;
-    // wave w copies the w-th KiB of each of the six blocks of a slot
-    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
-        const int64_t ko = (int64_t)kc * GX_BLK;
-        const uint32_t m0b = lds0 + (uint32_t)(slot * GX_SLOT + wave * 1024);
-#define GX_PIECE(I, SRC)                                                                                         \
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"((SRC) + ko),             \
-                 "s"(m0b + (uint32_t)((I)*GX_BLK))                                                                 \
-                 : "memory")
-        GX_PIECE(0, src0);
-        GX_PIECE(1, src1);
-        GX_PIECE(2, src2);
-        GX_PIECE(3, src3);
-        GX_PIECE(4, src4);
-        GX_PIECE(5, src5);
-#undef GX_PIECE
-    };
-
-    // this lane's 64 target values in accumulator order: pre[i][jj][r] = T[p0 + wm*64 + i*32 + (r&3) + 8(r>>2) + 4hi][q0 + wn*64 + jj*32 + l31]
-    float pre[2][2][16];
-    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
-    auto prefetch = [&](int i) __attribute__((always_inline)) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                pre[i][jj][r] = (wgt && !(abl & 16)) ? tgt[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32] : 0.f;
-    };
-
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-
-    // fragment offsets inside a slot (bytes): unit (ks*2 + hi) of row R sits at ((ks*2 + hi) ^ ((R >> 2) & 3))
-    const int sw = (l31 >> 2) & 3;
-    const int rA = (wm * 64 + l31) * 64, rB = 4 * GX_BLK + (wn * 64 + l31) * 64;
-    const int u0 = ((0 + hi) ^ sw) * 16, u1 = ((2 + hi) ^ sw) * 16;
-
-    // `deep`: the counted schedule below (32 target loads ride behind chunks 1 and 3); short K loops drain everything
-    const bool deep = nk >= 6;
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    prefetch(0);
-    if (!deep) prefetch(1);
-    if (deep)
-        gx_wait_barrier<38>();  // younger than chunk 0: chunk 1 (6 pieces) + 32 target loads
-    else
-        gx_wait_barrier<0>();
-    int slot = 0;
-    for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 2 < nk && !(abl & 32)) stage(kc + 2, slot >= 1 ? slot - 1 : GX_NS - 1);  // the slot chunk kc - 1 was read from
-        if (deep && kc == 1) prefetch(1);
-        const char* Ls = gx_smem + slot * GX_SLOT;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int u = ks ? u1 : u0;
-            half8_t ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const half8_t*>(Ls + rA + i * 2048 + u);
-                al[i] = *reinterpret_cast<const half8_t*>(Ls + 2 * GX_BLK + rA + i * 2048 + u);
-                bh[i] = *reinterpret_cast<const half8_t*>(Ls + rB + i * 2048 + u);
-                bl[i] = *reinterpret_cast<const half8_t*>(Ls + GX_BLK + rB + i * 2048 + u);
-            }
-            if (abl & 64) {  // (ablation: no MFMAs; keep the fragments alive)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
-                }
-        }
-        // wait for chunk kc + 1; what may stay in flight is everything issued after it
-        if (kc + 1 < nk) {
-            if (!deep || kc + 2 >= nk)
-                gx_wait_barrier<0>();
-            else if (kc <= 2)
-                gx_wait_barrier<38>();  // kc 0: targets(32) + chunk 2;  kc 1: chunk 3 + targets(32);  kc 2: targets + chunk 4
-            else
-                gx_wait_barrier<6>();
-        }
-        slot = slot == GX_NS - 1 ? 0 : slot + 1;
-    }
-    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
-    if (abl & 128) {  // (ablation: no epilogue)
-        if (acc[0][0][0] + acc[1][1][3] + pre[0][0][0] + pre[1][1][5] == 123.456f) sgn_out[0] = 1;
-        return;
-    }
-
-    // ---- epilogue: sign(G - T) bytes as 16-byte rows through LDS: the tile, then (halves above the diagonal) its transpose
-    int8_t* tr = reinterpret_cast<int8_t*>(gx_smem);
-    float lsum = 0.f;
-    uint32_t sg[2][2][4];  // this lane's 64 signs, 4 per dword (kept for the transposed tile)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int cl = wn * 64 + jj * 32 + l31;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                uint32_t wv4 = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = r4 * 4 + e;
-                    const int rl = wm * 64 + i * 32 + e + 8 * r4 + 4 * hi;
-                    const float d = acc[i][jj][r] - pre[i][jj][r];
-                    const int8_t v8 = sign_byte(d);
-                    lsum += fabsf(d);
-                    tr[rl * GX_TRS + cl] = v8;
-                    wv4 |= (uint32_t)(uint8_t)v8 << (8 * e);
-                }
-                sg[i][jj][r4] = wv4;
-            }
-        }
-    __syncthreads();
-    for (int idx = tid; idx < 256 * 8; idx += 512) {
-        const int rl = idx >> 3, ch = idx & 7;
-        const int a = 2 * ti + (rl >> 7);
-        if (a > tj) continue;
-        const int gp = p0 + rl, gq = q0 + ch * 16;
-        s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, gp, gq, hw, s_tiled);
-    }
-    if (2 * ti < tj) {  // at least the upper half is above the diagonal: transposed copy
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int cl = wn * 64 + jj * 32 + l31;
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;  // 4 consecutive rows: one dword of the transposed row
-                    *reinterpret_cast<uint32_t*>(tr + cl * GX_TRS2 + rl) = sg[i][jj][r4];
-                }
-            }
-        __syncthreads();
-        for (int idx = tid; idx < 128 * 16; idx += 512) {
-            const int rl = idx >> 4, ch = idx & 15;  // row = B pixel, 16 consecutive A pixels
-            const int a = 2 * ti + (ch >> 3);
-            if (a >= tj) continue;
-            const int gp = q0 + rl, gq = p0 + ch * 16;
-            s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS2 + ch * 16), b, gp, gq, hw, s_tiled);
-        }
-    }
-    if (loss) {
-        float* red = reinterpret_cast<float*>(gx_smem + GX_SLOT);  // behind both staging areas
-        const float tot = wave_sum((float)wgt * lsum);
-        __syncthreads();
-        if (lane == 0) red[wave] = tot;
-        __syncthreads();
-        if (tid == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7]);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// The same Gram step with TWO workgroups per CU (gram16x measured: matrix pipe busy 44 % -- its DMA waits, target
-// stream and 6 us sign / store epilogue do not overlap with anything when one workgroup owns the CU; ablations
-// profiles/r04_gram_ablation.txt).  Same 256 x 128 tile and 64 x 64 wave tiles, but
+// gram16y_kernel: 256 x 128 workgroup tiles, 8 waves as 4 x 2 with wave tiles 64 x 64 (per k16 step a wave reads 4 + 4
+// LDS fragments for 12 MFMAs; round 3's 128 x 128 / 64 x 32 form: 6 for 6), TWO workgroups per CU.  A first form with one
+// workgroup per CU (K chunks of 32 in a 3 x 48 KB ring, targets prefetched into 64 registers; removed, see git history)
+// measured 559 us at (640, 64^2) with the matrix pipe busy 44 %: its DMA waits, target stream and 6 us sign / store
+// epilogue overlapped with nothing (ablations: profiles/r04_gram_ablation.txt, PMC: profiles/r04_pmc_opt_gram16x.csv).
+// This form: 478 us.
 //   * K chunks of 16 channels: a slot is six 4 KB blocks (24 KB), three slots = 72 KB per workgroup -> two per CU;
 //     operands pre-tiled by prep as [plane][128-pixel tile][16-channel chunk][128][2 x 16 B], the two units of pixel row r
 //     swapped when (r >> 3) & 1 (conflict-free ds_read_b128 on 32-byte rows);
@@ -689,7 +466,7 @@ constexpr int GY_NS = 3;
 template <bool LOSS>
 __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
                                                          const float* __restrict__ target, int8_t* __restrict__ sgn_out,
-                                                         float* __restrict__ loss, int C, int hw, int s_tiled, int abl) {
+                                                         float* __restrict__ loss, int C, int hw, int s_tiled) {
     extern __shared__ __attribute__((aligned(16))) char gy_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -697,7 +474,7 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
     const int l31 = lane & 31, hi = lane >> 5;
     int lin = blockIdx.x + gridDim.x * blockIdx.z;
     const int total = gridDim.x * gridDim.z;
-    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;  // XCD-contiguous ranges (see gram16x_kernel)
+    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;  // XCD-contiguous ranges: the operand row blocks the tiles of an XCD share stay in ONE L2
     const int b = lin / gridDim.x;
     int ti, tj;
     gx_tile(lin % gridDim.x, hw, ti, tj);
@@ -753,7 +530,7 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
     }
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 2 < nk && !(abl & 32)) stage(kc + 2, slot >= 1 ? slot - 1 : GY_NS - 1);  // the slot chunk kc - 1 was read from
+        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : GY_NS - 1);  // the slot chunk kc - 1 was read from
         const char* Ls = gy_smem + slot * GY_SLOT;
         half8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -763,21 +540,16 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
             bh[i] = *reinterpret_cast<const half8_t*>(Ls + rB + i * 1024);
             bl[i] = *reinterpret_cast<const half8_t*>(Ls + GY_BLK + rB + i * 1024);
         }
-        if (!(abl & 64)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
-        }
+            for (int jj = 0; jj < 2; ++jj) {
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+            }
         if (kc + 1 < nk) {
-            if (kc + 2 < nk && !(abl & 32))
+            if (kc + 2 < nk)
                 gx_wait_barrier<3>();
             else
                 gx_wait_barrier<0>();
@@ -785,10 +557,6 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
         slot = slot == GY_NS - 1 ? 0 : slot + 1;
     }
     __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
-    if (abl & 128) {
-        if (acc[0][0][0] + acc[1][1][3] == 123.456f) sgn_out[0] = 1;
-        return;
-    }
 
     // ---- epilogue ----
     int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
@@ -803,7 +571,7 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
             float tv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                tv[r] = (wgt && !(abl & 16)) ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
+                tv[r] = wgt ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 float s4[4];
@@ -1156,14 +924,14 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
 #pragma unroll
         for (int ni = 0; ni < NJ; ++ni) {
             const int col = p0 + wn * (32 * NJ) + ni * 32 + l31;
-            const int64_t vt0 = (int64_t)(col >> 5) * (128 * 32) + (l31 & 7);  // tiled V: [pixel chunk of 32][128 channels][4 swizzled units of 8 pixels]
+            const int vt0 = (col >> 5) * (128 * 32) + (l31 & 7);  // tiled V: [pixel chunk of 32][128 channels][4 swizzled units of 8 pixels]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = hf * 64 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // row inside the 128-channel tile
                 const float val = acc[mi][ni][r] * alpha;
                 dvt[((int64_t)b * C + c0 + rl) * hw + col] = val;
                 if (dotp) {
-                    const int64_t vi = vt0 + rl * 32 + ((((l31 >> 3) ^ (rl >> 2)) & 3) << 3);
+                    const int vi = vt0 + rl * 32 + ((((l31 >> 3) ^ (rl >> 2)) & 3) << 3);
                     dsum[ni] = fmaf(val, (float)vht[vi] + (float)vlt[vi], dsum[ni]);
                 }
             }
@@ -1220,10 +988,6 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     const bool cm_tiled = sv_tiled_layout(hw, C);
     const bool small = hw <= 256 && C % 32 == 0;
     const bool big = gram_x_layout(hw, C);
-    static const int gram_y = [] {
-        const char* e = getenv("FRESCO_OPT_GRAM");
-        return (e && e[0] == 'x') ? 0 : 1;
-    }();
     const float kscale = 2.f / ((float)Bg * (float)C * (float)hw);
     const int parts = sync ? sync->parts : 3;
     if (parts & 1) {
@@ -1252,9 +1016,8 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         pa.NPART = NPART;
         pa.NPB = NPB;
         pa.has_t = has_t;
-        pa.pm_tiled = big ? (gram_y ? 2 : 1) : 0;
+        pa.pm_tiled = big ? 1 : 0;
         pa.cm_tiled = cm_tiled ? 1 : 0;
-        pa.abl = opt_abl() & 15;
         const int nz = nck * (has_t ? L.n_pairs : L.n_loc);
         hipLaunchKernelGGL(opt_prep_kernel, dim3(hw / 64, NPB, nz), dim3(256), 0, st, pa);
     }
@@ -1262,7 +1025,7 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     if (sync && sync->wait_before_gram) (void)hipStreamWaitEvent(st, sync->wait_before_gram, 0);
     {
         ProfScope ps(FRESCO_PROF_OPT_GRAM, planes, C, hw, 0, st);
-        if (big && gram_y) {
+        if (big) {
             constexpr int lds = GY_NS * GY_SLOT;
             static const bool once = [] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<false>),
@@ -1274,20 +1037,10 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
             (void)once;
             if (gloss)
                 hipLaunchKernelGGL(gram16y_kernel<true>, dim3(gx_tiles_per_plane(hw), 1, planes), dim3(512), lds, st, w.vph,
-                                   w.vpl, target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0, opt_abl());
+                                   w.vpl, target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
             else
                 hipLaunchKernelGGL(gram16y_kernel<false>, dim3(gx_tiles_per_plane(hw), 1, planes), dim3(512), lds, st, w.vph,
-                                   w.vpl, target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0, opt_abl());
-        } else if (big) {
-            constexpr int lds = GX_NS * GX_SLOT;
-            static const bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16x_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                return true;
-            }();
-            (void)once;
-            hipLaunchKernelGGL(gram16x_kernel, dim3(gx_tiles_per_plane(hw), 1, planes), dim3(512), lds, st, w.vph, w.vpl,
-                               target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0, opt_abl());
+                                   w.vpl, target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
         } else if (small) {
             const int nt = hw / 64;
             if (nt * nt * planes < 128) {

@@ -176,9 +176,9 @@ __device__ __forceinline__ float sign_from_byte(uint32_t b) {
 // V as [plane][channel tile of 128][pixel chunk of 32][128][32] halfs, S as [plane][pixel tile of 256][chunk of 32][256][32] bytes,
 // both with XOR-swizzled units inside a row: see sv16b_kernel)
 __host__ __device__ __forceinline__ bool sv_tiled_layout(int hw, int C) { return hw % 256 == 0 && C % 128 == 0; }
-// (the condition under which gram16x_kernel runs: the pixel-major operand copies are then stored pre-tiled AND swizzled:
-// [plane][pixel tile of 128][channel chunk of 32][128 pixels][4 x 16-byte units], unit u of pixel row r at position
-// u ^ ((r >> 2) & 3) -- the image a linear LDS-DMA copy needs for conflict-free ds_read_b128 on 64-byte rows)
+// (the condition under which gram16y_kernel runs: the pixel-major operand copies are then stored pre-tiled AND swizzled:
+// [plane][pixel tile of 128][channel chunk of 16][128 pixels][2 x 16-byte units], the two units of pixel row r swapped
+// when (r >> 3) & 1 -- the image a linear LDS-DMA copy needs for conflict-free ds_read_b128 on 32-byte rows)
 __host__ __device__ __forceinline__ bool gram_x_layout(int hw, int C) { return hw % 256 == 0 && hw >= 512 && C % 32 == 0; }
 
 // ---- host side ---------------------------------------------------------------------------------------------------

@@ -188,6 +188,27 @@ __global__ __launch_bounds__(256) void adain_kernel(const T* __restrict__ conten
         op[i] = (T)((((float)cp[i] - mean_c) / std_c) * std_s + mean_s);
 }
 
+// calc_mean_std (src/utils.py:58-67): the two reductions of AdaIN on their own: mean[row], std[row] = sqrt(var_unbiased + eps)
+template <typename T>
+__global__ __launch_bounds__(256) void chan_mean_std_kernel(const T* __restrict__ x, float* __restrict__ mean,
+                                                             float* __restrict__ stdv, int L, float eps) {
+    __shared__ float red[4];
+    const T* xp = x + (int64_t)blockIdx.x * L;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) s += (float)xp[i];
+    const float m = block_sum_256(s, red) / (float)L;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const float a = (float)xp[i] - m;
+        v = fmaf(a, a, v);
+    }
+    const float var = block_sum_256(v, red) / (float)(L - 1);
+    if (threadIdx.x == 0) {
+        mean[blockIdx.x] = m;
+        stdv[blockIdx.x] = sqrtf(var + eps);
+    }
+}
+
 // forward_backward_consistency_check (geometry.py:75-96) + the colour-difference refinement of
 // get_flow_and_interframe_paras (diffusion_hacked.py:919-926), one thread per (pair, pixel):
 //   occ_f = |fwd + warp(bwd, fwd)| > alpha (|fwd| + |bwd|) + beta   [OR  mean_c |img_n - warp(img_n+1, fwd)| > thr]
@@ -312,6 +333,21 @@ extern "C" int fresco_adain(const void* content, const void* style, void* out, i
         hipLaunchKernelGGL((adain_kernel<float>), dim3(rows), dim3(256), 0, st,
                            static_cast<const float*>(content), static_cast<const float*>(style),
                            static_cast<float*>(out), L, eps_content, eps_style);
+    else
+        return FRESCO_EUNSUPPORTED;
+    return check_launch();
+}
+
+extern "C" int fresco_chan_mean_std(const void* x, float* mean, float* stdv, int rows, int L, float eps, int dtype,
+                                    void* stream) {
+    if (!x || !mean || !stdv || rows <= 0 || L <= 1) return FRESCO_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (dtype == FRESCO_F16)
+        hipLaunchKernelGGL((chan_mean_std_kernel<half_t>), dim3(rows), dim3(256), 0, st, static_cast<const half_t*>(x), mean,
+                           stdv, L, eps);
+    else if (dtype == FRESCO_F32)
+        hipLaunchKernelGGL((chan_mean_std_kernel<float>), dim3(rows), dim3(256), 0, st, static_cast<const float*>(x), mean,
+                           stdv, L, eps);
     else
         return FRESCO_EUNSUPPORTED;
     return check_launch();

@@ -464,6 +464,21 @@ def adain(content, style, eps_content=1e-5, eps_style=1.0):
     return out
 
 
+def chan_mean_std(feat, eps=1e-5):
+    """-> (mean, std) fp32 of shape (N*C,): per-plane mean and sqrt(unbiased variance + eps)  (src/utils.py:58-67)."""
+    _need_gpu(feat)
+    dt = feat.dtype if feat.dtype in (torch.float16, torch.float32) else torch.float32
+    x = feat.to(dt).contiguous()
+    rows = x.shape[0] * x.shape[1]
+    L = x.numel() // rows
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    std = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rc = _lib.load().fresco_chan_mean_std(x.data_ptr(), mean.data_ptr(), std.data_ptr(), rows, L, float(eps),
+                                          _lib.F16 if dt == torch.float16 else _lib.F32, _stream())
+    _lib.check(rc, "fresco_chan_mean_std")
+    return mean, std
+
+
 # ---------------------------------------------------------------------------------------------
 # feature optimisation (fp32)
 # ---------------------------------------------------------------------------------------------

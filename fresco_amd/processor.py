@@ -154,6 +154,10 @@ class FRESCOAttnProcessor2_0:
                 xp[..., D] = col
             return xp.view(B, L, heads * Dp)
 
+        # the bias rides in the contraction as bias / scale: keep that inside the kernel's +-6e4 running-max window on every
+        # head-dim instantiation (a fully masked row then gives the uniform softmax of the reference's -10000 masks, not
+        # 0 / 0); exp(-5e4 * scale) is still exactly 0 next to any unmasked key
+        bias = bias.clamp_min(-5.0e4 * scale)
         qp = pad(q, Lq, 1.0 / scale)
         kp = pad(k, Lk, bias.transpose(1, 2).to(k.dtype))
         vp = pad(v, Lk, None)
@@ -251,8 +255,11 @@ class FRESCOAttnProcessor2_0:
         # main pass: efficient cross-frame attention (225-247, 303-305) or plain attention
         if mask_bias is not None:
             if fresco and ctrl.use_cfattn:
-                # (the reference hands SDPA a mask shaped for `sequence_length` keys next to M != sequence_length
-                # cross-frame keys, :303-305: it cannot run this combination either)
+                # DELIBERATE NARROWING: with controller.attn_mask set the reference hands SDPA a mask shaped for
+                # `sequence_length` keys next to M != sequence_length cross-frame keys (:303-305) and cannot run either;
+                # with controller.attn_mask None (every frame attends to frame 0's HW keys, :227-234) its SDPA would accept
+                # the mask -- a combination the pipeline never produces (src/pipe_FRESCO.py:201-209) and this side path
+                # does not implement
                 raise ValueError("fresco_amd: attention_mask cannot be combined with cross-frame attention "
                                  "(the mask addresses %d keys, the cross-frame pass has another key set)" % mask_bias.shape[-1])
             hs = self._masked_attention(q_att, key, value, heads, sm_scale, mask_bias)

@@ -241,6 +241,11 @@ int fresco_warp_fuse_chain(float* lat, const float* bwd_flow, const float* fwd_f
 int fresco_adain(const void* content, const void* style, void* out, int rows, int L,
                  float eps_content, float eps_style, int dtype, void* stream);
 
+/* calc_mean_std (src/utils.py:58-67): per row (= one (sample, channel) plane of L values, dtype F16 / F32):
+ *   mean[row] = mean(x), stdv[row] = sqrt(unbiased variance + eps), both fp32.  L > 1. */
+int fresco_chan_mean_std(const void* x, float* mean, float* stdv, int rows, int L, float eps, int dtype,
+                         void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * (a6)  optimize_feature (DH:416-488): Adam on an fp32 copy of the features against
  *   L = 2*mean(|(c2 - W_b c1)(1-occ_b)| + |(c1 - W_f c2)(1-occ_f)|) + intra_weight*mean|V V^T - T|.

@@ -141,6 +141,35 @@ def test_attention_logit_ranges(D, qgain):
     _check(out, ref, what="qgain %g D=%d" % (qgain, D))
 
 
+@pytest.mark.parametrize("D", [40, 80])
+def test_attention_fold_limit_structured(D):
+    """The folded exponent scale is taken up to a logit bound of 24 on an EMPIRICAL margin (attn_cfg.h, tools/fold_margin.py:
+    N(0,1) and query-aligned keys).  Structured activations at that limit: a few dominant channels carry most of |q|, |k|,
+    and k is correlated with q (the keys of a query's own neighbourhood), so many logits sit near the Cauchy-Schwarz
+    bound with the same sign -- the case a Gaussian test does not reach.  Bounds c |q| max|k| of 16 ... 24."""
+    import fresco_amd.ops as ops
+    g = synth.gen(900 + D)
+    B, H, Lq, M = 2, 8, 256, 640
+    C = H * D
+    prof = torch.ones(D)
+    prof[:3] = 6.0                                  # three dominant channels per head
+    prof = prof / prof.norm() * math.sqrt(D)
+    base = torch.randn(B, 1, H, D, generator=g)     # a direction shared by queries and keys of a batch element
+    qd = (0.8 * base + 0.6 * torch.randn(B, Lq, H, D, generator=g)) * prof
+    kd = (0.8 * base + 0.6 * torch.randn(B, M, H, D, generator=g)) * prof
+    scale = 1.0 / math.sqrt(D)
+    c = scale * math.log2(math.e)
+    # scale q so that the largest per-wave bound c |q| max|k| lands just under the fold limit
+    bound = c * qd.norm(dim=-1).max() * kd.norm(dim=-1).max()
+    qd = qd * (23.5 / float(bound))
+    q, k = qd.reshape(B, Lq, C).half(), kd.reshape(B, M, C).half()
+    v = torch.randn(B, M, C, generator=g).half()
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, scale)
+    ref = _dense_ref(q.float(), k.float(), v.float(), H, scale, list(range(B)))
+    e = _check(out, ref, what="structured fold limit D=%d" % D)
+    print("fold limit, structured q / k, D=%d: max err %.2e" % (D, e if e is not None else float("nan")))
+
+
 @pytest.mark.parametrize("D,H,N,HW", [
     (8, 8, 4, 150), (40, 8, 8, 150), (80, 8, 5, 150), (40, 8, 16, 150),   # one MFMA tile: 4, 2, 3 (15 of 16 slots), 1 trajectories
     (40, 8, 3, 151), (16, 5, 7, 149), (64, 3, 12, 90), (32, 8, 1, 100),  # ragged last block, odd head counts, N = 1
@@ -404,3 +433,37 @@ def test_processor_attention_mask(C, heads, kind):
     procf = fresco_amd.FRESCOAttnProcessor2_0(1, ctrl)
     with pytest.raises(ValueError):
         procf(dev_attn, torch.randn(1, L, C).half().to(DEV), attention_mask=torch.zeros(1, L, device=DEV))
+
+
+@pytest.mark.parametrize("C,heads", [(256, 8), (512, 8), (320, 8)])
+def test_processor_attention_mask_fully_masked_rows(C, heads):
+    """Head dims 32 and 64 run the flash kernel's MCOL instantiations (running max clamped to +-6e4 raw units), 40 the
+    padded one.  A batch element whose keys are ALL masked (the reference's additive -10000: a uniform softmax, not NaN)
+    and one whose whole first 64-key tile is masked must give the reference's result on every head dim."""
+    import fresco_amd
+    g = synth.gen(C + 7)
+    B, L = 3, 160
+    D = C // heads
+    attn = synth.FakeAttn(C, heads)
+    with torch.no_grad():
+        for p in attn.parameters():
+            p.copy_(p.half().float())
+    x = torch.randn(B, L, C, generator=g).half()
+    keep = torch.rand(B, L, generator=g) < 0.7
+    keep[0, :] = False           # every key masked
+    keep[1, :64] = False         # the first key tile masked
+    keep[1, 64] = True
+    bias = (1 - keep.float()) * -10000.0
+    q = (x.float() @ attn.to_q.weight.T).half().float()
+    k = (x.float() @ attn.to_k.weight.T).half().float()
+    v = (x.float() @ attn.to_v.weight.T).half().float()
+    qh, kh, vh = (t.view(B, L, heads, D).transpose(1, 2) for t in (q, k, v))
+    sc = qh @ kh.transpose(-1, -2) / math.sqrt(D) + bias[:, None, None, :]
+    o = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B, L, C).half().float()
+    ref = (o @ attn.to_out[0].weight.T + attn.to_out[0].bias).detach()
+    proc = fresco_amd.FRESCOAttnProcessor2_0(2, None)
+    with torch.no_grad():
+        out = proc(copy.deepcopy(attn).to(DEV).half(), x.to(DEV), attention_mask=bias.to(DEV))
+    assert bool(torch.isfinite(out).all())
+    _check(out, ref, atol=1e-3, rtol=2e-3, what="fully masked rows D=%d" % D)
+

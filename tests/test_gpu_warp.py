@@ -72,6 +72,20 @@ def test_adain(golden):
     assert maxdiff(out16, ref16) < 4e-3
 
 
+def test_calc_mean_std():
+    """src/utils.py:58-67 on the reduction of the AdaIN kernel: mean and sqrt(unbiased variance + eps) per (sample, channel)"""
+    import fresco_amd
+    x = cf.feat(8, 16, 8, 8, 0.4) * 1.3 - 0.1
+    for xx, tol in ((x, 2e-6), (x.half(), 2e-3)):
+        m, s = fresco_amd.calc_mean_std(xx.to(DEV), eps=1e-5)
+        assert m.shape == s.shape == (8, 16, 1, 1) and m.dtype == xx.dtype
+        xf = xx.float().reshape(8, 16, -1)
+        assert maxdiff(m.float(), xf.mean(2).view(8, 16, 1, 1)) < tol
+        assert maxdiff(s.float(), (xf.var(2) + 1e-5).sqrt().view(8, 16, 1, 1)) < tol
+    m, s = fresco_amd.calc_mean_std(x.to(DEV), 1)  # the reference's positional slip: eps = chunk = 1 (utils.py:73)
+    assert maxdiff(s, (x.reshape(8, 16, -1).var(2) + 1.0).sqrt().view(8, 16, 1, 1)) < 2e-6
+
+
 def test_warp_tensor_kat4_kat5(d, golden):
     import fresco_amd
     fl = [d["fwd"].to(DEV), d["bwd"].to(DEV)]

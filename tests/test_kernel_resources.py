@@ -52,11 +52,15 @@ def test_flash_and_projection_kernels_fit_two_waves_per_simd(tmp_path):
 
 
 def test_gram_and_sv_kernels_fit_four_waves_per_simd(tmp_path):
-    k = _listing("opt.hip", tmp_path)
-    for pat in (r"gram16w_kernel", r"sv16b_kernelILi256ELi2E"):  # launch_bounds(512, 4): 16 waves per CU
+    k = _listing("opt_fast.hip", tmp_path)
+    # launch_bounds(512, 4): two 8-wave workgroups per CU (the Gram kernel of the run path, both S V tile shapes)
+    for pat in (r"gram16y_kernelILb0E", r"gram16y_kernelILb1E", r"sv16b_kernelILi128E", r"sv16b_kernelILi64E"):
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 128 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
-    r = _one(k, r"adam_update_kernel")
+    for pat in (r"opt_prep_kernel", r"opt_adam_kernel"):  # HBM-bound: at least three waves per SIMD, nothing in scratch
+        r = _one(k, pat)
+        assert r["vgpr"] + r["agpr"] <= 168 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+    r = _one(_listing("opt.hip", tmp_path), r"adam_update_kernel")
     assert r["spill"] == 0 and r["scratch"] == 0, r
 
 

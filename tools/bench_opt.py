@@ -33,7 +33,7 @@ def _dominant_roofline(kern):
     k = kern.get("C640_h64", {}).get("gram_roofline")
     if not k:
         return None
-    return dict(bound="mfma", kernel="gram16x_kernel at (C 640, 64 x 64)", achieved=k["algorithmic_tflops"],
+    return dict(bound="mfma", kernel="gram16y_kernel at (C 640, 64 x 64)", achieved=k["algorithmic_tflops"],
                 peak=PEAK_F16_DENSE / 1e12, unit="TFLOP/s", frac=k["frac_algorithmic"], frac_executed=k["frac_executed"],
                 note="the Gram and S V products are fp32-accurate products built from 3 / 2 fp16 MFMAs on hi / lo halves "
                      "(exact to ~2^-22); per-kernel fractions of every launch, MFMA- and HBM-bound alike, are in "
