@@ -561,6 +561,10 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_opt
 
+            import bench_gmflow
+
+            # auxiliary, NOT part of `value`: SURVEY 8 row f3 (flows + occlusions + masks + mappings, once per batch of frames)
+            res["f3_gmflow"] = bench_gmflow.measure(N=N, R=R, dev=device)
             res["cfg3"] = bench_opt.measure(N=N, R=R, dev=device)
             # the step of BASELINE.json's configs[2] (attention + feature optimisation + warp): what a denoising step costs
             # on the 15 of 20 steps the pipeline optimises features on (run_fresco.py:232)

@@ -16,6 +16,7 @@
 //
 // q (B, Lq, D), k (B, Lk, D), v (B, Lk, DV), out (B, Lq, DV), all fp32 row-major.  grid (ceil(Lq/128), B).
 #include "common.h"
+#include <stdlib.h>
 
 namespace fresco {
 
@@ -130,12 +131,214 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the same attention on the fp16 matrix pipe at fp32 accuracy.  Every fp32 operand x is split x = xh + xl into two
+// halfs (xh = fp16(x), xl = fp16(x - xh): x to a relative 2^-22) and every product a b is taken as ah bh + ah bl + al bh
+// (the dropped al bl term is < 2^-22 relative) -- three v_mfma_f32_32x32x16_f16 per 16 contraction steps instead of eight
+// v_mfma_f32_32x32x2_f32: 3/16 of the matrix-pipe time, products exact in the fp32 accumulator (the scheme of the Gram /
+// S V kernels of opt_fast.hip).  Both contractions: S^T = K Q^T with K, Q split, O^T += V^T P^T with V and the fp32
+// probabilities P split; row max / sum / exp2 stay fp32.  The matrix pipe FLUSHES fp16 subnormals, so the lo parts must stay
+// normal numbers (> 6.1e-5): every operand is scaled by a power of two before the split -- Q (with the exponent scale
+// folded in) and K by 2^6, V by 2^6, P (in [0, 1]) by 2^12 -- and the products are scaled back exactly in fp32 (one
+// multiply per score, one on the final normalisation).  Without that, a P below 0.25 loses its lo part: 2e-4 relative on
+// the output (measured).  Operands must stay below fp16 range after scaling: |q c|, |k|, |v| < 1000 (GMFlow's
+// LayerNorm-bounded tokens and pixel coordinates are).
+//   * K tile (32 keys): split while staged, LDS rows [key][D halfs + 16 B pad] for hi and lo;
+//   * V tile: split and TRANSPOSED while staged, V^T rows [d][32 key slots + 16 B pad], the slots in the order the S^T
+//     accumulator registers hold the keys (slot(key) = (key>>4)*16 + ((key>>2)&1)*8 + ((key>>3)&1)*4 + (key&3)), so the
+//     packed P registers ARE the B operand of the second product;
+//   * a wave owns 32 queries: Q fragments (hi, lo) resident in registers.
+// q (B, Lq, D), k (B, Lk, D), v (B, Lk, dv_real), out (B, Lq, dv_real) fp32.  grid (ceil(Lq/128), B), 256 threads.
+// ------------------------------------------------------------------------------------------------
+template <int D, int DV, int NPQ>  // NPQ = fp16 pieces of the Q / K operands: 2 (22 bits, 3 MFMAs) or 3 (33 bits, 6 MFMAs)
+__global__ __launch_bounds__(256, 2) void attn_f32s_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, float* __restrict__ out,
+                                                            int Lq, int Lk, int dv_real, float scale_log2) {
+    constexpr int KROW = D * 2 + 16;   // bytes per K row (an odd number of 16-byte units)
+    constexpr int VROW = 64 + 16;      // bytes per V^T row (32 key slots)
+    constexpr int NDB = DV / 32, NKS = D / 16;
+    __shared__ __attribute__((aligned(16))) char kh_s[32 * KROW];
+    __shared__ __attribute__((aligned(16))) char kl_s[32 * KROW];
+    __shared__ __attribute__((aligned(16))) char km_s[NPQ == 3 ? 32 * KROW : 16];  // (third piece: bits 23 .. 33)
+    __shared__ __attribute__((aligned(16))) char vh_s[DV * VROW];
+    __shared__ __attribute__((aligned(16))) char vl_s[DV * VROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.y;
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const float* qp = q + ((int64_t)b * Lq + (qrow < Lq ? qrow : Lq - 1)) * D + hi * 8;
+    const float* kb = k + (int64_t)b * Lk * D;
+    const float* vb = v + (int64_t)b * Lk * dv_real;
+
+    auto split8 = [](const float (&x)[8], half8_t& h, half8_t& l) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const half_t hh = (half_t)x[e];
+            h[e] = hh;
+            l[e] = (half_t)(x[e] - (float)hh);
+        }
+    };
+    // Q fragments of k-step ks: d = ks*16 + hi*8 .. +7, exponent scale applied in fp32 before the split
+    half8_t qh[NKS], ql[NKS], qm[NPQ == 3 ? NKS : 1];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const floatx4 a = *reinterpret_cast<const floatx4*>(qp + ks * 16);
+        const floatx4 c = *reinterpret_cast<const floatx4*>(qp + ks * 16 + 4);
+        const float sq = scale_log2 * 64.f;  // 2^6
+        const float x[8] = {a[0] * sq, a[1] * sq, a[2] * sq, a[3] * sq, c[0] * sq, c[1] * sq, c[2] * sq, c[3] * sq};
+        split8(x, qh[ks], ql[ks]);
+        if (NPQ == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qm[ks][e] = (half_t)(((x[e] - (float)qh[ks][e]) - (float)ql[ks][e]) * 4096.f);
+        }
+    }
+    floatx16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int nT = (Lk + 31) / 32;
+    for (int t = 0; t < nT; ++t) {
+        __syncthreads();  // the previous tile's fragments have been read
+        for (int c = tid; c < 32 * (D / 4); c += 256) {  // K: coalesced 16-byte loads, split, 8-byte LDS writes
+            const int r = c / (D / 4), d4 = c % (D / 4);
+            const int key = t * 32 + r;
+            floatx4 val = {0.f, 0.f, 0.f, 0.f};
+            if (key < Lk) val = *reinterpret_cast<const floatx4*>(kb + (int64_t)key * D + d4 * 4) * 64.f;  // 2^6
+            half4_t h4, l4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const half_t hh = (half_t)val[e];
+                h4[e] = hh;
+                l4[e] = (half_t)(val[e] - (float)hh);
+            }
+            *reinterpret_cast<half4_t*>(kh_s + r * KROW + d4 * 8) = h4;
+            *reinterpret_cast<half4_t*>(kl_s + r * KROW + d4 * 8) = l4;
+            if (NPQ == 3) {
+                half4_t m4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m4[e] = (half_t)(((val[e] - (float)h4[e]) - (float)l4[e]) * 4096.f);
+                *reinterpret_cast<half4_t*>(km_s + r * KROW + d4 * 8) = m4;
+            }
+        }
+        for (int c = tid; c < 32 * DV; c += 256) {  // V: split + transposed into the accumulator's key order
+            const int r = c / DV, d = c % DV;
+            const int key = t * 32 + r;
+            const float val = (key < Lk && d < dv_real) ? vb[(int64_t)key * dv_real + d] * 64.f : 0.f;  // 2^6
+            const int pos = (r >> 4) * 16 + ((r >> 2) & 1) * 8 + ((r >> 3) & 1) * 4 + (r & 3);
+            const half_t hh = (half_t)val;
+            *reinterpret_cast<half_t*>(vh_s + d * VROW + pos * 2) = hh;
+            *reinterpret_cast<half_t*>(vl_s + d * VROW + pos * 2) = (half_t)(val - (float)hh);
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T (exponent arguments) ----------------------------------------------------------------------
+        floatx16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        if (NPQ == 3) {
+            // third pieces xm = x - xh - xl (<= 2^-22 |x|) are stored scaled by 2^12 (they would be fp16 subnormals, which
+            // the matrix pipe flushes): their two products go first and are scaled back before the large terms are added
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const half8_t ah = *reinterpret_cast<const half8_t*>(kh_s + l31 * KROW + ks * 32 + hi * 16);
+                const half8_t am = *reinterpret_cast<const half8_t*>(km_s + l31 * KROW + ks * 32 + hi * 16);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, qh[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qm[ks], s, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] *= 0x1p-12f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const half8_t ah = *reinterpret_cast<const half8_t*>(kh_s + l31 * KROW + ks * 32 + hi * 16);
+            const half8_t al = *reinterpret_cast<const half8_t*>(kl_s + l31 * KROW + ks * 32 + hi * 16);
+            if (NPQ == 3) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ql[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], s, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= 0x1p-12f;  // undo the 2^6 of Q and of K (exact)
+        if ((t + 1) * 32 > Lk) {  // keys beyond Lk (last tile only)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (key >= Lk) s[r] = -1e30f;
+            }
+        }
+        // ---- online softmax, one query per lane (fp32) -------------------------------------------------------------
+        float mt = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = exp2f(s[r] - m_new);
+            psum += s[r];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        // ---- O^T += V^T P^T: k-step st contracts the 16 keys whose probabilities registers 8 st .. 8 st + 7 hold --------
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = s[st * 8 + e] * 4096.f;  // 2^12
+            half8_t ph, pl;
+            split8(x, ph, pl);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const half8_t vh8 = *reinterpret_cast<const half8_t*>(vh_s + (db * 32 + l31) * VROW + st * 32 + hi * 16);
+                const half8_t vl8 = *reinterpret_cast<const half8_t*>(vl_s + (db * 32 + l31) * VROW + st * 32 + hi * 16);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph, o[db], 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 0x1p-18f / l_tot;  // (the accumulators carry the 2^12 of P and the 2^6 of V)
+    if (qrow < Lq) {
+        float* op = out + ((int64_t)b * Lq + qrow) * dv_real;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (d < dv_real) op[d] = o[db][r] * inv;
+            }
+    }
+}
+
 template <int D, int DV>
 static int launch_attn32(const float* q, const float* k, const float* v, float* out, int B, int Lq, int Lk, int dv,
                          float scale, hipStream_t st) {
     ProfScope ps(FRESCO_PROF_ATTN_F32, B, Lq, Lk, D, st);
-    hipLaunchKernelGGL((attn_f32_kernel<D, DV>), dim3((Lq + 127) / 128, B), dim3(256), 0, st, q, k, v, out, Lq, Lk,
-                       dv, scale * 1.4426950408889634f);
+    // FRESCO_ATTN_F32=mfma32: the fp32-MFMA kernel (exact fp32 products; A/B measurements, and operands beyond fp16 range)
+    static const int use_f32_mfma = [] {
+        const char* e = getenv("FRESCO_ATTN_F32");
+        return (e && e[0] == 'm') ? 1 : ((e && e[0] == '2') ? 2 : 0);
+    }();
+    if (use_f32_mfma == 2)  // (22-bit logits: 3 MFMAs per product in both contractions; measurements)
+        hipLaunchKernelGGL((attn_f32s_kernel<D, DV, 2>), dim3((Lq + 127) / 128, B), dim3(256), 0, st, q, k, v, out, Lq, Lk,
+                           dv, scale * 1.4426950408889634f);
+    else if (use_f32_mfma)
+        hipLaunchKernelGGL((attn_f32_kernel<D, DV>), dim3((Lq + 127) / 128, B), dim3(256), 0, st, q, k, v, out, Lq, Lk,
+                           dv, scale * 1.4426950408889634f);
+    else
+        hipLaunchKernelGGL((attn_f32s_kernel<D, DV, 3>), dim3((Lq + 127) / 128, B), dim3(256), 0, st, q, k, v, out, Lq, Lk,
+                           dv, scale * 1.4426950408889634f);
     return check_launch();
 }
 

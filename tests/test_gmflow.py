@@ -103,8 +103,10 @@ def test_gmflow_gpu_matches_reference(gm_golden, tag, monkeypatch):
     monkeypatch.setattr(ops, "attention_f32", _att64)
     flow64 = m(imgs, imgs[nxt], **KW)["flow_preds"][-1]
     e_kernel = _epe(flow, flow64)
+    print("gmflow %s: EPE vs fp64 attention max %.2e px" % (tag, float(e_kernel.max())))
     assert float(e_kernel.max()) < 5e-3, float(e_kernel.max())
     e = _epe(flow.cpu(), torch.from_numpy(gm_golden["flow_" + tag]))
+    print("gmflow %s: EPE vs the reference's CPU flows max %.3f mean %.4f px" % (tag, float(e.max()), float(e.mean())))
     assert float(e.max()) < 0.15 and float(e.mean()) < 0.05, (float(e.max()), float(e.mean()))
 
 
@@ -119,3 +121,31 @@ def test_gmflow_feeds_interframe_paras():
     assert tuple(flows[0].shape) == (N, 2, H, W) and tuple(occs[1].shape) == (N, H, W)
     assert len(attn_mask) == 3 and len(paras["fwd_mappings"]) == 2
     assert torch.isfinite(flows[0]).all() and set(torch.unique(occs[0]).tolist()) <= {0.0, 1.0}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("lib_convs", [True, False])
+def test_gmflow_distance_to_the_cpu_flows_is_the_librarys_not_the_kernels(gm_golden, tag, lib_convs, monkeypatch):
+    """What separates the GPU flows from the reference's CPU flows (0.03 - 0.07 px max on this untrained, chaotic
+    network) is the fp32 summation order of the GPU library ops around the attention -- MIOpen's convolutions, or with
+    torch.backends.cudnn.enabled = False PyTorch's im2col + rocBLAS path: measured 0.069 / 0.028 px (MIOpen) and
+    0.025 / 0.058 px (off) for the two cases, i.e. pinning MIOpen does NOT give a tighter absolute bar.  The rigorous
+    statement is relative: on the SAME GPU, with the SAME library ops, exchanging fresco_attn_f32 for an fp64 softmax
+    moves the distance to the CPU flows by less than 5e-3 px."""
+    import fresco_amd.ops as ops
+    m, _ = _model("cuda")
+    N, H, W = CASES[tag]
+    imgs = cf.gmflow_frames(N, H, W).cuda()
+    nxt = list(range(1, N)) + [0]
+    ref = torch.from_numpy(gm_golden["flow_" + tag])
+    with torch.backends.cudnn.flags(enabled=lib_convs):
+        flow = m(imgs, imgs[nxt], **KW)["flow_preds"][-1].cpu()
+        monkeypatch.setattr(ops, "attention_f32", _att64)
+        flow64 = m(imgs, imgs[nxt], **KW)["flow_preds"][-1].cpu()
+    e_ours, e_floor = _epe(flow, ref), _epe(flow64, ref)
+    print("gmflow %s, library convolutions %s: EPE vs the reference's CPU flows: with fresco_attn_f32 max %.4f mean %.5f | "
+          "with fp64 attention max %.4f mean %.5f px" % (tag, "on" if lib_convs else "off", float(e_ours.max()),
+                                                       float(e_ours.mean()), float(e_floor.max()), float(e_floor.mean())))
+    assert float(e_ours.max()) < float(e_floor.max()) + 5e-3
+    assert float(e_ours.mean()) < float(e_floor.mean()) + 1e-3

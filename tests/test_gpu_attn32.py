@@ -1,4 +1,5 @@
-"""GPU parity of the fp32 attention kernel (fresco_attn_f32) against an fp64 softmax(q k^T) v."""
+"""GPU parity of the fp32 attention kernel (fresco_attn_f32: fp32 operands split into fp16 pieces on the fp16 matrix pipe,
+33-bit logits, 22-bit P V products) against an fp64 softmax(q k^T) v."""
 import math
 
 import pytest
