@@ -20,6 +20,12 @@
 // barrier-coupled workgroup per CU nothing overlaps.  Splitting the features over more workgroups (staggered
 // lifetimes) re-reads x and is slower (2 / 3 / 5 splits: 68 / 78 / 94 us).  Output tiles are transposed through LDS
 // so that a store instruction writes whole 128-byte lines (16-byte pieces of 32 rows each: +4 us).
+// Round 4: a TILED form was written and measured against this one (both operands by swizzled LDS-DMA from where they
+// live, 256 x 128 workgroup tiles of the concatenated output list, wave tiles 64 x 64, two workgroups per CU, 3-slot
+// ring -- the structure of opt_fast.hip's Gram kernel; parity-green; commit history): 61.0 vs 52.7 us for q,k,v at
+// (65536, 320), 56.5 vs 52.9 at (16384, 640), ties (+-1 us) on the gathered K|V launches and on to_out.  With K = 320
+// a tile's K loop is 10 chunks: DMA prologue and store epilogue per tile outweigh what the deeper ring and the second
+// workgroup per CU buy, and x is re-streamed 7.5 times.  Removed again; the resident-x form stays.
 #include "common.h"
 
 namespace fresco {

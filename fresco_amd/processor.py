@@ -64,9 +64,10 @@ class FRESCOAttnProcessor2_0:
 
     def _project_out(self, attn, hs):
         lin = attn.to_out[0]
-        # a single C = 640 projection is faster in the library GEMM (csrc/proj.hip header): fuse only C = 320
+        # (round 3 left the C = 640 case to the library GEMM; on repeated measurement the two tie within the box-to-box
+        # spread -- 27-30 us here, 24-33 us hipBLASLt at (16384, 640, 640) -- so the hot path now has no library GEMM)
         if (self.fuse_projections and hs.dtype == torch.float16 and hs.is_cuda and _plain_linear(lin, True)
-                and lin.in_features == 320):
+                and ops.linear_supported(lin.in_features, lin.out_features, hs.dtype)):
             return ops.linear(hs, [lin.weight.detach()], [lin.bias.detach()])[0]
         return lin(hs)
 
