@@ -354,6 +354,41 @@ def read_prof(lib, cap):
     return [(tags[i], tuple(dims[4 * i: 4 * i + 4]), ms[i]) for i in range(n)]
 
 
+def timed_workload(N, R, device, shard_args, steps, warmup, barrier, max_over_ranks):
+    """K timed steps of another batch shape on the same ranks (the N > 1 bench line's `cfg5` leg): the workload the
+    frame-parallel claim of BASELINE.json rests on, next to the strong-scaling `value` of the headline batch."""
+    layers, params = build_workload(N, R, device)
+    shard = None
+    if shard_args is not None:
+        from fresco_amd.dist import FrameShard
+
+        shard = FrameShard(N, 2, *shard_args)
+    proc, ctrl, refs, paras, masks = make_processor(layers, params, device, shard)
+    for l in layers:
+        if shard is not None:
+            sel = shard.local_batch_index().to(device)
+            l["hidden_local"] = l["hidden"].index_select(0, sel).contiguous()
+            l["ref_local"] = l["ref"].index_select(0, sel).contiguous()
+        else:
+            l["hidden_local"], l["ref_local"] = l["hidden"], l["ref"]
+    refs = [l["ref_local"] for l in layers]
+    with torch.no_grad():
+        for mode in sorted(set(SCHEDULE)):
+            run_step(proc, ctrl, layers, mode, refs, paras, masks)
+        for s in range(warmup):
+            run_step(proc, ctrl, layers, SCHEDULE[s % len(SCHEDULE)], refs, paras, masks)
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            run_step(proc, ctrl, layers, SCHEDULE[s % len(SCHEDULE)], refs, paras, masks)
+        barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    return dict(workload="cfg5's batch (BASELINE.json configs[4]): %d frames %dx%d, frame-sharded" % (N, R, R), steps=steps,
+                value=round(steps / dt, 3), unit="denoising-steps/sec", ms_per_step=round(1e3 * dt / steps, 4),
+                note="weak-scaling companion of `value`: per-frame work 16x config 2's; compare with a one-GPU run of "
+                     "`bench.py --frames %d --res %d`" % (N, R))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -511,7 +546,7 @@ def main():
                                 (32, 768): "cfg5's batch (configs[4]: 32 frames at 768^2)"}.get((N, R), "custom batch"),
                                N, R, R, (R // 16) ** 2, HW3),
                 "cross_frame_keys_M": {"L3": M3, "L2": int(params[16][3].sum())},
-                "parallelism": ("frame-shard x%d: broadcast of frame 0's K|V + all-gather of the masked rows, trajectory "
+                XX
                                 "all-to-all for the temporal pass (RCCL)" % world) if world > 1 else "single GPU",
             },
             "roofline": roofline,
@@ -526,9 +561,9 @@ def main():
                 cnt = [int(m[max(r * n_loc, 1):(r + 1) * n_loc].sum()) for r in range(world)]
                 M_rest[name] = max(cnt)
             res["collective_bytes_received_per_rank"] = collective_bytes_per_step(N, R, world, M_rest)
-            # per layer call: 1 broadcast + 1 all-gather (cross-frame exchange; no all-gather when no rank has selected
-            # rows), + 2 all-to-alls while the temporal pass is on (8 of 15 steps); 6 layer calls per step
-            cf_coll = sum(3 * (1 + (1 if M_rest[n_] > 0 else 0)) for n_ in ("L2", "L3"))
+            # per layer call: ONE grouped point-to-point launch for the cross-frame exchange (round 3: 1 broadcast + 1
+            # all-gather), + 2 all-to-alls while the temporal pass is on (8 of 15 steps); 6 layer calls per step
+            cf_coll = sum(3 * (1 if shard.p2p_exchange else 1 + (1 if M_rest[n_] > 0 else 0)) for n_ in ("L2", "L3"))
             res["collectives_per_step"] = dict(cross_frame=cf_coll, temporal_all_to_all=12,
                                                schedule_mean=round(cf_coll + 12 * 8.0 / 15.0, 1))
         if world == 1 and not args.no_aux:
@@ -576,6 +611,11 @@ def main():
                                                         res["cfg3"]["torch_gpu_baseline"]["ms_per_step"]) / tot_ms, 2))
         elif world == 1:
             res["cpu_baseline"] = None
+    # ---- cfg5 leg (N > 1 only, every rank takes part): 32 frames x 768^2 sharded over the same ranks
+    if world > 1 and (N, R) == (8, 512) and 32 % world == 0 and not args.no_aux:
+        c5 = timed_workload(32, 768, device, (rank, world), max(args.steps // 2, 2), 1, barrier, max_over_ranks)
+        if rank == 0:
+            res["cfg5"] = c5
     # ---- hipGraph replay (N > 1 by default; FRESCO_BENCH_GRAPH=0 / 1 overrides): one graph per attention mode, captured
     # after the eager measurement above and replayed over the same K steps -- the same kernels (and, sharded, the same RCCL
     # collectives) without the Python / launch gaps between them.  One GPU: replay is 3 % SLOWER than eager (the step is

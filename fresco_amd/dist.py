@@ -9,14 +9,15 @@ not read):
 
   1. cross-frame keys (`exchange_cf`): the efficient cross-frame pass reads frame 0 (all tokens) and the
      occluded tokens of the other frames (controller.attn_mask, src/diffusion_hacked.py:935-938).  Frame 0's fused
-     K|V rows are BROADCAST from their owner; the other frames' selected rows are compacted per rank, padded
-     to the largest rank's count (the mask is replicated, so every rank knows the counts) and ALL-GATHERED.
+     K|V rows go from their owner to every rank; the other frames' selected rows are compacted per rank, padded
+     to the largest rank's count (the mask is replicated, so every rank knows the counts) and sent to every rank --
+     since round 4 as ONE grouped launch of point-to-point transfers (before: one broadcast + one all-gather).
      Both land in one (HW + world*Rmax, chunk, 2C) buffer -- the CFG halves side by side in a row, so that frame 0's
-     rows of BOTH halves are one contiguous block (ONE broadcast) and the ranks' selected rows another (ONE
-     all-gather): two collectives per layer call.  The kernel addresses the buffer through the remapped row table of
+     rows of BOTH halves are one contiguous block and every rank's selected rows another: one transfer each per
+     peer, all of them in one launch.  The kernel addresses the buffer through the remapped row table of
      `cf_plan` (row t of half c = flat row t*chunk + c) -- no re-layout pass after the collectives.  At 8 x 512^2 on
      8 GPUs a rank receives 10.5 MB + 0.1 MB per up_blocks.3 call instead of the 73 MB of an all-gather of every
-     frame's K|V.  The collectives are launched right after the K / V projection and overlap the spatial pass.
+     frame's K|V.  The exchange is launched right after the K / V projection and overlaps the spatial pass.
   2. temporal-guided pass (`temporal`): sharded by TRAJECTORY, not by frame.  fresco_temporal_pack gathers the
      local frames' q | k | v rows along the trajectories into per-destination ranges, an ALL-TO-ALL delivers
      to rank r all N frames of its HW/world trajectories, the packed kernel runs on them, and the way back
@@ -92,6 +93,9 @@ class FrameShard:
         self.f0 = rank * self.n_loc
         self.B_loc = chunk * self.n_loc
         self._rows_cache = {}
+        # cross-frame exchange as ONE grouped launch of point-to-point transfers (exchange_cf); False: one broadcast +
+        # one all-gather (round-3 form)
+        self.p2p_exchange = True
 
     def local_batch_index(self):
         return local_batch_index(self.N, self.chunk, self.rank, self.world)
@@ -186,27 +190,46 @@ class FrameShard:
         return dist.get_global_rank(self.group, group_rank)
 
     def exchange_cf(self, kv_loc, plan):
-        """kv_loc: this rank's fused K|V rows (chunk*n_loc, HW, 2C).  Starts ONE broadcast (frame 0's rows of both CFG
-        halves) and ONE all-gather (every rank's selected rows of its other frames) into a (HW + world*Rmax, chunk, 2C)
-        buffer; returns (buffer, [works]) -- wait on the works before the kernel reads the buffer through
-        plan["kv_table"] / plan["kv_group_rows"]."""
+        """kv_loc: this rank's fused K|V rows (chunk*n_loc, HW, 2C).  Fills a (HW + world*Rmax, chunk, 2C) buffer with
+        frame 0's rows of both CFG halves (from their owner, rank 0) and every rank's selected rows of its other frames;
+        returns (buffer, [works]) -- wait on the works before the kernel reads the buffer through plan["kv_table"] /
+        plan["kv_group_rows"].
+        Round 4: ONE grouped launch of point-to-point transfers (dist.batch_isend_irecv: the owner of frame 0 sends its
+        block to every peer, every rank sends its selected rows to every peer) instead of one broadcast + one
+        all-gather: xGMI is point-to-point -- the owner drives its 7 links in parallel either way -- and a layer call
+        pays ONE collective launch (12 -> 6 per step at 8 x 512^2).  `p2p_exchange = False`, or a host-staged test
+        backend, keeps the two-collective form."""
         Bl, HW, C2 = kv_loc.shape
         Rmax = plan["Rmax"]
         buf = torch.empty(HW + self.world * Rmax, self.chunk, C2, dtype=kv_loc.dtype, device=kv_loc.device)
         x = kv_loc.view(self.chunk, self.n_loc, HW, C2)
-        works = []
         if self.rank == 0:  # frame 0 lives on the group's rank 0
             buf[:HW].copy_(x[:, 0].transpose(0, 1))
-        works.append(self.broadcast(buf[:HW], src=self._global_rank(0), async_op=True))
+        mine = None
         if Rmax > 0:
-            mine = x.reshape(self.chunk, self.n_loc * HW, C2).index_select(1, plan["local_sel"])  # (chunk, Rmax, 2C)
-            works.append(self.all_gather_into(buf[HW:], mine.transpose(0, 1).contiguous(), async_op=True))
+            mine = x.reshape(self.chunk, self.n_loc * HW, C2).index_select(1, plan["local_sel"]).transpose(0, 1).contiguous()
+        if self.p2p_exchange and self.world > 1 and not self._host_staged(kv_loc):
+            ops = []
+            peers = [p for p in range(self.world) if p != self.rank]
+            if self.rank == 0:
+                ops += [dist.P2POp(dist.isend, buf[:HW], self._global_rank(p), self.group) for p in peers]
+            else:
+                ops.append(dist.P2POp(dist.irecv, buf[:HW], self._global_rank(0), self.group))
+            if Rmax > 0:
+                buf[HW + self.rank * Rmax: HW + (self.rank + 1) * Rmax].copy_(mine)
+                for p in peers:
+                    ops.append(dist.P2POp(dist.isend, mine, self._global_rank(p), self.group))
+                    ops.append(dist.P2POp(dist.irecv, buf[HW + p * Rmax: HW + (p + 1) * Rmax], self._global_rank(p), self.group))
+            works = dist.batch_isend_irecv(ops) if ops else []
+            return buf, [w for w in works if w is not None]
+        works = [self.broadcast(buf[:HW], src=self._global_rank(0), async_op=True)]
+        if Rmax > 0:
+            works.append(self.all_gather_into(buf[HW:], mine, async_op=True))
         return buf, [w for w in works if w is not None]
 
     # collectives one layer call issues (bench.py reports the count per step)
-    @staticmethod
-    def cf_collectives(plan):
-        return 1 + (1 if plan["Rmax"] > 0 else 0)
+    def cf_collectives(self, plan):
+        return 1 if self.p2p_exchange else 1 + (1 if plan["Rmax"] > 0 else 0)
 
     def temporal(self, q, k, v, fwd_map, mask, heads, scale):
         """trajectory-sharded temporal-guided pass: q, k, v local (chunk*n_loc, HW, C); returns the local rows"""

@@ -21,6 +21,7 @@ class ThreadShard:
     def __init__(self, base, slots, barrier):
         self.__dict__.update(base.__dict__)
         self._base, self._slots, self._barrier = base, slots, barrier
+        self.p2p_exchange = False  # (threads have no process group: the broadcast + all-gather form, emulated below)
 
     def _exchange(self, x):
         self._slots[self.rank] = x
