@@ -546,8 +546,9 @@ def main():
                                 (32, 768): "cfg5's batch (configs[4]: 32 frames at 768^2)"}.get((N, R), "custom batch"),
                                N, R, R, (R // 16) ** 2, HW3),
                 "cross_frame_keys_M": {"L3": M3, "L2": int(params[16][3].sum())},
-                XX
-                                "all-to-all for the temporal pass (RCCL)" % world) if world > 1 else "single GPU",
+                "parallelism": ("frame-shard x%d: frame 0's K|V + the masked rows of the other frames to every rank in one grouped "
+                                "point-to-point launch, trajectory all-to-all for the temporal pass (RCCL)" % world)
+                               if world > 1 else "single GPU",
             },
             "roofline": roofline,
             "kernel_avg_us": kernels_us,

@@ -321,6 +321,256 @@ __global__ __launch_bounds__(256, 2) void attn_f32s_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4, second step: K / V are split ONCE per launch, not once per 128-query workgroup.  attn_f32s_kernel above
+// converts every 32-key tile in every workgroup that reads it (a window of 1024 tokens: 8 times), and its matrix pipe
+// idles while all 256 threads run the conversion: 102 TFLOP/s at (B 64, L 1024, D 128).  Here
+//   kv_split_kernel   writes, per (batch entry, 32-key tile), the exact LDS image the attention loop consumes -- K hi / lo /
+//                     third piece as [key][D halfs + 16 B] rows, V^T hi / lo as [d][32 key slots + 16 B] rows in the
+//                     accumulator's key order, all scaled as above -- padded to whole 4 KiB so that every wave copies the
+//                     same number of 1 KiB pieces;
+//   attn_f32p_kernel  copies the images by LDS-DMA into ONE K buffer and ONE V buffer and alternates them: while the waves
+//                     multiply K(t) Q^T the V^T(t) image lands, while they multiply V^T(t) P^T the K(t+1) image lands
+//                     (four barriers per tile, counted vmcnt); no conversion, no staging registers, no ds_write.
+// Same arithmetic as attn_f32s_kernel<D, DV, 3>, bit for bit (the pieces are the same numbers).
+// ------------------------------------------------------------------------------------------------
+template <int D, int DV>
+struct A32Img {
+    static constexpr int KROW = D * 2 + 16, VROW = 64 + 16;
+    static constexpr int KIMG = 3 * 32 * KROW, VIMG = 2 * DV * VROW;
+    static constexpr int NKP = (KIMG + 4095) / 4096, NVP = (VIMG + 4095) / 4096;  // 1 KiB pieces PER WAVE (4 waves)
+    static constexpr int KIMGP = NKP * 4096, VIMGP = NVP * 4096;
+    static constexpr int TILE = KIMGP + VIMGP;
+};
+
+template <int D, int DV>
+__global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                        char* __restrict__ img, int Lk, int dv_real) {
+    using I = A32Img<D, DV>;
+    constexpr int KROW = I::KROW, VROW = I::VROW;
+    __shared__ __attribute__((aligned(16))) char s[I::TILE];
+    const int t = blockIdx.x, b = blockIdx.y, nT = gridDim.x, tid = threadIdx.x;
+    const float* kb = k + (int64_t)b * Lk * D;
+    const float* vb = v + (int64_t)b * Lk * dv_real;
+    for (int i = tid; i < I::TILE / 16; i += 256) reinterpret_cast<uint4*>(s)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    char* kh_s = s;
+    char* kl_s = s + 32 * KROW;
+    char* km_s = s + 2 * 32 * KROW;
+    char* vh_s = s + I::KIMGP;
+    char* vl_s = vh_s + DV * VROW;
+    for (int c = tid; c < 32 * (D / 4); c += 256) {
+        const int r = c / (D / 4), d4 = c % (D / 4);
+        const int key = t * 32 + r;
+        floatx4 val = {0.f, 0.f, 0.f, 0.f};
+        if (key < Lk) val = *reinterpret_cast<const floatx4*>(kb + (int64_t)key * D + d4 * 4) * 64.f;
+        half4_t h4, l4, m4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const half_t hh = (half_t)val[e];
+            const half_t ll = (half_t)(val[e] - (float)hh);
+            h4[e] = hh;
+            l4[e] = ll;
+            m4[e] = (half_t)(((val[e] - (float)hh) - (float)ll) * 4096.f);
+        }
+        *reinterpret_cast<half4_t*>(kh_s + r * KROW + d4 * 8) = h4;
+        *reinterpret_cast<half4_t*>(kl_s + r * KROW + d4 * 8) = l4;
+        *reinterpret_cast<half4_t*>(km_s + r * KROW + d4 * 8) = m4;
+    }
+    for (int c = tid; c < 32 * DV; c += 256) {
+        const int r = c / DV, d = c % DV;
+        const int key = t * 32 + r;
+        const float val = (key < Lk && d < dv_real) ? vb[(int64_t)key * dv_real + d] * 64.f : 0.f;
+        const int pos = (r >> 4) * 16 + ((r >> 2) & 1) * 8 + ((r >> 3) & 1) * 4 + (r & 3);
+        const half_t hh = (half_t)val;
+        *reinterpret_cast<half_t*>(vh_s + d * VROW + pos * 2) = hh;
+        *reinterpret_cast<half_t*>(vl_s + d * VROW + pos * 2) = (half_t)(val - (float)hh);
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(img + ((int64_t)b * nT + t) * I::TILE);
+    for (int i = tid; i < I::TILE / 16; i += 256) dst[i] = reinterpret_cast<const uint4*>(s)[i];
+}
+
+template <int N_>
+__device__ __forceinline__ void a32_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
+}
+
+template <int D, int DV>
+__global__ __launch_bounds__(256, 2) void attn_f32p_kernel(const float* __restrict__ q, const char* __restrict__ img,
+                                                            float* __restrict__ out, int Lq, int Lk, int dv_real,
+                                                            float scale_log2) {
+    using I = A32Img<D, DV>;
+    constexpr int KROW = I::KROW, VROW = I::VROW, NKP = I::NKP, NVP = I::NVP;
+    constexpr int NDB = DV / 32, NKS = D / 16;
+    __shared__ __attribute__((aligned(16))) char kbuf[I::KIMGP];
+    __shared__ __attribute__((aligned(16))) char vbuf[I::VIMGP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.y;
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const float* qp = q + ((int64_t)b * Lq + (qrow < Lq ? qrow : Lq - 1)) * D + hi * 8;
+    const int nT = (Lk + 31) / 32;
+    const char* ib = img + (int64_t)b * nT * I::TILE;
+    const uint32_t ldsk =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)kbuf);
+    const uint32_t ldsv =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)vbuf);
+    const uint32_t voff = (uint32_t)lane * 16;
+    auto stage_k = [&](int t) __attribute__((always_inline)) {  // wave w copies KiB w, w + 4, ... of the K image
+        const char* src = ib + (int64_t)t * I::TILE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NKP; ++i)
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src + i * 4096),
+                         "s"(ldsk + (uint32_t)(wave * 1024 + i * 4096))
+                         : "memory");
+    };
+    auto stage_v = [&](int t) __attribute__((always_inline)) {
+        const char* src = ib + (int64_t)t * I::TILE + I::KIMGP + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NVP; ++i)
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src + i * 4096),
+                         "s"(ldsv + (uint32_t)(wave * 1024 + i * 4096))
+                         : "memory");
+    };
+    stage_k(0);
+    stage_v(0);
+
+    half8_t qh[NKS], ql[NKS], qm[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const floatx4 a = *reinterpret_cast<const floatx4*>(qp + ks * 16);
+        const floatx4 c = *reinterpret_cast<const floatx4*>(qp + ks * 16 + 4);
+        const float sq = scale_log2 * 64.f;
+        const float x[8] = {a[0] * sq, a[1] * sq, a[2] * sq, a[3] * sq, c[0] * sq, c[1] * sq, c[2] * sq, c[3] * sq};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const half_t hh = (half_t)x[e];
+            const half_t ll = (half_t)(x[e] - (float)hh);
+            qh[ks][e] = hh;
+            ql[ks][e] = ll;
+            qm[ks][e] = (half_t)(((x[e] - (float)hh) - (float)ll) * 4096.f);
+        }
+    }
+    floatx16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const char* kh_s = kbuf;
+    const char* kl_s = kbuf + 32 * KROW;
+    const char* km_s = kbuf + 2 * 32 * KROW;
+    const char* vh_s = vbuf;
+    const char* vl_s = vbuf + DV * VROW;
+
+    for (int t = 0; t < nT; ++t) {
+        a32_wait_barrier<NVP>();  // K(t) has landed for everyone (the V(t) pieces, issued after it, may still fly)
+        floatx16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const half8_t ah = *reinterpret_cast<const half8_t*>(kh_s + l31 * KROW + ks * 32 + hi * 16);
+            const half8_t am = *reinterpret_cast<const half8_t*>(km_s + l31 * KROW + ks * 32 + hi * 16);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, qh[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qm[ks], s, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= 0x1p-12f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const half8_t ah = *reinterpret_cast<const half8_t*>(kh_s + l31 * KROW + ks * 32 + hi * 16);
+            const half8_t al = *reinterpret_cast<const half8_t*>(kl_s + l31 * KROW + ks * 32 + hi * 16);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ql[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], s, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done reading the K buffer
+        if (t + 1 < nT) stage_k(t + 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= 0x1p-12f;  // undo the 2^6 of Q and of K (exact)
+        if ((t + 1) * 32 > Lk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (key >= Lk) s[r] = -1e30f;
+            }
+        }
+        float mt = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = exp2f(s[r] - m_new);
+            psum += s[r];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        // V(t) has landed (what may still fly is K(t + 1), issued after it)
+        if (t + 1 < nT)
+            a32_wait_barrier<NKP>();
+        else
+            a32_wait_barrier<0>();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            half8_t ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = s[st * 8 + e] * 4096.f;
+                const half_t hh = (half_t)x;
+                ph[e] = hh;
+                pl[e] = (half_t)(x - (float)hh);
+            }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const half8_t vh8 = *reinterpret_cast<const half8_t*>(vh_s + (db * 32 + l31) * VROW + st * 32 + hi * 16);
+                const half8_t vl8 = *reinterpret_cast<const half8_t*>(vl_s + (db * 32 + l31) * VROW + st * 32 + hi * 16);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph, o[db], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nT) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done reading the V buffer
+            stage_v(t + 1);
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 0x1p-18f / l_tot;
+    if (qrow < Lq) {
+        float* op = out + ((int64_t)b * Lq + qrow) * dv_real;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (d < dv_real) op[d] = o[db][r] * inv;
+            }
+    }
+}
+
+template <int D, int DV>
+static int launch_attn32p(const float* q, const float* k, const float* v, float* out, char* img, int B, int Lq, int Lk, int dv,
+                          float scale, hipStream_t st) {
+    ProfScope ps(FRESCO_PROF_ATTN_F32, B, Lq, Lk, D, st);
+    const int nT = (Lk + 31) / 32;
+    hipLaunchKernelGGL((kv_split_kernel<D, DV>), dim3(nT, B), dim3(256), 0, st, k, v, img, Lk, dv);
+    hipLaunchKernelGGL((attn_f32p_kernel<D, DV>), dim3((Lq + 127) / 128, B), dim3(256), 0, st, q, img, out, Lq, Lk, dv,
+                       scale * 1.4426950408889634f);
+    return check_launch();
+}
+
 template <int D, int DV>
 static int launch_attn32(const float* q, const float* k, const float* v, float* out, int B, int Lq, int Lk, int dv,
                          float scale, hipStream_t st) {
@@ -365,3 +615,48 @@ extern "C" int fresco_attn_f32(const float* q, const float* k, const float* v, f
 #undef FRESCO_A32
     return FRESCO_EUNSUPPORTED;
 }
+
+// ---- the same with a caller-provided workspace: K / V are split once per launch (kv_split_kernel + attn_f32p_kernel) ----
+template <int D, int DV>
+static size_t a32_ws_bytes(int B, int Lk) {
+    return (size_t)B * ((Lk + 31) / 32) * A32Img<D, DV>::TILE;
+}
+
+extern "C" size_t fresco_attn_f32_workspace_bytes(int B, int Lk, int D, int Dv) {
+    if (B <= 0 || Lk <= 0 || Dv <= 0 || Dv > 128) return 0;
+#define FRESCO_A32W(DD)                                                  \
+    if (D == DD) {                                                       \
+        if (Dv <= 32) return a32_ws_bytes<DD, 32>(B, Lk);                \
+        if (Dv <= 64) return a32_ws_bytes<DD, 64>(B, Lk);                \
+        return a32_ws_bytes<DD, 128>(B, Lk);                             \
+    }
+    FRESCO_A32W(32)
+    FRESCO_A32W(64)
+    FRESCO_A32W(128)
+#undef FRESCO_A32W
+    return 0;
+}
+
+extern "C" int fresco_attn_f32_ws(const float* q, const float* k, const float* v, float* out, void* workspace,
+                                  size_t workspace_bytes, int B, int Lq, int Lk, int D, int Dv, float scale, void* stream) {
+    if (!q || !k || !v || !out || !workspace || B <= 0 || Lq <= 0 || Lk <= 0 || D <= 0 || Dv <= 0 || !(scale > 0.f))
+        return FRESCO_EINVAL;
+    if (B > 65535) return FRESCO_EUNSUPPORTED;
+    const size_t need = fresco_attn_f32_workspace_bytes(B, Lk, D, Dv);
+    if (need == 0) return FRESCO_EUNSUPPORTED;
+    if (workspace_bytes < need) return FRESCO_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    char* img = static_cast<char*>(workspace);
+#define FRESCO_A32P(DD)                                                                                  \
+    if (D == DD) {                                                                                       \
+        if (Dv <= 32) return launch_attn32p<DD, 32>(q, k, v, out, img, B, Lq, Lk, Dv, scale, st);        \
+        if (Dv <= 64) return launch_attn32p<DD, 64>(q, k, v, out, img, B, Lq, Lk, Dv, scale, st);        \
+        return launch_attn32p<DD, 128>(q, k, v, out, img, B, Lq, Lk, Dv, scale, st);                     \
+    }
+    FRESCO_A32P(32)
+    FRESCO_A32P(64)
+    FRESCO_A32P(128)
+#undef FRESCO_A32P
+    return FRESCO_EUNSUPPORTED;
+}
+

@@ -229,9 +229,14 @@ def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, gro
     return out
 
 
+_a32_ws = {}
+
+
 def attention_f32(q, k, v, scale):
-    """softmax(scale * q k^T) v in fp32 (fresco_attn_f32): q (B,Lq,D), k (B,Lk,D), v (B,Lk,Dv) -> (B,Lq,Dv).
-    One head; batch entries are independent problems (windows)."""
+    """softmax(scale * q k^T) v at fp32 accuracy (fresco_attn_f32 / fresco_attn_f32_ws): q (B,Lq,D), k (B,Lk,D),
+    v (B,Lk,Dv) -> (B,Lq,Dv).  One head; batch entries are independent problems (windows).  When several 128-query
+    workgroups share a key set (Lq >= 512) K and V are converted to the kernel's operand images once per launch, into a
+    workspace cached per device (grown on demand)."""
     _need_gpu(q, k, v)
     q, k, v = _f32c(q), _f32c(k), _f32c(v)
     B, Lq, D = q.shape
@@ -239,8 +244,18 @@ def attention_f32(q, k, v, scale):
     if k.shape != (B, Lk, D) or v.shape[:2] != (B, Lk):
         raise ValueError("attention_f32: q (B,Lq,D), k (B,Lk,D), v (B,Lk,Dv) expected")
     out = torch.empty(B, Lq, Dv, dtype=torch.float32, device=q.device)
-    rc = _lib.load().fresco_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, Lk, D, Dv,
-                                     float(scale), _stream())
+    lib = _lib.load()
+    need = lib.fresco_attn_f32_workspace_bytes(B, Lk, D, Dv) if Lq >= 512 else 0
+    if need:
+        ws = _a32_ws.get(q.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+            _a32_ws[q.device] = ws
+        rc = lib.fresco_attn_f32_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B,
+                                    Lq, Lk, D, Dv, float(scale), _stream())
+    else:
+        rc = lib.fresco_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, Lk, D, Dv,
+                                 float(scale), _stream())
     _lib.check(rc, "fresco_attn_f32(B=%d,Lq=%d,Lk=%d,D=%d,Dv=%d)" % (B, Lq, Lk, D, Dv))
     return out
 

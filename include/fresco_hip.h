@@ -200,9 +200,17 @@ int fresco_max_pool(const float* x, float* out, int BC, int H, int W, int k, voi
  *   correlation softmax (gmflow/matching.py:7-36: v = pixel grid, Dv = 2) and flow propagation
  *   (gmflow/transformer.py:356-372: v = flow, Dv = 2).
  *   q (B,Lq,D), k (B,Lk,D), v (B,Lk,Dv), out (B,Lq,Dv): fp32 row-major, dense.  D in {32, 64, 128}, Dv <= 128.
- *   fp32 MFMA for both contractions, fp32 softmax (the flows feed integer decisions downstream). */
+ *   fp32-class accuracy on the fp16 matrix pipe: operands split into fp16 pieces (33-bit logits, 22-bit P V products),
+ *   fp32 softmax (the flows feed integer decisions downstream).  |q scale|, |k|, |v| < 1000. */
 int fresco_attn_f32(const float* q, const float* k, const float* v, float* out, int B, int Lq, int Lk, int D, int Dv,
                     float scale, void* stream);
+
+/* The same with a caller-provided workspace (fresco_attn_f32_workspace_bytes(B, Lk, D, Dv) bytes, 16-byte aligned): K and
+ * V are converted to the kernel's split-fp16 LDS images ONCE per launch instead of once per 128-query workgroup (what
+ * pays as soon as several workgroups share a key set: Lq >= 512).  Same results as fresco_attn_f32, bit for bit. */
+size_t fresco_attn_f32_workspace_bytes(int B, int Lk, int D, int Dv);
+int fresco_attn_f32_ws(const float* q, const float* k, const float* v, float* out, void* workspace,
+                       size_t workspace_bytes, int B, int Lq, int Lk, int D, int Dv, float scale, void* stream);
 
 /* forward_backward_consistency_check (gmflow/geometry.py:75-96) fused with the colour-difference
  * occlusion refinement of get_flow_and_interframe_paras (DH:919-926).  Pair n couples frame n with frame

@@ -47,3 +47,25 @@ def test_attention_f32_peaked_logits_and_validation():
         ops.attention_f32(q.to(DEV)[..., :48], k.to(DEV)[..., :48], v.to(DEV), 1.0)   # D = 48 unsupported
     with pytest.raises(ValueError):
         ops.attention_f32(q.to(DEV), k.to(DEV)[:, :10], v.to(DEV), 1.0)
+
+
+def test_attention_f32_workspace_form_is_bit_identical():
+    """fresco_attn_f32_ws (K / V split once per launch, operand images by LDS-DMA) runs the arithmetic of fresco_attn_f32 on the
+    same numbers: the results must be equal bit for bit (ragged last key tile, Lq not a multiple of 128, Dv 128 / 2)."""
+    import fresco_amd.ops as ops
+    from fresco_amd import _lib
+    lib = _lib.load()
+    g = synth.gen(77)
+    for (B, Lq, Lk, D, Dv) in ((3, 600, 333, 128, 128), (2, 1024, 1024, 128, 2), (2, 512, 96, 64, 40), (1, 515, 700, 32, 5)):
+        q = (torch.randn(B, Lq, D, generator=g) * 1.5).to(DEV)
+        k = (torch.randn(B, Lk, D, generator=g) * 1.5).to(DEV)
+        v = torch.randn(B, Lk, Dv, generator=g).to(DEV)
+        a = ops.attention_f32(q, k, v, 1.0 / math.sqrt(D))          # Lq >= 512: the workspace form
+        b = torch.empty_like(a)
+        rc = lib.fresco_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), b.data_ptr(), B, Lq, Lk, D, Dv,
+                                 1.0 / math.sqrt(D), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (B, Lq, Lk, D, Dv, float((a - b).abs().max()))
+        assert float((a.cpu().double() - _ref(q.cpu(), k.cpu(), v.cpu(), 1.0 / math.sqrt(D))).abs().max()) < 2e-5 * max(1.0, float(a.abs().max()))
+
