@@ -235,7 +235,7 @@ _a32_ws = {}
 def attention_f32(q, k, v, scale):
     """softmax(scale * q k^T) v at fp32 accuracy (fresco_attn_f32 / fresco_attn_f32_ws): q (B,Lq,D), k (B,Lk,D),
     v (B,Lk,Dv) -> (B,Lq,Dv).  One head; batch entries are independent problems (windows).  When several 128-query
-    workgroups share a key set (Lq >= 512) K and V are converted to the kernel's operand images once per launch, into a
+    workgroups share a key set (Lq >= 256) K and V are converted to the kernel's operand images once per launch, into a
     workspace cached per device (grown on demand)."""
     _need_gpu(q, k, v)
     q, k, v = _f32c(q), _f32c(k), _f32c(v)
@@ -245,7 +245,7 @@ def attention_f32(q, k, v, scale):
         raise ValueError("attention_f32: q (B,Lq,D), k (B,Lk,D), v (B,Lk,Dv) expected")
     out = torch.empty(B, Lq, Dv, dtype=torch.float32, device=q.device)
     lib = _lib.load()
-    need = lib.fresco_attn_f32_workspace_bytes(B, Lk, D, Dv) if Lq >= 512 else 0
+    need = lib.fresco_attn_f32_workspace_bytes(B, Lk, D, Dv) if Lq >= 256 else 0
     if need:
         ws = _a32_ws.get(q.device)
         if ws is None or ws.numel() < need:

@@ -207,7 +207,7 @@ int fresco_attn_f32(const float* q, const float* k, const float* v, float* out, 
 
 /* The same with a caller-provided workspace (fresco_attn_f32_workspace_bytes(B, Lk, D, Dv) bytes, 16-byte aligned): K and
  * V are converted to the kernel's split-fp16 LDS images ONCE per launch instead of once per 128-query workgroup (what
- * pays as soon as several workgroups share a key set: Lq >= 512).  Same results as fresco_attn_f32, bit for bit. */
+ * pays as soon as two workgroups share a key set: Lq >= 256).  Same results as fresco_attn_f32, bit for bit. */
 size_t fresco_attn_f32_workspace_bytes(int B, int Lk, int D, int Dv);
 int fresco_attn_f32_ws(const float* q, const float* k, const float* v, float* out, void* workspace,
                        size_t workspace_bytes, int B, int Lq, int Lk, int D, int Dv, float scale, void* stream);

@@ -60,7 +60,7 @@ def test_attention_f32_workspace_form_is_bit_identical():
         q = (torch.randn(B, Lq, D, generator=g) * 1.5).to(DEV)
         k = (torch.randn(B, Lk, D, generator=g) * 1.5).to(DEV)
         v = torch.randn(B, Lk, Dv, generator=g).to(DEV)
-        a = ops.attention_f32(q, k, v, 1.0 / math.sqrt(D))          # Lq >= 512: the workspace form
+        a = ops.attention_f32(q, k, v, 1.0 / math.sqrt(D))          # Lq >= 256: the workspace form
         b = torch.empty_like(a)
         rc = lib.fresco_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), b.data_ptr(), B, Lq, Lk, D, Dv,
                                  1.0 / math.sqrt(D), None)

@@ -67,7 +67,7 @@ def measure(N=8, R=512, dev="cuda", reps=3, verbose=False):
                gmflow_forward_ms=round(1e3 * t_net, 2), get_flow_and_interframe_paras_ms=round(1e3 * t_all, 2),
                attention_ms_of_forward=round(tot, 2), timing="fastest of %d" % reps, attn_f32_launches=launches)
     if best:
-        res["roofline"] = dict(bound="mfma", kernel="attn_f32s_kernel<128,128,3> (swin window attention, B 64, L 1024, D 128)",
+        res["roofline"] = dict(bound="mfma", kernel="kv_split_kernel + attn_f32p_kernel<128,128> (swin window attention, B 64, L 1024, D 128)",
                                achieved=best["executed_fp16_tflops"], peak=PEAK_F16_DENSE / 1e12, unit="TFLOP/s",
                                frac=best["frac_executed_of_fp16_peak"],
                                algorithmic_tflops=best["algorithmic_tflops"],
