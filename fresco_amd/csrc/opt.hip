@@ -24,6 +24,7 @@
 //   adam_update    temporal gradient + norm backward + Adam step, fused, fp32 state
 #include "opt_shared.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace fresco {
 
@@ -996,25 +997,30 @@ static OptWs ws_half(const OptWs& w, int ck0, int N, int NP, int C, int hw) {
 // 4: as 3, and a half's adam (+ next prep) additionally waits for the OTHER half's Gram launch to finish, so that the
 // HBM-bound launches run beside the S V launch (the least memory-hungry one), never beside a Gram launch.
 struct SideStream {
+    std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call at a time uses the side stream; a concurrent caller runs on one stream
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
     hipEvent_t sv_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // [half][iteration parity]
     hipEvent_t gram_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][iteration parity]
 };
-static SideStream* side_stream() {
+static SideStream* side_stream() {  // (the slot of the current device; its stream / events are created by its first owner)
     static SideStream tab[32];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    SideStream& t = tab[dev];
-    if (!t.s) {
-        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        (void)hipEventCreateWithFlags(&t.fork, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&t.mid, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&t.join, hipEventDisableTiming);
-        for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&t.sv_done[i >> 1][i & 1], hipEventDisableTiming);
-        for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&t.gram_done[i >> 1][i & 1], hipEventDisableTiming);
+    return &tab[dev];
+}
+static bool side_stream_ready(SideStream& t) {  // call with t.busy held
+    if (t.s) return true;
+    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) {
+        t.s = nullptr;
+        return false;
     }
-    return &t;
+    (void)hipEventCreateWithFlags(&t.fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&t.mid, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&t.join, hipEventDisableTiming);
+    for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&t.sv_done[i >> 1][i & 1], hipEventDisableTiming);
+    for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&t.gram_done[i >> 1][i & 1], hipEventDisableTiming);
+    return true;
 }
 static int opt_split_mode(int planes_hw) {
     static const int env = [] {
@@ -1046,7 +1052,15 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
     if (opt_fast_ok(C, h, w, has_s)) {
         const int hw = h * w;
         SideStream* sd = (chunk == 2 && !prof_active() && iters > 0) ? side_stream() : nullptr;
-        const int split = sd ? opt_split_mode(N * hw) : 0;
+        int split = sd ? opt_split_mode(N * hw) : 0;
+        if (split && sd->busy.test_and_set(std::memory_order_acquire)) split = 0;  // (another host thread owns the side stream)
+        struct Release {
+            SideStream* p;
+            ~Release() {
+                if (p) p->busy.clear(std::memory_order_release);
+            }
+        } release{split ? sd : nullptr};
+        if (split && !side_stream_ready(*sd)) split = 0;
         if (!split) {
             opt_fast_begin(ws, cs, chunk * N, C, hw, st);
             for (int it = 1; it <= iters; ++it)
