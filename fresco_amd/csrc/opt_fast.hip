@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
     const int fn = (L.circular || !a.has_t) ? pj : pj - 1;  // the local frame this thread normalises (-1: a halo frame)
     const int sa = pj, sb = L.circular ? (pj + 1) % L.n_loc : pj + 1;
     float lsum = 0.f;
+    __shared__ __attribute__((aligned(16))) half_t cmx[4][2][8][64];  // [slice = wave][hi, lo][channel of the octet][pixel]
     if (j < a.NPART) {
         const bool do_norm = fn >= 0;
         const int64_t bn = (int64_t)ck * L.n_loc + fn;
@@ -151,6 +152,11 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
             }
             if (do_norm) {
                 half8_t h8, l8;
+                // channel-major copies: the wave (= one slice: 64 consecutive pixels x 8 channels) transposes its octet
+                // through its own LDS rows so that a lane stores 8 consecutive PIXELS of one channel -- one 16-byte unit of
+                // either layout -- instead of 16 two-byte stores per thread
+                half_t* th = &cmx[sl][0][0][0];
+                half_t* tl = &cmx[sl][1][0][0];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float val = x1[k] / n;
@@ -158,13 +164,24 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
                     const half_t lo16 = (half_t)(val - (float)hi16);
                     h8[k] = hi16;
                     l8[k] = lo16;
-                    const int c = c0 + k;
-                    const int64_t ov = a.cm_tiled ? ((((int64_t)bn * (C / 128) + c / 128) * (hw / 32) + p / 32) * 128 + c % 128) * 32 +
-                                                        (((((p & 31) >> 3) ^ (c >> 2)) & 3) << 3) + (p & 7)
-                                                  : ((int64_t)bn * C + c) * hw + p;
-                    a.vh[ov] = hi16;
-                    a.vl[ov] = lo16;
+                    th[k * 64 + px] = hi16;
+                    tl[k * 64 + px] = lo16;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {
+                    const int kk = px >> 3, g = px & 7, c = c0 + kk, P = p - px + g * 8;
+                    const half8_t uh = *reinterpret_cast<const half8_t*>(th + kk * 64 + g * 8);
+                    const half8_t ul = *reinterpret_cast<const half8_t*>(tl + kk * 64 + g * 8);
+                    const int64_t ov = a.cm_tiled ? ((((int64_t)bn * (C / 128) + c / 128) * (hw / 32) + P / 32) * 128 + c % 128) * 32 +
+                                                        (((((P & 31) >> 3) ^ (c >> 2)) & 3) << 3)
+                                                  : ((int64_t)bn * C + c) * hw + P;
+                    *reinterpret_cast<half8_t*>(a.vh + ov) = uh;
+                    *reinterpret_cast<half8_t*>(a.vl + ov) = ul;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // (the rows are rewritten by the next octet)
                 // pixel-major: the octet is one 16-byte unit of the pixel's row
                 const int64_t op = a.pm_tiled ? ((((int64_t)bn * (hw / 128) + p / 128) * (C / 16) + c0 / 16) * 128 + p % 128) * 16 +
                                                     ((((c0 % 16) >> 3) ^ ((p >> 3) & 1)) << 3)
