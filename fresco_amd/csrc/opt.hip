@@ -1023,10 +1023,8 @@ static bool side_stream_ready(SideStream& t) {  // call with t.busy held
     return true;
 }
 static int opt_split_mode(int planes_hw) {
-    static const int env = [] {
-        const char* e = getenv("FRESCO_OPT_SPLIT");
-        return e ? atoi(e) : -1;
-    }();
+    const char* e = getenv("FRESCO_OPT_SPLIT");  // (read per call: the tests switch it)
+    const int env = e ? atoi(e) : -1;
     if (env >= 0) return env;
     return planes_hw >= 8 * 1024 ? 1 : 0;  // small planes are launch-bound: twice the launches would not pay
 }

@@ -965,9 +965,9 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
         __syncthreads();
         if (tid < TP) {
             float* dp = dotp + ((int64_t)b * (2 * nct) + 2 * (c0 / SB_TC)) * hw + p0 + tid;
-            if (CT == 128) {
-                dp[0] = red[tid] + red[TP + tid];
-                dp[hw] = 0.f;
+            if (CT == 128) {  // (one slot per 64 channels in both tile shapes: the Adam kernel adds them in the same order)
+                dp[0] = red[tid];
+                dp[hw] = red[TP + tid];
             } else {
                 dp[(int64_t)hf * hw] = red[tid];
             }
@@ -1060,7 +1060,9 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
                                    w.vpl, target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
         } else if (small) {
             const int nt = hw / 64;
-            if (nt * nt * planes < 128) {
+            // (the wave count is the split of the contraction, i.e. part of the arithmetic: chosen by the size of the WHOLE
+            // problem, so that one CFG half alone, or a rank's frame shard, rounds exactly as the undivided batch does)
+            if (nt * nt * Bg < 128) {
                 constexpr int lds = 8 * 64 * GS_RS * 4;
                 static const bool once = [] {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16s_kernel<8>),
@@ -1103,10 +1105,8 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
             // fill at most a quarter of the slots (or a launch smaller than one round) run as two half tiles each: measured
             // 116 -> 102 us at (1280, 32^2), 28 -> 21 us at (1280, 16^2); at (640, 64^2) -- 2.5 rounds -- the half-tile round
             // does not pay (514 -> 534 us).  FRESCO_OPT_SVTAIL=0: whole tiles only
-            static const int tail_split = [] {
-                const char* e = getenv("FRESCO_OPT_SVTAIL");
-                return (e && e[0] == '0') ? 0 : 1;
-            }();
+            const char* tail_env = getenv("FRESCO_OPT_SVTAIL");  // (read per call: the tests switch it)
+            const int tail_split = (tail_env && tail_env[0] == '0') ? 0 : 1;
             const int tiles = (hw / 256) * (C / SB_TC) * planes, slots = 512;
             int rem = tiles % slots;
             if (!tail_split || (rem > slots / 4 && tiles > slots)) rem = 0;

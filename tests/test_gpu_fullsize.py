@@ -210,7 +210,7 @@ def test_opt_20_iterations_final_loss_at_a_shipping_shape():
 
 
 @pytest.mark.parametrize("C,h", [(640, 64), (1280, 32)])
-def test_opt_20_iterations_final_loss_at_the_big_shapes(C, h):
+def test_opt_20_iterations_final_loss_at_the_big_shapes(C, h, monkeypatch):
     """The same criterion at the two shapes that cost 89 % of the feature optimisation's time: up_blocks.3's input
     (C = 640, 64 x 64) and up_blocks.2's (C = 1280, 32 x 32), 8 frames, CFG batch 16, 20 Adam iterations
     (src/diffusion_hacked.py:432-485).  The oracle's loop (analytic gradients, fp32) is evaluated by torch on the GPU
@@ -228,6 +228,14 @@ def test_opt_20_iterations_final_loss_at_the_big_shapes(C, h):
     cs2 = x.to(DEV).clone()
     ops.opt_run(cs2, prep, td, 100.0, 20, 2)
     assert torch.equal(cs, cs2)
+    # ... and the launch form must not matter: one stream (FRESCO_OPT_SPLIT=0), two pipelines started half an iteration
+    # apart (2), whole S V tiles only (FRESCO_OPT_SVTAIL=0: these shapes run a half-tile tail round in one form or the other)
+    for var, val in (("FRESCO_OPT_SPLIT", "0"), ("FRESCO_OPT_SPLIT", "2"), ("FRESCO_OPT_SVTAIL", "0")):
+        monkeypatch.setenv(var, val)
+        cs3 = x.to(DEV).clone()
+        ops.opt_run(cs3, prep, td, 100.0, 20, 2)
+        monkeypatch.delenv(var)
+        assert torch.equal(cs, cs3), (var, val, int((cs != cs3).sum()))
     ref = O.optimize_feature(x.to(DEV), fd, od, [td], iters=20, return_raw=True)
     prep64 = O.opt_prepare(h, fd, od, 2, torch.float64)
     l_ours = float(O.opt_loss_and_grad(cs.double(), prep64, td.double(), 100.0)[0])

@@ -197,3 +197,32 @@ def test_optimize_feature_fp16_sample_layer_shape():
     ref = O.optimize_feature(x16, case["flows"], case["occs"], [case["target"]], iters=2)
     df = (out.float().cpu() - ref.float()).abs()
     assert float(df.median()) < 2e-3 and float((df > 2e-2).double().mean()) < 0.02
+
+
+@pytest.mark.parametrize("C,h,w", [(256, 16, 16), (128, 16, 32), (1280, 8, 8)])
+def test_launch_forms_are_bit_identical(C, h, w, monkeypatch):
+    """the S V tile shape (whole 128-channel tiles or two 64-channel halves: FRESCO_OPT_SVTAIL) and the one- / two-stream
+    forms (FRESCO_OPT_SPLIT) are scheduling choices: the features after 5 Adam steps must not depend on them (a first
+    form of the <V, dV> partials added (a + b) + (c + d) in one tile shape and a + b + c + d in the other: the chaotic
+    L1 + Adam dynamics turned that last-place difference into 0.25 after 20 iterations)"""
+    import fresco_amd.ops as ops
+    from fresco_amd.warp import _prep_flow_occ
+    g = synth.gen(3 * C + h)
+    N = 4
+    x = torch.randn(2 * N, C, h, w, generator=g)
+    bwd = torch.tensor([0.8, -1.2]).view(1, 2, 1, 1) + 0.3 * torch.randn(N, 2, 4 * h, 4 * w, generator=g)
+    flows = [-bwd, bwd]
+    occs = [(torch.rand(N, 4 * h, 4 * w, generator=g) < 0.1).float() for _ in range(2)]
+    target = O.gram_target(torch.randn(2 * N, C, h, w, generator=g)).to(DEV)
+    prep = _prep_flow_occ(h, [f.to(DEV) for f in flows], [o.to(DEV) for o in occs], with_dilate=False)
+    outs = {}
+    for split in ("0", "1", "2"):
+        for tail in ("0", "1"):
+            monkeypatch.setenv("FRESCO_OPT_SPLIT", split)
+            monkeypatch.setenv("FRESCO_OPT_SVTAIL", tail)
+            cs = x.to(DEV).clone()
+            ops.opt_run(cs, prep, target, 100.0, 5, 2)
+            outs[(split, tail)] = cs
+    ref = outs[("0", "0")]
+    for k, v in outs.items():
+        assert torch.equal(ref, v), (k, int((ref != v).sum()))
