@@ -573,11 +573,22 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
         }
         slot = slot == GY_NS - 1 ? 0 : slot + 1;
     }
-    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
-
     // ---- epilogue ----
-    int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
+    // the targets of 32 x 32 block n + 1 are requested before block n is turned into signs (block 0: before the barrier
+    // below): the epilogue waits for about one memory round trip instead of four -- while a workgroup waits there its
+    // neighbour has the CU alone and cannot fill the matrix pipe (526 -> 512 us at (640, 64^2); two blocks ahead, or
+    // block 0 from inside the K loop, spill and lose: 585 / 548 us)
     const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
+    float tnext[16];
+    auto load_targets = [&](int blk) __attribute__((always_inline)) {
+        const int i = blk >> 1, jj = blk & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            tnext[r] = wgt ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
+    };
+    load_targets(0);
+    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
+    int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
     float lsum = 0.f;
     uint32_t sg[2][2][4];  // this lane's 64 signs, 4 per dword (rows e, e+1, e+2, e+3 of one column)
 #pragma unroll
@@ -587,8 +598,8 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
             const int cl = wn * 64 + jj * 32 + l31;
             float tv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                tv[r] = wgt ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
+            for (int r = 0; r < 16; ++r) tv[r] = tnext[r];
+            if (i * 2 + jj < 3) load_targets(i * 2 + jj + 1);
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 float s4[4];
