@@ -549,22 +549,24 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
     for (int kc = 0; kc < nk; ++kc) {
         if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : GY_NS - 1);  // the slot chunk kc - 1 was read from
         const char* Ls = gy_smem + slot * GY_SLOT;
-        half8_t ah[2], al[2], bh[2], bl[2];
+        if (wgt) {  // (the waves below the diagonal of a diagonal tile only copy and synchronise: 3 % of the products)
+            half8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ah[i] = *reinterpret_cast<const half8_t*>(Ls + rA + i * 1024);
-            al[i] = *reinterpret_cast<const half8_t*>(Ls + 2 * GY_BLK + rA + i * 1024);
-            bh[i] = *reinterpret_cast<const half8_t*>(Ls + rB + i * 1024);
-            bl[i] = *reinterpret_cast<const half8_t*>(Ls + GY_BLK + rB + i * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const half8_t*>(Ls + rA + i * 1024);
+                al[i] = *reinterpret_cast<const half8_t*>(Ls + 2 * GY_BLK + rA + i * 1024);
+                bh[i] = *reinterpret_cast<const half8_t*>(Ls + rB + i * 1024);
+                bl[i] = *reinterpret_cast<const half8_t*>(Ls + GY_BLK + rB + i * 1024);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+                }
+        }
         if (kc + 1 < nk) {
             if (kc + 2 < nk)
                 gx_wait_barrier<3>();
