@@ -265,7 +265,7 @@ int fresco_chan_mean_std(const void* x, float* mean, float* stdv, int rows, int 
  *   iters Adam steps (lr, beta1, beta2, eps as torch.optim.Adam); no autograd: analytic
  *   gradients.  The adjoint of the bilinear warp is evaluated as a deterministic gather over a
  *   per-call CSR of the tap matrix (no atomics), so results are run-to-run reproducible.
- *   With chunk == 2 and planes of >= 1024 pixels fresco_opt_run runs the two CFG halves (independent
+ *   With chunk == 2 and N * h * w >= 2048 fresco_opt_run runs the two CFG halves (independent
  *   problems) as two pipelines: one on `stream`, one on an internal side stream that is forked from
  *   and joined back into `stream` by events inside the call -- the caller sees ordinary stream order
  *   (FRESCO_OPT_SPLIT=0 keeps everything on `stream`; the results are bit-identical either way).
