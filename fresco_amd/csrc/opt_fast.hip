@@ -480,7 +480,7 @@ constexpr int GY_BLK = 128 * 32;       // one (pixel tile, chunk) block of one a
 constexpr int GY_SLOT = 6 * GY_BLK;    // Ah0 Ah1 Al0 Al1 Bh Bl
 constexpr int GY_NS = 3;
 
-template <bool LOSS>
+template <bool LOSS, bool TINIT>
 __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
                                                          const float* __restrict__ target, int8_t* __restrict__ sgn_out,
                                                          float* __restrict__ loss, int C, int hw, int s_tiled) {
@@ -526,13 +526,30 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
 #undef GY_PIECE
     };
 
+    // TINIT: the accumulators START at -T, so the K loop ends with G - T and the epilogue has no target loads on its
+    // path (they were half of its time: profiles/r04_gram_ablation.txt).  The loads are the first memory operations of
+    // the workgroup -- older than the ring's DMA copies, so the counted vmcnt waits below cover them -- and their
+    // latency is paid once, beside the ring prologue, while the other workgroup of the CU multiplies.  The partial
+    // sums run from -T towards G - T (|.| <= |T|) instead of from 0 towards G: the same rounding class as the
+    // reference's bmm followed by a subtraction, not the same last bit.
+    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
     floatx16 acc[2][2];
+    if (TINIT && wgt) {  // (one branch around all 64 loads: a select per load becomes a branch per load)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+                for (int r = 0; r < 16; ++r)
+                    acc[i][jj][r] = __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    }
 
     // fragment offsets inside a slot: unit hi of row R sits at hi ^ ((R >> 3) & 1)
     const int u = (hi ^ ((l31 >> 3) & 1)) * 16;
@@ -544,6 +561,14 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
         gx_wait_barrier<3>();
     } else {
         gx_wait_barrier<0>();
+    }
+    if (TINIT) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = -acc[i][jj][r];
     }
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
@@ -580,15 +605,14 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
     // below): the epilogue waits for about one memory round trip instead of four -- while a workgroup waits there its
     // neighbour has the CU alone and cannot fill the matrix pipe (526 -> 512 us at (640, 64^2); two blocks ahead, or
     // block 0 from inside the K loop, spill and lose: 585 / 548 us)
-    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
     float tnext[16];
     auto load_targets = [&](int blk) __attribute__((always_inline)) {
         const int i = blk >> 1, jj = blk & 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            tnext[r] = wgt ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
+            tnext[r] = (!TINIT && wgt) ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
     };
-    load_targets(0);
+    if (!TINIT) load_targets(0);
     __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
     int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
     float lsum = 0.f;
@@ -600,14 +624,14 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
             const int cl = wn * 64 + jj * 32 + l31;
             float tv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tv[r] = tnext[r];
-            if (i * 2 + jj < 3) load_targets(i * 2 + jj + 1);
+            for (int r = 0; r < 16; ++r) tv[r] = TINIT ? 0.f : tnext[r];
+            if (!TINIT && i * 2 + jj < 3) load_targets(i * 2 + jj + 1);
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 float s4[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d = acc[i][jj][r4 * 4 + e] - tv[r4 * 4 + e];
+                    const float d = TINIT ? acc[i][jj][r4 * 4 + e] : acc[i][jj][r4 * 4 + e] - tv[r4 * 4 + e];
                     if (LOSS) lsum += fabsf(d);
                     s4[e] = __builtin_amdgcn_fmed3f(d * 0x1p126f, -1.f, 1.f);  // exactly -1, 0 or +1 for d = 0 and every normal d
                 }
@@ -659,6 +683,216 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
         if (lane == 0) red[wave] = tot;
         __syncthreads();
         if (tid == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gram16z_kernel: the same product on 128 x 128 workgroup tiles, 4 waves (2 x 2, wave tiles 64 x 64), THREE workgroups
+// per CU (slot = Ah Al Bh Bl = 16 KB, 3 slots = 48 KB), for launches whose 256 x 128 tiles do not fill the chip's 512
+// workgroup slots twice: at (1280, 32^2) the 320 tiles of gram16y_kernel put two workgroups on 64 CUs and one on the
+// other 192 -- the launch takes as long as the CUs with two; 576 half-size tiles on 768 slots spread evenly.  The price
+// is 16 KB instead of 12 KB of operand copies per 48 MFMAs, which is why the big planes keep the 256-row form.
+// Tiles (ti, tj >= ti) in 128-pixel units; a diagonal tile is computed and written whole, the others are also written
+// transposed.  Every entry is the same sum in the same order as in gram16y_kernel (same chunks, same three products per
+// step, the same choice of which of S[p][q] / S[q][p] is computed and which is the copy): the two forms are bit-identical.
+// grid (tiles per plane, 1, B), 256 threads, dynamic LDS 3 * 16 KB.
+// ------------------------------------------------------------------------------------------------
+constexpr int GZ_SLOT = 4 * GY_BLK;  // Ah Al Bh Bl
+constexpr int GZ_NS = 3;
+
+static int gz_tiles_per_plane(int hw) {
+    const int n = hw / 128;
+    return n * (n + 1) / 2;
+}
+
+template <bool LOSS, bool TINIT>
+__global__ __launch_bounds__(256, 3) void gram16z_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
+                                                         const float* __restrict__ target, int8_t* __restrict__ sgn_out,
+                                                         float* __restrict__ loss, int C, int hw, int s_tiled) {
+    extern __shared__ __attribute__((aligned(16))) char gy_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const int total = gridDim.x * gridDim.z;
+    if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;  // XCD-contiguous ranges (as gram16y_kernel)
+    const int b = lin / gridDim.x;
+    int ti = 0, tj;
+    {
+        int idx = lin % gridDim.x;
+        const int n = hw / 128;
+        while (idx >= n - ti) {
+            idx -= n - ti;
+            ++ti;
+        }
+        tj = ti + idx;
+    }
+    const int p0 = ti * 128, q0 = tj * 128;
+    const int nk = C / 16;
+    const bool mirrored = ti < tj;
+
+    const char* baseH = reinterpret_cast<const char*>(vph) + (int64_t)b * hw * C * 2;
+    const char* baseL = reinterpret_cast<const char*>(vpl) + (int64_t)b * hw * C * 2;
+    // wave w copies KiB w of each of the four blocks
+    const int64_t oA = ((int64_t)ti * nk) * GY_BLK + wave * 1024;
+    const int64_t oB = ((int64_t)tj * nk) * GY_BLK + wave * 1024;
+    const uint32_t lds0 =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)gy_smem);
+    const uint32_t voff = (uint32_t)lane * 16;
+    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
+        const int64_t ko = (int64_t)kc * GY_BLK;
+        const uint32_t m0b = lds0 + (uint32_t)(slot * GZ_SLOT + wave * 1024);
+#define GZ_PIECE(I, SRC)                                                                                         \
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"((SRC) + ko),             \
+                 "s"(m0b + (uint32_t)((I)*GY_BLK))                                                                 \
+                 : "memory")
+        GZ_PIECE(0, baseH + oA);
+        GZ_PIECE(1, baseL + oA);
+        GZ_PIECE(2, baseH + oB);
+        GZ_PIECE(3, baseL + oB);
+#undef GZ_PIECE
+    };
+
+    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
+    floatx16 acc[2][2];
+    if (TINIT) {  // the accumulators start at -T (see gram16y_kernel)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][jj][r] = __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    }
+
+    // fragment offsets inside a slot: unit hi of row R sits at hi ^ ((R >> 3) & 1)
+    const int u = (hi ^ ((l31 >> 3) & 1)) * 16;
+    const int rA = (wm * 64 + l31) * 32 + u, rB = 2 * GY_BLK + (wn * 64 + l31) * 32 + u;
+
+    stage(0, 0);
+    if (nk > 1) {
+        stage(1, 1);
+        gx_wait_barrier<4>();
+    } else {
+        gx_wait_barrier<0>();
+    }
+    if (TINIT) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = -acc[i][jj][r];
+    }
+    int slot = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : GZ_NS - 1);  // the slot chunk kc - 1 was read from
+        const char* Ls = gy_smem + slot * GZ_SLOT;
+        half8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const half8_t*>(Ls + rA + i * 1024);
+            al[i] = *reinterpret_cast<const half8_t*>(Ls + GY_BLK + rA + i * 1024);
+            bh[i] = *reinterpret_cast<const half8_t*>(Ls + rB + i * 1024);
+            bl[i] = *reinterpret_cast<const half8_t*>(Ls + GY_BLK + rB + i * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+            }
+        if (kc + 1 < nk) {
+            if (kc + 2 < nk)
+                gx_wait_barrier<4>();
+            else
+                gx_wait_barrier<0>();
+        }
+        slot = slot == GZ_NS - 1 ? 0 : slot + 1;
+    }
+    // ---- epilogue (as gram16y_kernel, 128 rows) ----
+    float tnext[16];
+    auto load_targets = [&](int blk) __attribute__((always_inline)) {
+        const int i = blk >> 1, jj = blk & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            tnext[r] = TINIT ? 0.f : __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32);
+    };
+    if (!TINIT) load_targets(0);
+    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
+    int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
+    float lsum = 0.f;
+    uint32_t sg[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int cl = wn * 64 + jj * 32 + l31;
+            float tv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tv[r] = TINIT ? 0.f : tnext[r];
+            if (!TINIT && i * 2 + jj < 3) load_targets(i * 2 + jj + 1);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float s4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = TINIT ? acc[i][jj][r4 * 4 + e] : acc[i][jj][r4 * 4 + e] - tv[r4 * 4 + e];
+                    if (LOSS) lsum += fabsf(d);
+                    s4[e] = __builtin_amdgcn_fmed3f(d * 0x1p126f, -1.f, 1.f);
+                }
+                const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[0], s4[1]));
+                const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[2], s4[3]));
+                const uint32_t wv4 = __builtin_amdgcn_perm(h23, h01, 0x07050301u);
+                sg[i][jj][r4] = wv4;
+                const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
+                tr[(rl + 0) * GX_TRS + cl] = (int8_t)(wv4 & 0xff);
+                tr[(rl + 1) * GX_TRS + cl] = (int8_t)((wv4 >> 8) & 0xff);
+                tr[(rl + 2) * GX_TRS + cl] = (int8_t)((wv4 >> 16) & 0xff);
+                tr[(rl + 3) * GX_TRS + cl] = (int8_t)(wv4 >> 24);
+            }
+        }
+    __syncthreads();
+    for (int idx = tid; idx < 128 * 8; idx += 256) {
+        const int rl = idx >> 3, ch = idx & 7;
+        s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, p0 + rl, q0 + ch * 16, hw, s_tiled);
+    }
+    if (mirrored) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int cl = wn * 64 + jj * 32 + l31;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
+                    *reinterpret_cast<uint32_t*>(tr + cl * GX_TRS + rl) = sg[i][jj][r4];
+                }
+            }
+        __syncthreads();
+        for (int idx = tid; idx < 128 * 8; idx += 256) {
+            const int rl = idx >> 3, ch = idx & 7;
+            s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, q0 + rl, p0 + ch * 16, hw, s_tiled);
+        }
+    }
+    if (LOSS) {
+        float* red = reinterpret_cast<float*>(gy_smem + 40960);  // behind the staging area
+        const float tot = wave_sum((mirrored ? 2.f : 1.f) * lsum);
+        __syncthreads();
+        if (lane == 0) red[wave] = tot;
+        __syncthreads();
+        if (tid == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
     }
 }
 
@@ -833,7 +1067,7 @@ __device__ __forceinline__ void sb_wait_barrier() {
 // 2.5 rounds -- run as 2 rounds of whole tiles + 1 round of half tiles (0.6 of the time) instead of 3 whole rounds.
 // Tile t of the launch's list = (plane, pixel tile, channel tile), channel tile fastest (neighbours share their S rows).
 // <V, dV> partials: two slots per channel tile (a whole tile writes its sum and a zero, half tiles one each).
-template <int CT>
+template <int CT, bool DL>
 __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
                                                        const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
                                                        float* __restrict__ dotp, int C, int hw, float alpha, int tile_base) {
@@ -943,12 +1177,59 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
         slot = slot == NS - 1 ? 0 : slot + 1;
     }
     // epilogue: dV^T, and (dotp) this workgroup's share of <V, dV> per pixel: the sum over its channels, V = Vh + Vl
-    // re-read from the tiled copies (L2-resident: this workgroup has just streamed them)
+    // re-read from the tiled copies (L2-resident: this workgroup has just streamed them).
+    // DL (round 4): the V values come through LDS instead of 128 two-byte global gathers per lane (38 of the launch's
+    // 500 us at (640, 64^2)): the ring is free, every wave copies the rows of its own tile -- 32 channel rows x NJ pixel
+    // chunks x (hi, lo) = NJ x 4 KB, as linear 1 KiB LDS-DMA pieces of the tiled copies -- into a region of its own (no
+    // barrier: the wave that copies is the wave that reads), picks its values with ds_read_u16 through the same swizzle,
+    // and only then issues the dV stores (stores count in vmcnt: they must not sit in front of the copies).  Same
+    // products in the same order: bit-identical to the gather form.
     float dsum[NJ];
     const half_t* vht = reinterpret_cast<const half_t*>(vhb);
     const half_t* vlt = reinterpret_cast<const half_t*>(vlb);
 #pragma unroll
     for (int ni = 0; ni < NJ; ++ni) dsum[ni] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NJ; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= alpha;  // (in place: both phases below read the scaled value)
+    if (DL && dotp) {
+        __syncthreads();  // the ring is free
+        const uint32_t mybase = lds0 + (uint32_t)(wave * (NJ * 4096));
+        const char* myrd = sb_smem + wave * (NJ * 4096);
+        const int ch0 = (p0 >> 5) + wn * NJ;  // first pixel chunk of the wave's columns
+        // a lane's value of accumulator row r sits at row lr = (r & 3) + 8 (r >> 2) + 4 hi of the 32, unit ((l31 >> 3) ^ (lr >> 2)) & 3
+        // of the 64-byte row: two lane offsets (r >> 2 even / odd), the rest are immediates
+        const int lb0 = hi * 256 + ((((l31 >> 3) ^ hi) & 3) << 4) + (l31 & 7) * 2, lb1 = lb0 ^ 32;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int rl0 = hf * 64 + wm * 64 + mi * 32;  // first of the 32 channel rows (inside the 128-channel tile)
+#pragma unroll
+            for (int ni = 0; ni < NJ; ++ni)
+#pragma unroll
+                for (int ar = 0; ar < 2; ++ar)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const char* src = (ar ? vlb : vhb) + ((int64_t)(ch0 + ni) * 128 + rl0) * SB_VROW + pc * 1024;
+                        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src),
+                                     "s"(mybase + (uint32_t)(ni * 4096 + ar * 2048 + pc * 1024))
+                                     : "memory");
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ni = 0; ni < NJ; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (((r >> 2) & 1) ? lb1 : lb0) + ni * 4096 + ((r & 3) + 8 * (r >> 2)) * SB_VROW;
+                    const float vv = (float)*reinterpret_cast<const half_t*>(myrd + off) +
+                                     (float)*reinterpret_cast<const half_t*>(myrd + off + 2048);
+                    dsum[ni] = fmaf(acc[mi][ni][r], vv, dsum[ni]);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next copies overwrite the rows just read)
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -958,9 +1239,9 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = hf * 64 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // row inside the 128-channel tile
-                const float val = acc[mi][ni][r] * alpha;
+                const float val = acc[mi][ni][r];
                 dvt[((int64_t)b * C + c0 + rl) * hw + col] = val;
-                if (dotp) {
+                if (!DL && dotp) {
                     const int vi = vt0 + rl * 32 + ((((l31 >> 3) ^ (rl >> 2)) & 3) << 3);
                     dsum[ni] = fmaf(val, (float)vht[vi] + (float)vlt[vi], dsum[ni]);
                 }
@@ -1058,24 +1339,66 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         if (big) {
             constexpr int lds = GY_NS * GY_SLOT;
             static const bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<false>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<false, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<true>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<true, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 return true;
             }();
             (void)once;
-            if (gloss)
-                hipLaunchKernelGGL(gram16y_kernel<true>, dim3(gx_tiles_per_plane(hw), 1, planes), dim3(512), lds, st, w.vph,
-                                   w.vpl, target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
-            else
-                hipLaunchKernelGGL(gram16y_kernel<false>, dim3(gx_tiles_per_plane(hw), 1, planes), dim3(512), lds, st, w.vph,
-                                   w.vpl, target, w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
+            const char* ti_env = getenv("FRESCO_GRAM_TINIT");  // (experiment switch, read per call)
+            const bool tinit = !(ti_env && ti_env[0] == '0');
+            // launches whose 256 x 128 tiles would not fill the 512 workgroup slots twice take the 128 x 128 form (three
+            // workgroups per CU; same bits): FRESCO_GRAM_Z=0 keeps the 256-row form
+            const char* z_env = getenv("FRESCO_GRAM_Z");
+            const bool zform = !(z_env && z_env[0] == '0') && gx_tiles_per_plane(hw) * Bg < 1024;
+            if (zform) {
+                constexpr int ldsz = GZ_NS * GZ_SLOT;
+                static const bool oncez = [] {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<false, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsz);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<true, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsz);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsz);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<true, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsz);
+                    return true;
+                }();
+                (void)oncez;
+                const dim3 gridz(gz_tiles_per_plane(hw), 1, planes);
+#define GZ_LAUNCH(L_, T_)                                                                                                \
+    hipLaunchKernelGGL((gram16z_kernel<L_, T_>), gridz, dim3(256), ldsz, st, w.vph, w.vpl, target, w.ssign, gloss, C, hw, \
+                       cm_tiled ? 1 : 0)
+                if (gloss) {
+                    if (tinit) GZ_LAUNCH(true, true); else GZ_LAUNCH(true, false);
+                } else {
+                    if (tinit) GZ_LAUNCH(false, true); else GZ_LAUNCH(false, false);
+                }
+#undef GZ_LAUNCH
+            } else {
+            const dim3 grid(gx_tiles_per_plane(hw), 1, planes);
+#define GY_LAUNCH(L_, T_)                                                                                              \
+    hipLaunchKernelGGL((gram16y_kernel<L_, T_>), grid, dim3(512), lds, st, w.vph, w.vpl, target, w.ssign, gloss, C, hw, \
+                       cm_tiled ? 1 : 0)
+            if (gloss) {
+                if (tinit) GY_LAUNCH(true, true); else GY_LAUNCH(true, false);
+            } else {
+                if (tinit) GY_LAUNCH(false, true); else GY_LAUNCH(false, false);
+            }
+#undef GY_LAUNCH
+            }
         } else if (small) {
             const int nt = hw / 64;
             // (the wave count is the split of the contraction, i.e. part of the arithmetic: chosen by the size of the WHOLE
             // problem, so that one CFG half alone, or a rank's frame shard, rounds exactly as the undivided batch does)
-            if (nt * nt * Bg < 128) {
+            const char* s8_env = getenv("FRESCO_GRAM_S8");  // (experiment switch: 8-way K split up to 16 x 16 planes)
+            const int s8_limit = (s8_env && s8_env[0] == '0') ? 128 : 512;
+            if (nt * nt * Bg < s8_limit) {
                 constexpr int lds = 8 * 64 * GS_RS * 4;
                 static const bool once = [] {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16s_kernel<8>),
@@ -1107,13 +1430,19 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         if (cm_tiled) {
             constexpr int lds128 = SB_NSLOT * (2 * 128 * SB_VROW + 256 * SB_SROW), lds64 = SB_NSLOT * (2 * 64 * SB_VROW + 256 * SB_SROW);
             static const bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<128>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<128, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<64>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<64, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds64);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<128, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<64, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds64);
                 return true;
             }();
             (void)once;
+            const char* dl_env = getenv("FRESCO_SV_DOTLDS");  // (experiment switch, read per call)
+            const bool dl = !(dl_env && dl_env[0] == '0');
             // whole tiles for the full rounds of the chip's 2 x 256 workgroup slots; the tiles of a last round that would
             // fill at most a quarter of the slots (or a launch smaller than one round) run as two half tiles each: measured
             // 116 -> 102 us at (1280, 32^2), 28 -> 21 us at (1280, 16^2); at (640, 64^2) -- 2.5 rounds -- the half-tile round
@@ -1125,12 +1454,16 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
             if (!tail_split || (rem > slots / 4 && tiles > slots)) rem = 0;
             if (tiles <= slots && tiles > slots / 2) rem = 0;  // (more than half a round of whole tiles: leave it)
             const int whole = tiles - rem;
-            if (whole > 0)
-                hipLaunchKernelGGL(sv16b_kernel<128>, dim3(whole), dim3(512), lds128, st, w.vh, w.vl, w.ssign, w.dvt, w.dotp, C,
-                                   hw, 2.f * coef, 0);
-            if (rem > 0)
-                hipLaunchKernelGGL(sv16b_kernel<64>, dim3(2 * rem), dim3(512), lds64, st, w.vh, w.vl, w.ssign, w.dvt, w.dotp, C,
-                                   hw, 2.f * coef, whole);
+#define SB_LAUNCH(CT_, DL_, GRID_, LDS_, BASE_)                                                                          \
+    hipLaunchKernelGGL((sv16b_kernel<CT_, DL_>), dim3(GRID_), dim3(512), LDS_, st, w.vh, w.vl, w.ssign, w.dvt, w.dotp, C, hw, \
+                       2.f * coef, BASE_)
+            if (whole > 0) {
+                if (dl) SB_LAUNCH(128, true, whole, lds128, 0); else SB_LAUNCH(128, false, whole, lds128, 0);
+            }
+            if (rem > 0) {
+                if (dl) SB_LAUNCH(64, true, 2 * rem, lds64, whole); else SB_LAUNCH(64, false, 2 * rem, lds64, whole);
+            }
+#undef SB_LAUNCH
         } else {
             launch_sv16_plain(w.vh, w.vl, w.ssign, w.dvt, w.dotp, planes, C, hw, 2.f * coef, st);
         }
