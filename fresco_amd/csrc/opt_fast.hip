@@ -413,7 +413,6 @@ __global__ __launch_bounds__(NW * 64) void gram16s_kernel(const half_t* __restri
 // above the diagonal are also written transposed to their mirror position; XCD-contiguous walk in 1024 x 1024 super-tiles.
 // ------------------------------------------------------------------------------------------------
 constexpr int GX_TRS = 128 + 16;       // staged sign tile: bytes per row
-constexpr int GX_TRS2 = 256 + 16;      // ... of the transposed tile
 
 static int gx_tiles_per_plane(int hw) {
     const int n128 = hw / 128, n256 = hw / 256;
@@ -460,6 +459,79 @@ __device__ __forceinline__ void gx_wait_barrier() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Epilogue of the 256 x 128 / 128 x 128 Gram kernels for one wave's 64 x 64 sub-tile (rows wm * 64 .., columns wn * 64 ..
+// of the workgroup tile): G - T -> sign bytes.
+//   * the targets of 32 x 32 block n + 1 are requested before block n is turned into signs (block 0: before the barrier
+//     that ends the K loop): the epilogue waits for about one memory round trip instead of four -- while a workgroup
+//     waits there its neighbour has the CU alone and cannot fill the matrix pipe (526 -> 512 us at (640, 64^2); two
+//     blocks ahead, or block 0 from inside the K loop, spill and lose: 585 / 548 us; accumulators that START at -T, so
+//     that the epilogue has no target loads at all: 467 against 461 us, and more near-tie signs off -- the partial sums
+//     then live at |T| for the whole K loop; profiles/r04_ab_opt_forms.txt);
+//   * sign bytes by arithmetic: med3(d * 2^126, -1, 1) -> cvt_pkrtz -> v_perm of the high bytes;
+//   * DIRECT position (rows p, 16 consecutive q per piece): the lane's bytes go to the LDS tile `tr` (rows of GX_TRS
+//     bytes), the caller stores it after a barrier;
+//   * MIRROR position (wgt == 2; rows q, consecutive p): a lane's dword already holds S[p .. p + 3][q]; one
+//     v_permlane32_swap per dword pair leaves lanes 0-31 with rows 0-15 and lanes 32-63 with rows 16-31 of the lane's
+//     column -- a 16-byte piece of mirror row q -- stored straight from registers: a wave instruction writes 32 rows x
+//     32 bytes = 1 KiB contiguous of the tiled layout.  (Before: a second LDS tile, two more barriers.)
+// Returns the lane's sum of |G - T| (LOSS).
+// ------------------------------------------------------------------------------------------------
+template <bool LOSS>
+__device__ __forceinline__ float gram_sign_epilogue(const floatx16 (&acc)[2][2], const float* __restrict__ tgt, int hw, int wgt,
+                                                     int8_t* __restrict__ tr, int wm, int wn, int l31, int hi,
+                                                     int8_t* __restrict__ sgn_out, int b, int p0, int q0, int s_tiled) {
+    float tnext[16];
+    auto load_targets = [&](int blk) __attribute__((always_inline)) {
+        const int i = blk >> 1, jj = blk & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            tnext[r] = wgt ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
+    };
+    load_targets(0);
+    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int cl = wn * 64 + jj * 32 + l31;
+            float tv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tv[r] = tnext[r];
+            if (i * 2 + jj < 3) load_targets(i * 2 + jj + 1);
+            uint32_t sg[4];  // this lane's 16 signs of the block, 4 per dword (rows e .. e + 3 of one column)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float s4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = acc[i][jj][r4 * 4 + e] - tv[r4 * 4 + e];
+                    if (LOSS) lsum += fabsf(d);
+                    s4[e] = __builtin_amdgcn_fmed3f(d * 0x1p126f, -1.f, 1.f);  // exactly -1, 0 or +1 for d = 0 and every normal d
+                }
+                const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[0], s4[1]));
+                const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[2], s4[3]));
+                const uint32_t wv4 = __builtin_amdgcn_perm(h23, h01, 0x07050301u);  // the four high bytes: 0x3C / 0xBC / 0x00
+                sg[r4] = wv4;
+                const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
+                tr[(rl + 0) * GX_TRS + cl] = (int8_t)(wv4 & 0xff);
+                tr[(rl + 1) * GX_TRS + cl] = (int8_t)((wv4 >> 8) & 0xff);
+                tr[(rl + 2) * GX_TRS + cl] = (int8_t)((wv4 >> 16) & 0xff);
+                tr[(rl + 3) * GX_TRS + cl] = (int8_t)(wv4 >> 24);
+            }
+            if (wgt == 2) {  // (wave-uniform)
+                // sg[r4] = rows 8 r4 + 4 hi .. + 3.  swap(a, b): lanes 0-31 get (own a, upper partner's a), lanes 32-63
+                // (lower partner's b, own b)
+                const auto P = __builtin_amdgcn_permlane32_swap(sg[0], sg[2], false, false);
+                const auto Q = __builtin_amdgcn_permlane32_swap(sg[1], sg[3], false, false);
+                const u32x4 piece = {(uint32_t)P[0], (uint32_t)P[1], (uint32_t)Q[0], (uint32_t)Q[1]};
+                s_store_piece(sgn_out, piece, b, q0 + cl, p0 + wm * 64 + i * 32 + hi * 16, hw, s_tiled);
+            }
+        }
+    return lsum;
+}
+
+// ------------------------------------------------------------------------------------------------
 // gram16y_kernel: 256 x 128 workgroup tiles, 8 waves as 4 x 2 with wave tiles 64 x 64 (per k16 step a wave reads 4 + 4
 // LDS fragments for 12 MFMAs; round 3's 128 x 128 / 64 x 32 form: 6 for 6), TWO workgroups per CU.  A first form with one
 // workgroup per CU (K chunks of 32 in a 3 x 48 KB ring, targets prefetched into 64 registers; removed, see git history)
@@ -480,7 +552,7 @@ constexpr int GY_BLK = 128 * 32;       // one (pixel tile, chunk) block of one a
 constexpr int GY_SLOT = 6 * GY_BLK;    // Ah0 Ah1 Al0 Al1 Bh Bl
 constexpr int GY_NS = 3;
 
-template <bool LOSS, bool TINIT>
+template <bool LOSS>
 __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
                                                          const float* __restrict__ target, int8_t* __restrict__ sgn_out,
                                                          float* __restrict__ loss, int C, int hw, int s_tiled) {
@@ -526,30 +598,13 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
 #undef GY_PIECE
     };
 
-    // TINIT: the accumulators START at -T, so the K loop ends with G - T and the epilogue has no target loads on its
-    // path (they were half of its time: profiles/r04_gram_ablation.txt).  The loads are the first memory operations of
-    // the workgroup -- older than the ring's DMA copies, so the counted vmcnt waits below cover them -- and their
-    // latency is paid once, beside the ring prologue, while the other workgroup of the CU multiplies.  The partial
-    // sums run from -T towards G - T (|.| <= |T|) instead of from 0 towards G: the same rounding class as the
-    // reference's bmm followed by a subtraction, not the same last bit.
-    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
     floatx16 acc[2][2];
-    if (TINIT && wgt) {  // (one branch around all 64 loads: a select per load becomes a branch per load)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[i][jj][r] = __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-    }
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
     // fragment offsets inside a slot: unit hi of row R sits at hi ^ ((R >> 3) & 1)
     const int u = (hi ^ ((l31 >> 3) & 1)) * 16;
@@ -561,14 +616,6 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
         gx_wait_barrier<3>();
     } else {
         gx_wait_barrier<0>();
-    }
-    if (TINIT) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] = -acc[i][jj][r];
     }
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
@@ -600,52 +647,10 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
         }
         slot = slot == GY_NS - 1 ? 0 : slot + 1;
     }
-    // ---- epilogue ----
-    // the targets of 32 x 32 block n + 1 are requested before block n is turned into signs (block 0: before the barrier
-    // below): the epilogue waits for about one memory round trip instead of four -- while a workgroup waits there its
-    // neighbour has the CU alone and cannot fill the matrix pipe (526 -> 512 us at (640, 64^2); two blocks ahead, or
-    // block 0 from inside the K loop, spill and lose: 585 / 548 us)
-    float tnext[16];
-    auto load_targets = [&](int blk) __attribute__((always_inline)) {
-        const int i = blk >> 1, jj = blk & 1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            tnext[r] = (!TINIT && wgt) ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
-    };
-    if (!TINIT) load_targets(0);
-    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
+    // ---- epilogue ---- (gram_sign_epilogue above)
+    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
     int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
-    float lsum = 0.f;
-    uint32_t sg[2][2][4];  // this lane's 64 signs, 4 per dword (rows e, e+1, e+2, e+3 of one column)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int cl = wn * 64 + jj * 32 + l31;
-            float tv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tv[r] = TINIT ? 0.f : tnext[r];
-            if (!TINIT && i * 2 + jj < 3) load_targets(i * 2 + jj + 1);
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                float s4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = TINIT ? acc[i][jj][r4 * 4 + e] : acc[i][jj][r4 * 4 + e] - tv[r4 * 4 + e];
-                    if (LOSS) lsum += fabsf(d);
-                    s4[e] = __builtin_amdgcn_fmed3f(d * 0x1p126f, -1.f, 1.f);  // exactly -1, 0 or +1 for d = 0 and every normal d
-                }
-                const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[0], s4[1]));
-                const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[2], s4[3]));
-                const uint32_t wv4 = __builtin_amdgcn_perm(h23, h01, 0x07050301u);  // the four high bytes: 0x3C / 0xBC / 0x00
-                sg[i][jj][r4] = wv4;
-                const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
-                tr[(rl + 0) * GX_TRS + cl] = (int8_t)(wv4 & 0xff);
-                tr[(rl + 1) * GX_TRS + cl] = (int8_t)((wv4 >> 8) & 0xff);
-                tr[(rl + 2) * GX_TRS + cl] = (int8_t)((wv4 >> 16) & 0xff);
-                tr[(rl + 3) * GX_TRS + cl] = (int8_t)(wv4 >> 24);
-            }
-        }
+    const float lsum = gram_sign_epilogue<LOSS>(acc, tgt, hw, wgt, tr, wm, wn, l31, hi, sgn_out, b, p0, q0, s_tiled);
     __syncthreads();
     for (int idx = tid; idx < 256 * 8; idx += 512) {
         const int rl = idx >> 3, ch = idx & 7;
@@ -654,30 +659,8 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
         const int gp = p0 + rl, gq = q0 + ch * 16;
         s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, gp, gq, hw, s_tiled);
     }
-    if (2 * ti < tj) {  // at least the upper half is above the diagonal: transposed copy
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int cl = wn * 64 + jj * 32 + l31;
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
-                    *reinterpret_cast<uint32_t*>(tr + cl * GX_TRS2 + rl) = sg[i][jj][r4];
-                }
-            }
-        __syncthreads();
-        for (int idx = tid; idx < 128 * 16; idx += 512) {
-            const int rl = idx >> 4, ch = idx & 15;
-            const int a = 2 * ti + (ch >> 3);
-            if (a >= tj) continue;
-            const int gp = q0 + rl, gq = p0 + ch * 16;
-            s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS2 + ch * 16), b, gp, gq, hw, s_tiled);
-        }
-    }
     if (LOSS) {
-        float* red = reinterpret_cast<float*>(gy_smem + 40960);  // behind both staging areas
+        float* red = reinterpret_cast<float*>(gy_smem + 40960);  // behind the staging area
         const float tot = wave_sum((float)wgt * lsum);
         __syncthreads();
         if (lane == 0) red[wave] = tot;
@@ -705,7 +688,7 @@ static int gz_tiles_per_plane(int hw) {
     return n * (n + 1) / 2;
 }
 
-template <bool LOSS, bool TINIT>
+template <bool LOSS>
 __global__ __launch_bounds__(256, 3) void gram16z_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
                                                          const float* __restrict__ target, int8_t* __restrict__ sgn_out,
                                                          float* __restrict__ loss, int C, int hw, int s_tiled) {
@@ -754,24 +737,13 @@ __global__ __launch_bounds__(256, 3) void gram16z_kernel(const half_t* __restric
 #undef GZ_PIECE
     };
 
-    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
     floatx16 acc[2][2];
-    if (TINIT) {  // the accumulators start at -T (see gram16y_kernel)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[i][jj][r] = __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-    }
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
     // fragment offsets inside a slot: unit hi of row R sits at hi ^ ((R >> 3) & 1)
     const int u = (hi ^ ((l31 >> 3) & 1)) * 16;
@@ -783,14 +755,6 @@ __global__ __launch_bounds__(256, 3) void gram16z_kernel(const half_t* __restric
         gx_wait_barrier<4>();
     } else {
         gx_wait_barrier<0>();
-    }
-    if (TINIT) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] = -acc[i][jj][r];
     }
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
@@ -820,75 +784,19 @@ __global__ __launch_bounds__(256, 3) void gram16z_kernel(const half_t* __restric
         }
         slot = slot == GZ_NS - 1 ? 0 : slot + 1;
     }
-    // ---- epilogue (as gram16y_kernel, 128 rows) ----
-    float tnext[16];
-    auto load_targets = [&](int blk) __attribute__((always_inline)) {
-        const int i = blk >> 1, jj = blk & 1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            tnext[r] = TINIT ? 0.f : __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32);
-    };
-    if (!TINIT) load_targets(0);
-    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
+    // ---- epilogue ---- (gram_sign_epilogue above)
+    const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
     int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
-    float lsum = 0.f;
-    uint32_t sg[2][2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int cl = wn * 64 + jj * 32 + l31;
-            float tv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tv[r] = TINIT ? 0.f : tnext[r];
-            if (!TINIT && i * 2 + jj < 3) load_targets(i * 2 + jj + 1);
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                float s4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = TINIT ? acc[i][jj][r4 * 4 + e] : acc[i][jj][r4 * 4 + e] - tv[r4 * 4 + e];
-                    if (LOSS) lsum += fabsf(d);
-                    s4[e] = __builtin_amdgcn_fmed3f(d * 0x1p126f, -1.f, 1.f);
-                }
-                const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[0], s4[1]));
-                const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[2], s4[3]));
-                const uint32_t wv4 = __builtin_amdgcn_perm(h23, h01, 0x07050301u);
-                sg[i][jj][r4] = wv4;
-                const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
-                tr[(rl + 0) * GX_TRS + cl] = (int8_t)(wv4 & 0xff);
-                tr[(rl + 1) * GX_TRS + cl] = (int8_t)((wv4 >> 8) & 0xff);
-                tr[(rl + 2) * GX_TRS + cl] = (int8_t)((wv4 >> 16) & 0xff);
-                tr[(rl + 3) * GX_TRS + cl] = (int8_t)(wv4 >> 24);
-            }
-        }
+    const int wgt = mirrored ? 2 : 1;
+    const float lsum = gram_sign_epilogue<LOSS>(acc, tgt, hw, wgt, tr, wm, wn, l31, hi, sgn_out, b, p0, q0, s_tiled);
     __syncthreads();
     for (int idx = tid; idx < 128 * 8; idx += 256) {
         const int rl = idx >> 3, ch = idx & 7;
         s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, p0 + rl, q0 + ch * 16, hw, s_tiled);
     }
-    if (mirrored) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int cl = wn * 64 + jj * 32 + l31;
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
-                    *reinterpret_cast<uint32_t*>(tr + cl * GX_TRS + rl) = sg[i][jj][r4];
-                }
-            }
-        __syncthreads();
-        for (int idx = tid; idx < 128 * 8; idx += 256) {
-            const int rl = idx >> 3, ch = idx & 7;
-            s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, q0 + rl, p0 + ch * 16, hw, s_tiled);
-        }
-    }
     if (LOSS) {
         float* red = reinterpret_cast<float*>(gy_smem + 40960);  // behind the staging area
-        const float tot = wave_sum((mirrored ? 2.f : 1.f) * lsum);
+        const float tot = wave_sum((float)wgt * lsum);
         __syncthreads();
         if (lane == 0) red[wave] = tot;
         __syncthreads();
@@ -1067,7 +975,7 @@ __device__ __forceinline__ void sb_wait_barrier() {
 // 2.5 rounds -- run as 2 rounds of whole tiles + 1 round of half tiles (0.6 of the time) instead of 3 whole rounds.
 // Tile t of the launch's list = (plane, pixel tile, channel tile), channel tile fastest (neighbours share their S rows).
 // <V, dV> partials: two slots per channel tile (a whole tile writes its sum and a zero, half tiles one each).
-template <int CT, bool DL>
+template <int CT>
 __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict__ vh, const half_t* __restrict__ vl,
                                                        const int8_t* __restrict__ sgn_in, float* __restrict__ dvt,
                                                        float* __restrict__ dotp, int C, int hw, float alpha, int tile_base) {
@@ -1177,16 +1085,14 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
         slot = slot == NS - 1 ? 0 : slot + 1;
     }
     // epilogue: dV^T, and (dotp) this workgroup's share of <V, dV> per pixel: the sum over its channels, V = Vh + Vl
-    // re-read from the tiled copies (L2-resident: this workgroup has just streamed them).
-    // DL (round 4): the V values come through LDS instead of 128 two-byte global gathers per lane (38 of the launch's
-    // 500 us at (640, 64^2)): the ring is free, every wave copies the rows of its own tile -- 32 channel rows x NJ pixel
-    // chunks x (hi, lo) = NJ x 4 KB, as linear 1 KiB LDS-DMA pieces of the tiled copies -- into a region of its own (no
-    // barrier: the wave that copies is the wave that reads), picks its values with ds_read_u16 through the same swizzle,
-    // and only then issues the dV stores (stores count in vmcnt: they must not sit in front of the copies).  Same
-    // products in the same order: bit-identical to the gather form.
+    // re-read from the tiled copies (L2-resident: this workgroup has just streamed them) THROUGH LDS: the ring is free,
+    // every wave copies the rows of its own tile -- 32 channel rows x NJ pixel chunks x (hi, lo) = NJ x 4 KB, as linear
+    // 1 KiB LDS-DMA pieces -- into a region of its own (no barrier: the wave that copies is the wave that reads), picks
+    // its values with ds_read_u16 through the same swizzle, and only then issues the dV stores (stores count in vmcnt:
+    // they must not sit in front of the copies).  Before: 128 two-byte global gathers per lane -- 496 -> 469 us at
+    // (640, 64^2), 99 -> 85 at (1280, 32^2), 24 -> 17 at (1280, 16^2); same products in the same order, same bits
+    // (profiles/r04_ab_opt_forms.txt).
     float dsum[NJ];
-    const half_t* vht = reinterpret_cast<const half_t*>(vhb);
-    const half_t* vlt = reinterpret_cast<const half_t*>(vlb);
 #pragma unroll
     for (int ni = 0; ni < NJ; ++ni) dsum[ni] = 0.f;
 #pragma unroll
@@ -1195,7 +1101,7 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
         for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= alpha;  // (in place: both phases below read the scaled value)
-    if (DL && dotp) {
+    if (dotp) {
         __syncthreads();  // the ring is free
         const uint32_t mybase = lds0 + (uint32_t)(wave * (NJ * 4096));
         const char* myrd = sb_smem + wave * (NJ * 4096);
@@ -1235,16 +1141,10 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
 #pragma unroll
         for (int ni = 0; ni < NJ; ++ni) {
             const int col = p0 + wn * (32 * NJ) + ni * 32 + l31;
-            const int vt0 = (col >> 5) * (128 * 32) + (l31 & 7);  // tiled V: [pixel chunk of 32][128 channels][4 swizzled units of 8 pixels]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = hf * 64 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // row inside the 128-channel tile
-                const float val = acc[mi][ni][r];
-                dvt[((int64_t)b * C + c0 + rl) * hw + col] = val;
-                if (!DL && dotp) {
-                    const int vi = vt0 + rl * 32 + ((((l31 >> 3) ^ (rl >> 2)) & 3) << 3);
-                    dsum[ni] = fmaf(val, (float)vht[vi] + (float)vlt[vi], dsum[ni]);
-                }
+                dvt[((int64_t)b * C + c0 + rl) * hw + col] = acc[mi][ni][r];
             }
         }
     if (dotp) {
@@ -1337,68 +1237,51 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     {
         ProfScope ps(FRESCO_PROF_OPT_GRAM, planes, C, hw, 0, st);
         if (big) {
-            constexpr int lds = GY_NS * GY_SLOT;
-            static const bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<false, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<true, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<false, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                return true;
-            }();
-            (void)once;
-            const char* ti_env = getenv("FRESCO_GRAM_TINIT");  // (experiment switch, read per call)
-            const bool tinit = !(ti_env && ti_env[0] == '0');
             // launches whose 256 x 128 tiles would not fill the 512 workgroup slots twice take the 128 x 128 form (three
-            // workgroups per CU; same bits): FRESCO_GRAM_Z=0 keeps the 256-row form
-            const char* z_env = getenv("FRESCO_GRAM_Z");
+            // workgroups per CU; same bits): (1280, 32^2) 95 -> 83 us.  FRESCO_GRAM_Z=0 keeps the 256-row form (tests)
+            const char* z_env = getenv("FRESCO_GRAM_Z");  // (read per call)
             const bool zform = !(z_env && z_env[0] == '0') && gx_tiles_per_plane(hw) * Bg < 1024;
             if (zform) {
                 constexpr int ldsz = GZ_NS * GZ_SLOT;
                 static const bool oncez = [] {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<false, false>),
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsz);
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<true, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsz);
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<false, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsz);
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<true, true>),
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16z_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsz);
                     return true;
                 }();
                 (void)oncez;
                 const dim3 gridz(gz_tiles_per_plane(hw), 1, planes);
-#define GZ_LAUNCH(L_, T_)                                                                                                \
-    hipLaunchKernelGGL((gram16z_kernel<L_, T_>), gridz, dim3(256), ldsz, st, w.vph, w.vpl, target, w.ssign, gloss, C, hw, \
-                       cm_tiled ? 1 : 0)
-                if (gloss) {
-                    if (tinit) GZ_LAUNCH(true, true); else GZ_LAUNCH(true, false);
-                } else {
-                    if (tinit) GZ_LAUNCH(false, true); else GZ_LAUNCH(false, false);
-                }
-#undef GZ_LAUNCH
+                if (gloss)
+                    hipLaunchKernelGGL(gram16z_kernel<true>, gridz, dim3(256), ldsz, st, w.vph, w.vpl, target, w.ssign, gloss, C,
+                                       hw, cm_tiled ? 1 : 0);
+                else
+                    hipLaunchKernelGGL(gram16z_kernel<false>, gridz, dim3(256), ldsz, st, w.vph, w.vpl, target, w.ssign, gloss, C,
+                                       hw, cm_tiled ? 1 : 0);
             } else {
-            const dim3 grid(gx_tiles_per_plane(hw), 1, planes);
-#define GY_LAUNCH(L_, T_)                                                                                              \
-    hipLaunchKernelGGL((gram16y_kernel<L_, T_>), grid, dim3(512), lds, st, w.vph, w.vpl, target, w.ssign, gloss, C, hw, \
-                       cm_tiled ? 1 : 0)
-            if (gloss) {
-                if (tinit) GY_LAUNCH(true, true); else GY_LAUNCH(true, false);
-            } else {
-                if (tinit) GY_LAUNCH(false, true); else GY_LAUNCH(false, false);
-            }
-#undef GY_LAUNCH
+                constexpr int lds = GY_NS * GY_SLOT;
+                static const bool once = [] {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16y_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    return true;
+                }();
+                (void)once;
+                const dim3 grid(gx_tiles_per_plane(hw), 1, planes);
+                if (gloss)
+                    hipLaunchKernelGGL(gram16y_kernel<true>, grid, dim3(512), lds, st, w.vph, w.vpl, target, w.ssign, gloss, C,
+                                       hw, cm_tiled ? 1 : 0);
+                else
+                    hipLaunchKernelGGL(gram16y_kernel<false>, grid, dim3(512), lds, st, w.vph, w.vpl, target, w.ssign, gloss, C,
+                                       hw, cm_tiled ? 1 : 0);
             }
         } else if (small) {
             const int nt = hw / 64;
             // (the wave count is the split of the contraction, i.e. part of the arithmetic: chosen by the size of the WHOLE
             // problem, so that one CFG half alone, or a rank's frame shard, rounds exactly as the undivided batch does)
-            const char* s8_env = getenv("FRESCO_GRAM_S8");  // (experiment switch: 8-way K split up to 16 x 16 planes)
-            const int s8_limit = (s8_env && s8_env[0] == '0') ? 128 : 512;
-            if (nt * nt * Bg < s8_limit) {
+            // 8 waves (an 8-way split of K) up to 16 x 16 planes at batch 16: the launch is a latency chain of K steps
+            if (nt * nt * Bg < 512) {
                 constexpr int lds = 8 * 64 * GS_RS * 4;
                 static const bool once = [] {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16s_kernel<8>),
@@ -1430,19 +1313,13 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         if (cm_tiled) {
             constexpr int lds128 = SB_NSLOT * (2 * 128 * SB_VROW + 256 * SB_SROW), lds64 = SB_NSLOT * (2 * 64 * SB_VROW + 256 * SB_SROW);
             static const bool once = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<128, false>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<128>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<64, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds64);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<128, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<64, true>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sv16b_kernel<64>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds64);
                 return true;
             }();
             (void)once;
-            const char* dl_env = getenv("FRESCO_SV_DOTLDS");  // (experiment switch, read per call)
-            const bool dl = !(dl_env && dl_env[0] == '0');
             // whole tiles for the full rounds of the chip's 2 x 256 workgroup slots; the tiles of a last round that would
             // fill at most a quarter of the slots (or a launch smaller than one round) run as two half tiles each: measured
             // 116 -> 102 us at (1280, 32^2), 28 -> 21 us at (1280, 16^2); at (640, 64^2) -- 2.5 rounds -- the half-tile round
@@ -1454,16 +1331,12 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
             if (!tail_split || (rem > slots / 4 && tiles > slots)) rem = 0;
             if (tiles <= slots && tiles > slots / 2) rem = 0;  // (more than half a round of whole tiles: leave it)
             const int whole = tiles - rem;
-#define SB_LAUNCH(CT_, DL_, GRID_, LDS_, BASE_)                                                                          \
-    hipLaunchKernelGGL((sv16b_kernel<CT_, DL_>), dim3(GRID_), dim3(512), LDS_, st, w.vh, w.vl, w.ssign, w.dvt, w.dotp, C, hw, \
-                       2.f * coef, BASE_)
-            if (whole > 0) {
-                if (dl) SB_LAUNCH(128, true, whole, lds128, 0); else SB_LAUNCH(128, false, whole, lds128, 0);
-            }
-            if (rem > 0) {
-                if (dl) SB_LAUNCH(64, true, 2 * rem, lds64, whole); else SB_LAUNCH(64, false, 2 * rem, lds64, whole);
-            }
-#undef SB_LAUNCH
+            if (whole > 0)
+                hipLaunchKernelGGL(sv16b_kernel<128>, dim3(whole), dim3(512), lds128, st, w.vh, w.vl, w.ssign, w.dvt, w.dotp, C,
+                                   hw, 2.f * coef, 0);
+            if (rem > 0)
+                hipLaunchKernelGGL(sv16b_kernel<64>, dim3(2 * rem), dim3(512), lds64, st, w.vh, w.vl, w.ssign, w.dvt, w.dotp, C,
+                                   hw, 2.f * coef, whole);
         } else {
             launch_sv16_plain(w.vh, w.vl, w.ssign, w.dvt, w.dotp, planes, C, hw, 2.f * coef, st);
         }

@@ -231,9 +231,7 @@ def test_opt_20_iterations_final_loss_at_the_big_shapes(C, h, monkeypatch):
     # ... and the launch form must not matter: one stream (FRESCO_OPT_SPLIT=0), two pipelines started half an iteration
     # apart (2), whole S V tiles only (FRESCO_OPT_SVTAIL=0: these shapes run a half-tile tail round in one form or the other)
     # nor the Gram tile shape (FRESCO_GRAM_Z=0: 256 x 128 tiles also at 32 x 32, where the default is gram16z's 128 x 128)
-    # or the path of the <V, dV> operands (FRESCO_SV_DOTLDS=0: gathered from L2 instead of copied through LDS)
-    for var, val in (("FRESCO_OPT_SPLIT", "0"), ("FRESCO_OPT_SPLIT", "2"), ("FRESCO_OPT_SVTAIL", "0"), ("FRESCO_GRAM_Z", "0"),
-                     ("FRESCO_SV_DOTLDS", "0")):
+    for var, val in (("FRESCO_OPT_SPLIT", "0"), ("FRESCO_OPT_SPLIT", "2"), ("FRESCO_OPT_SVTAIL", "0"), ("FRESCO_GRAM_Z", "0")):
         monkeypatch.setenv(var, val)
         cs3 = x.to(DEV).clone()
         ops.opt_run(cs3, prep, td, 100.0, 20, 2)

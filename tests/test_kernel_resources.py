@@ -57,6 +57,9 @@ def test_gram_and_sv_kernels_fit_four_waves_per_simd(tmp_path):
     for pat in (r"gram16y_kernelILb0E", r"gram16y_kernelILb1E", r"sv16b_kernelILi128E", r"sv16b_kernelILi64E"):
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 128 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+    for pat in (r"gram16z_kernelILb0E", r"gram16z_kernelILb1E"):  # launch_bounds(256, 3): three 4-wave workgroups per CU
+        r = _one(k, pat)
+        assert r["vgpr"] + r["agpr"] <= 168 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
     for pat in (r"opt_prep_kernel", r"opt_adam_kernel"):  # HBM-bound: at least three waves per SIMD, nothing in scratch
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 168 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)

@@ -7,8 +7,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench_opt
 
-SWITCHES = ("FRESCO_GRAM_TINIT", "FRESCO_SV_DOTLDS", "FRESCO_GRAM_Z", "FRESCO_GRAM_S8")
-CONFIGS = [("default", {})] + [(k + "=0", {k: "0"}) for k in SWITCHES] + [("all=0", {k: "0" for k in SWITCHES})]
+SWITCHES = tuple(os.environ.get("AB_SWITCHES", "FRESCO_GRAM_Z").split(","))  # the library reads them per call
+SWITCHES = tuple(k for k in SWITCHES if k != "NONE")
+CONFIGS = [("default", {})] + [(k + "=0", {k: "0"}) for k in SWITCHES] + ([("all=0", {k: "0" for k in SWITCHES})] if len(SWITCHES) > 1 else [])
 
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2

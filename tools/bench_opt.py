@@ -86,11 +86,19 @@ def measure(iters=20, N=8, R=512, dev="cuda", verbose=False, baselines=True, rep
             if k in agg:
                 t = sum(agg[k]) / len(agg[k]) * 1e-3
                 # fp16-split forms: gram = 3 products (hi.hi + hi.lo + lo.hi) over the tiles it computes (256 x 128 tiles with
-                # tj >= 2 ti: the upper triangle + one 128 x 128 block per 256 rows; ALL tiles for planes <= 256 pixels),
+                # tj >= 2 ti: the upper triangle + one 128 x 128 block per 256 rows; 128 x 128 tiles with tj >= ti for launches that
+                # take gram16z; ALL tiles for planes <= 256 pixels),
                 # sv = 2 products (S exact)
                 if k == "gram":
                     n128, n256 = hw // 128, hw // 256
-                    execd = one * 3.0 * ((n256 * n128 - n256 * (n256 - 1)) * 2.0 / (n128 * n128) if hw >= 512 else 1.0)
+                    tiles_y = n256 * n128 - n256 * (n256 - 1)
+                    if hw < 512:
+                        share = 1.0
+                    elif tiles_y * 2 * N < 1024 and os.environ.get("FRESCO_GRAM_Z", "1") != "0":
+                        share = (n128 * (n128 + 1) / 2.0) / (n128 * n128)  # gram16z: 128 x 128 tiles (ti, tj >= ti), all of each
+                    else:
+                        share = tiles_y * 2.0 / (n128 * n128)              # gram16y: 256 x 128 tiles with tj >= 2 ti
+                    execd = one * 3.0 * share
                 else:
                     execd = one * 2.0
                 kl[k + "_roofline"] = dict(bound="mfma", algorithmic_tflops=round(one / t / 1e12, 1),
