@@ -18,7 +18,7 @@ if __name__ == "__main__":
             for k in SWITCHES:
                 os.environ.pop(k, None)
             os.environ.update(env)
-            r = bench_opt.measure(20, verbose=False, baselines=False)
+            r = bench_opt.measure(int(os.environ.get("AB_ITERS", "20")), verbose=False, baselines=False)
             kern = {L: {k: v for k, v in d.items() if not k.endswith("_roofline")} for L, d in r["kernel_avg_us"].items()}
             print("round %d %-22s cfg3 %.2f ms  layers %s  kernels %s" % (rnd, name, r["ms_per_step"], r["per_layer_ms"],
                                                                         json.dumps(kern)), flush=True)
