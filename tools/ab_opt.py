@@ -11,6 +11,13 @@ SWITCHES = tuple(os.environ.get("AB_SWITCHES", "FRESCO_GRAM_Z").split(","))  # t
 SWITCHES = tuple(k for k in SWITCHES if k != "NONE")
 CONFIGS = [("default", {})] + [(k + "=0", {k: "0"}) for k in SWITCHES] + ([("all=0", {k: "0" for k in SWITCHES})] if len(SWITCHES) > 1 else [])
 
+if os.environ.get("AB_CONFIGS"):  # "name:K=V,K=V;name2:K=V": explicit configurations beside the default
+    CONFIGS = [("default", {})]
+    for item in os.environ["AB_CONFIGS"].split(";"):
+        name, kv = item.split(":")
+        CONFIGS.append((name, dict(x.split("=") for x in kv.split(","))))
+    SWITCHES = tuple(sorted({k for _, e in CONFIGS for k in e}))
+
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     for rnd in range(rounds):
