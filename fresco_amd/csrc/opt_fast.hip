@@ -226,6 +226,14 @@ struct AdamKArgs {
     AdamArgs a;
 };
 
+// NT: m, v and dV -- read once and (m, v) written once per iteration -- carry the non-temporal hint on planes too big for
+// the caches (>= 64 MB of features: 32 x 32 and 64 x 64): they stop evicting x and the sign words, which the same
+// launch and the next prep re-read, and this instantiation fits 128 registers = four waves per SIMD (adam 295 -> 254 us
+// and the following prep 186 -> 180 at (640, 64^2), 160 -> 145 / 92 -> 84 at (1280, 32^2)); on the 8 x 8 / 16 x 16 planes
+// everything is cache-resident and the hint costs 3 us per launch.  The same hint on prep's copy / sign stores: slower
+// everywhere (163 -> 173, 36 -> 64 at 16 x 16); on the dV stores of the S V kernel: -8 us of the Adam launch at 32 x 32, +4
+// at 16 x 16, nothing at 64 x 64: neither kept.
+template <bool NT>
 __global__ __launch_bounds__(256) void opt_adam_kernel(AdamKArgs k) {
     const int hw = k.hw, C = k.C, C8 = C >> 3;
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -250,10 +258,11 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(AdamKArgs k) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             x[q] = k.cs[o0 + (int64_t)q * hw];
-            dv[q] = k.has_s ? k.dvt[o0 + (int64_t)q * hw] : 0.f;
+            const int64_t oq = o0 + (int64_t)q * hw;
+            dv[q] = !k.has_s ? 0.f : (NT ? __builtin_nontemporal_load(k.dvt + oq) : k.dvt[oq]);
             if (k.mode == 0) {
-                mo[q] = k.m[o0 + (int64_t)q * hw];
-                vo[q] = k.v2[o0 + (int64_t)q * hw];
+                mo[q] = NT ? __builtin_nontemporal_load(k.m + oq) : k.m[oq];
+                vo[q] = NT ? __builtin_nontemporal_load(k.v2 + oq) : k.v2[oq];
             }
         }
 #pragma unroll
@@ -265,8 +274,13 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(AdamKArgs k) {
             } else {
                 const float mm = a.beta1 * mo[q] + (1.f - a.beta1) * g;
                 const float vv = a.beta2 * vo[q] + (1.f - a.beta2) * g * g;
-                k.m[o0 + (int64_t)q * hw] = mm;
-                k.v2[o0 + (int64_t)q * hw] = vv;
+                if (NT) {
+                    __builtin_nontemporal_store(mm, k.m + o0 + (int64_t)q * hw);
+                    __builtin_nontemporal_store(vv, k.v2 + o0 + (int64_t)q * hw);
+                } else {
+                    k.m[o0 + (int64_t)q * hw] = mm;
+                    k.v2[o0 + (int64_t)q * hw] = vv;
+                }
                 const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
                 const float xn = x[q] - a.step_size * (mm / denom);
                 k.cs[o0 + (int64_t)q * hw] = xn;
@@ -1380,7 +1394,10 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         ka.has_s = 1;
         ka.mode = mode;
         ka.a = a;
-        hipLaunchKernelGGL(opt_adam_kernel, dim3(hw / 64, NPB, planes), dim3(256), 0, st, ka);
+        if ((int64_t)Bg * C * hw >= (int64_t)16 << 20)  // (the WHOLE batch decides, not this launch's share of it)
+            hipLaunchKernelGGL(opt_adam_kernel<true>, dim3(hw / 64, NPB, planes), dim3(256), 0, st, ka);
+        else
+            hipLaunchKernelGGL(opt_adam_kernel<false>, dim3(hw / 64, NPB, planes), dim3(256), 0, st, ka);
     }
 }
 

@@ -60,7 +60,7 @@ def test_gram_and_sv_kernels_fit_four_waves_per_simd(tmp_path):
     for pat in (r"gram16z_kernelILb0E", r"gram16z_kernelILb1E"):  # launch_bounds(256, 3): three 4-wave workgroups per CU
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 168 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
-    for pat in (r"opt_prep_kernel", r"opt_adam_kernel"):  # HBM-bound: at least three waves per SIMD, nothing in scratch
+    for pat in (r"opt_prep_kernel", r"opt_adam_kernelILb0E", r"opt_adam_kernelILb1E"):  # HBM-bound: at least three waves per SIMD, nothing in scratch
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 168 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
     r = _one(_listing("opt.hip", tmp_path), r"adam_update_kernel")
