@@ -63,6 +63,8 @@ def test_gram_and_sv_kernels_fit_four_waves_per_simd(tmp_path):
     for pat in (r"opt_prep_kernel", r"opt_adam_kernelILb0E", r"opt_adam_kernelILb1E"):  # HBM-bound: at least three waves per SIMD, nothing in scratch
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 168 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+    r = _one(k, r"opt_adam_kernelILb1E")  # the big-plane instantiation (non-temporal m / v / dV): four waves per SIMD
+    assert r["vgpr"] + r["agpr"] <= 128, r
     r = _one(_listing("opt.hip", tmp_path), r"adam_update_kernel")
     assert r["spill"] == 0 and r["scratch"] == 0, r
 
