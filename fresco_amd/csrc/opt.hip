@@ -1060,7 +1060,7 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
         } release{split ? sd : nullptr};
         if (split && !side_stream_ready(*sd)) split = 0;
         if (!split) {
-            opt_fast_begin(ws, cs, chunk * N, C, hw, st);
+            opt_fast_begin(ws, cs, chunk * N, C, hw, chunk * N, st);
             for (int it = 1; it <= iters; ++it)
                 opt_fast_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, C, h, w, intra_weight,
                                  has_t, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N);
@@ -1070,7 +1070,7 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
             const float* tg1 = target + (size_t)N * hw * hw;
             (void)hipEventRecord(sd->fork, st);  // (memsets + CSR are behind this)
             (void)hipStreamWaitEvent(sd->s, sd->fork, 0);
-            opt_fast_begin(ws, cs, N, C, hw, st);
+            opt_fast_begin(ws, cs, N, C, hw, chunk * N, st);
             if (split == 4) {
                 // host issue order: front0(1) front1(1) | back0(1) front0(2) | back1(1) front1(2) | back0(2) front0(3) | ...
                 auto issue = [&](int half, int it, int parts) {
@@ -1093,7 +1093,7 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
                         opt_fast_closure(w1, cs1, fwd_flow, bwd_flow, fwd_occ, bwd_occ, tg1, 1, C, h, w, intra_weight, has_t, 0,
                                          nullptr, nullptr, a, sd->s, L, chunk * N, &y);
                 };
-                opt_fast_begin(w1, cs1, N, C, hw, sd->s);
+                opt_fast_begin(w1, cs1, N, C, hw, chunk * N, sd->s);
                 issue(0, 1, 1);
                 issue(1, 1, 1);
                 for (int it = 1; it <= iters; ++it) {
@@ -1117,7 +1117,7 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
                 opt_fast_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, 1, C, h, w, intra_weight, has_t, 0,
                                  nullptr, nullptr, a, st, L, chunk * N, &y0);
                 if (it == 1 && split == 2) (void)hipStreamWaitEvent(sd->s, sd->mid, 0);  // (recorded by the call above)
-                if (it == 1) opt_fast_begin(w1, cs1, N, C, hw, sd->s);
+                if (it == 1) opt_fast_begin(w1, cs1, N, C, hw, chunk * N, sd->s);
                 opt_fast_closure(w1, cs1, fwd_flow, bwd_flow, fwd_occ, bwd_occ, tg1, 1, C, h, w, intra_weight, has_t, 0,
                                  nullptr, nullptr, a, sd->s, L, chunk * N, &y1);
             }
@@ -1150,7 +1150,7 @@ extern "C" int fresco_opt_loss_grad(const float* cs, const float* fwd_flow, cons
     AdamArgs a = {0.f, 0.f, 0.f, 1.f, 0.f};
     const TLayout L = {N, N, 1, nullptr, nullptr};
     if (opt_fast_ok(C, h, w, has_s)) {
-        opt_fast_begin(ws, cs, chunk * N, C, h * w, st);
+        opt_fast_begin(ws, cs, chunk * N, C, h * w, chunk * N, st);
         opt_fast_closure(ws, const_cast<float*>(cs), fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, C, h, w,
                          intra_weight, has_t, 1, grad, loss, a, st, L, chunk * N);
     } else
@@ -1214,7 +1214,7 @@ extern "C" int fresco_opt_sharded_step(float* cs, const float* halo_l, const flo
     opt_ws_layout(&ws, static_cast<char*>(workspace), chunk, n_loc, C, h, w, has_t, has_s, n_loc + 1);
     const TLayout L = {n_loc, n_loc + 1, 0, halo_l, halo_r};
     if (opt_fast_ok(C, h, w, has_s)) {
-        if (it == 1) opt_fast_begin(ws, cs, chunk * n_loc, C, h * w, st);
+        if (it == 1) opt_fast_begin(ws, cs, chunk * n_loc, C, h * w, chunk * N_total, st);
         opt_fast_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, C, h, w, intra_weight, has_t, 0,
                          nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N_total);
     } else

@@ -34,18 +34,23 @@ bool opt_fast_ok(int C, int h, int w, int has_s) {
 }
 
 // Work split of prep / adam: a thread owns K channel octets of one pixel, a 256-thread block 64 pixels x 4 such slices.
-// NPART = slices per pixel, NPB = blocks per pixel = partial sums of squares per pixel (one per block, <= FAST_MAX_PART).
-// K = 5 on the big planes (taps / CSR rows are set up once per thread), fewer on planes too small to fill the chip
-// otherwise (8 x 8, 16 x 16: the launch is a latency chain of K dependent octet rounds).
-static void fast_slices(int C, int planes, int hw, int* K, int* NPART, int* NPB) {
+// NPART = slices per pixel, NPB = blocks per pixel.  The ADAM split also fixes the partial sums of squares (one per Adam
+// block, <= FAST_MAX_PART per pixel) that the next prep adds up, i.e. it is part of the arithmetic: it follows the WHOLE
+// batch (Bg planes), not the launch's share of it, so that a CFG half on its own stream, or a rank's frame shard, rounds
+// exactly as the undivided batch does.  K: few octets on planes too small to fill the chip otherwise (8 x 8, 16 x 16:
+// the launch is a latency chain of K dependent octet rounds); on the big planes 5 for prep and 10 for adam (taps / CSR
+// rows are set up once per thread; adam at K = 3 / 4 / 5 / 8 / 10: 282 / 280 / 269 / 286 / 261 us at (640, 64^2), 164 / 156 /
+// 149 / 164 / 139 at (1280, 32^2); prep is flat between 4 and 10).
+static void fast_slices(int C, int Bg, int hw, int cap, int* K, int* NPART, int* NPB) {
     const int C8 = C / 8;
-    int64_t k = (int64_t)planes * hw * C8 / 262144;
-    k = k < 1 ? 1 : (k > 5 ? 5 : k);
+    int64_t k = (int64_t)Bg * hw * C8 / 262144;
+    k = k < 1 ? 1 : (k > cap ? cap : k);
     while (((C8 + k - 1) / k + 3) / 4 > FAST_MAX_PART) ++k;
     *K = (int)k;
     *NPART = (int)((C8 + k - 1) / k);
     *NPB = (*NPART + 3) / 4;
 }
+constexpr int PREP_K = 5, ADAM_K = 10;
 
 // sum over the 4 slices of a block, in slice order; valid in the threads of slice 0
 __device__ __forceinline__ float slice_sum_4(float v, int px, int sl, float (*red)[64]) {
@@ -1207,9 +1212,9 @@ void launch_sv16_plain(const half_t* vh, const half_t* vl, const int8_t* ssign, 
                        hw, alpha);
 }
 
-void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, hipStream_t st) {
+void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, int Bg, hipStream_t st) {
     int K, NPART, NPB;
-    fast_slices(C, planes, hw, &K, &NPART, &NPB);
+    fast_slices(C, Bg, hw, ADAM_K, &K, &NPART, &NPB);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(hw / 64, NPB, planes), dim3(256), 0, st, cs, w.part, C, hw, K, NPART);
 }
 
@@ -1221,8 +1226,9 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     TLayout L = Lin;
     if (!has_t) L = TLayout{Lin.n_loc, Lin.n_loc, 1, nullptr, nullptr};
     const int planes = nck * L.n_loc;
-    int K, NPART, NPB;
-    fast_slices(C, planes, hw, &K, &NPART, &NPB);
+    int K, NPART, NPB, Kp, NPARTp, NPBp;
+    fast_slices(C, Bg, hw, ADAM_K, &K, &NPART, &NPB);       // adam (and the partial sums of squares it leaves behind)
+    fast_slices(C, Bg, hw, PREP_K, &Kp, &NPARTp, &NPBp);    // prep
     const int NCT = (C + 127) / 128;  // channel tiles of the S V kernels
     const bool cm_tiled = sv_tiled_layout(hw, C);
     const bool small = hw <= 256 && C % 32 == 0;
@@ -1251,14 +1257,14 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         pa.C = C;
         pa.h = h;
         pa.w = wd;
-        pa.K = K;
-        pa.NPART = NPART;
-        pa.NPB = NPB;
+        pa.K = Kp;
+        pa.NPART = NPARTp;
+        pa.NPB = NPB;  // (the partial sums of squares it adds: adam's blocks)
         pa.has_t = has_t;
         pa.pm_tiled = big ? 1 : 0;
         pa.cm_tiled = cm_tiled ? 1 : 0;
         const int nz = nck * (has_t ? L.n_pairs : L.n_loc);
-        hipLaunchKernelGGL(opt_prep_kernel, dim3(hw / 64, NPB, nz), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(opt_prep_kernel, dim3(hw / 64, NPBp, nz), dim3(256), 0, st, pa);
     }
     float* gloss = loss ? loss + 1 : nullptr;
     if (sync && sync->wait_before_gram) (void)hipStreamWaitEvent(st, sync->wait_before_gram, 0);

@@ -197,8 +197,9 @@ struct OptWs {
 // opt_fast.hip: the pipeline the SD-1.5 shapes run (hw % 64 == 0, C % 8 == 0, a Gram target): per Adam iteration
 // prep -> gram -> S V -> adam, four launches.
 bool opt_fast_ok(int C, int h, int w, int has_s);
-// partial sums of squares of the initial features (the later ones come out of the Adam kernel); once per call
-void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, hipStream_t st);
+// partial sums of squares of the initial features (the later ones come out of the Adam kernel); once per call.
+// Bg = planes of the WHOLE batch (fixes the work split, i.e. the order of the partial sums)
+void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, int Bg, hipStream_t st);
 // one closure evaluation on `nck` CFG halves starting at the pointers given (w, cs, target already offset to the first
 // half); mode 0 = Adam step, mode 1 = write the gradient to gout.  Bg = global batch (normalises both loss terms);
 // sync (optional): events that order this pipeline against a second one on another stream
