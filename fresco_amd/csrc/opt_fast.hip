@@ -38,9 +38,11 @@ bool opt_fast_ok(int C, int h, int w, int has_s) {
 // block, <= FAST_MAX_PART per pixel) that the next prep adds up, i.e. it is part of the arithmetic: it follows the WHOLE
 // batch (Bg planes), not the launch's share of it, so that a CFG half on its own stream, or a rank's frame shard, rounds
 // exactly as the undivided batch does.  K: few octets on planes too small to fill the chip otherwise (8 x 8, 16 x 16:
-// the launch is a latency chain of K dependent octet rounds); on the big planes 5 for prep and 10 for adam (taps / CSR
-// rows are set up once per thread; adam at K = 3 / 4 / 5 / 8 / 10: 282 / 280 / 269 / 286 / 261 us at (640, 64^2), 164 / 156 /
-// 149 / 164 / 139 at (1280, 32^2); prep is flat between 4 and 10).
+// the launch is a latency chain of K dependent octet rounds); 5 on the big planes (taps / CSR rows are set up once per
+// thread).  Measured: adam alone at K = 3 / 4 / 5 / 8 / 10: 282 / 280 / 269 / 286 / 261 us at (640, 64^2), 164 / 156 / 149 /
+// 164 / 139 at (1280, 32^2), prep flat between 4 and 10 -- but with the two CFG halves on two streams (the shipping
+// form) K = 10 for adam makes the layer SLOWER (29.2 -> 29.5 ms: fewer, longer blocks beside the other half's
+// launches), so both keep 5.
 static void fast_slices(int C, int Bg, int hw, int cap, int* K, int* NPART, int* NPB) {
     const int C8 = C / 8;
     int64_t k = (int64_t)Bg * hw * C8 / 262144;
@@ -50,7 +52,7 @@ static void fast_slices(int C, int Bg, int hw, int cap, int* K, int* NPART, int*
     *NPART = (int)((C8 + k - 1) / k);
     *NPB = (*NPART + 3) / 4;
 }
-constexpr int PREP_K = 5, ADAM_K = 10;
+constexpr int PREP_K = 5, ADAM_K = 5;
 
 // sum over the 4 slices of a block, in slice order; valid in the threads of slice 0
 __device__ __forceinline__ float slice_sum_4(float v, int px, int sl, float (*red)[64]) {
