@@ -447,7 +447,6 @@ __global__ __launch_bounds__(NW * 64) void gram16s_kernel(const half_t* __restri
 // BELOW the diagonal (only when tj == 2 ti) is the mirror image of its neighbour's upper half and is not written; halves
 // above the diagonal are also written transposed to their mirror position; XCD-contiguous walk in 1024 x 1024 super-tiles.
 // ------------------------------------------------------------------------------------------------
-constexpr int GX_TRS = 128 + 16;       // staged sign tile: bytes per row
 
 static int gx_tiles_per_plane(int hw) {
     const int n128 = hw / 128, n256 = hw / 256;
@@ -495,46 +494,70 @@ __device__ __forceinline__ void gx_wait_barrier() {
 
 // ------------------------------------------------------------------------------------------------
 // Epilogue of the 256 x 128 / 128 x 128 Gram kernels for one wave's 64 x 64 sub-tile (rows wm * 64 .., columns wn * 64 ..
-// of the workgroup tile): G - T -> sign bytes.
-//   * the targets of 32 x 32 block n + 1 are requested before block n is turned into signs (block 0: before the barrier
-//     that ends the K loop): the epilogue waits for about one memory round trip instead of four -- while a workgroup
-//     waits there its neighbour has the CU alone and cannot fill the matrix pipe (526 -> 512 us at (640, 64^2); two
-//     blocks ahead, or block 0 from inside the K loop, spill and lose: 585 / 548 us; accumulators that START at -T, so
-//     that the epilogue has no target loads at all: 467 against 461 us, and more near-tie signs off -- the partial sums
-//     then live at |T| for the whole K loop; profiles/r04_ab_opt_forms.txt);
-//   * sign bytes by arithmetic: med3(d * 2^126, -1, 1) -> cvt_pkrtz -> v_perm of the high bytes;
-//   * DIRECT position (rows p, 16 consecutive q per piece): the lane's bytes go to the LDS tile `tr` (rows of GX_TRS
-//     bytes), the caller stores it after a barrier;
-//   * MIRROR position (wgt == 2; rows q, consecutive p): a lane's dword already holds S[p .. p + 3][q]; one
-//     v_permlane32_swap per dword pair leaves lanes 0-31 with rows 0-15 and lanes 32-63 with rows 16-31 of the lane's
-//     column -- a 16-byte piece of mirror row q -- stored straight from registers: a wave instruction writes 32 rows x
-//     32 bytes = 1 KiB contiguous of the tiled layout.  (Before: a second LDS tile, two more barriers.)
+// of the workgroup tile): G - T -> sign bytes, stored from registers in both positions -- no LDS, no barrier.
+//   * the targets of 32 x 32 block n + 1 are requested before block n is turned into signs: the epilogue waits for
+//     about one memory round trip instead of four -- while a workgroup waits there its neighbour has the CU alone and
+//     cannot fill the matrix pipe (526 -> 512 us at (640, 64^2); two blocks ahead, or block 0 from inside the K loop,
+//     spill and lose: 585 / 548 us; accumulators that START at -T, so that the epilogue has no target loads at all: 467
+//     against 461 us, and more near-tie signs off -- the partial sums then live at |T| for the whole K loop;
+//     profiles/r04_ab_opt_forms.txt);
+//   * signs by arithmetic: s = med3(d * 2^126, -1, 1) (exactly -1, 0 or +1), cvt_pkrtz packs two of them as fp16, v_perm
+//     keeps the high bytes (0x3C / 0xBC / 0x00: what the S V kernel expands);
+//   * MIRROR position (wgt == 2; rows q, consecutive p): the accumulator layout gives a lane S[p .. p + 3][q] per dword,
+//     for p = 8 r4 + 4 hi; one v_permlane32_swap per dword pair leaves lanes 0-31 with rows 0-15 and lanes 32-63 with rows
+//     16-31 of the lane's column -- a 16-byte piece of mirror row q; a wave instruction writes 32 rows x 32 bytes = 1 KiB
+//     contiguous of the tiled layout;
+//   * DIRECT position (rows p, consecutive q): the 32 x 32 block is TRANSPOSED ON THE MATRIX PIPE.  The packed fp16
+//     signs a lane holds are, as they are, the A operand of a 32 x 32 x 16 product whose row index is the lane's column
+//     q and whose k slots are the lane's rows; against a constant 0 / 1 B operand that sends k slot (hi, j) of step t
+//     to column 16 t + 8 (j >> 2) + 4 hi + (j & 3) -- the row that slot holds -- two MFMAs return S[p][q] with lanes
+//     along p and registers along q: the same bytes, the same swap, one 16-byte store per lane.  2 MFMAs per 120 of the
+//     K loop replace 16 one-byte LDS writes per lane and block, the staging tile, two workgroup barriers and the store
+//     loop (a first form kept the LDS tile for this position: profiles/r04_gram_ablation.txt, "direct" 20 us of 455).
 // Returns the lane's sum of |G - T| (LOSS).
 // ------------------------------------------------------------------------------------------------
 template <bool LOSS>
 __device__ __forceinline__ float gram_sign_epilogue(const floatx16 (&acc)[2][2], const float* __restrict__ tgt, int hw, int wgt,
-                                                     int8_t* __restrict__ tr, int wm, int wn, int l31, int hi,
-                                                     int8_t* __restrict__ sgn_out, int b, int p0, int q0, int s_tiled) {
+                                                     int wm, int wn, int l31, int hi, int8_t* __restrict__ sgn_out, int b,
+                                                     int p0, int q0, int s_tiled) {
+    float lsum = 0.f;
+    if (wgt == 0) return lsum;  // (wave-uniform: a sub-tile below the diagonal is the mirror image of another tile's)
+    half8_t bt[2];  // B operands of the transposing products
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bt[t][j] = (16 * t + 8 * (j >> 2) + 4 * hi + (j & 3) == l31) ? (half_t)1.f : (half_t)0.f;
     float tnext[16];
     auto load_targets = [&](int blk) __attribute__((always_inline)) {
         const int i = blk >> 1, jj = blk & 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            tnext[r] = wgt ? __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32) : 0.f;
+            tnext[r] = __builtin_nontemporal_load(tgt + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * hw + jj * 32);
     };
-    load_targets(0);
-    __syncthreads();  // every wave is done reading the ring: it becomes the staging area of the sign tile
-    float lsum = 0.f;
+    auto bytes_of = [](float s0, float s1, float s2, float s3, uint32_t& h01, uint32_t& h23) __attribute__((always_inline)) {
+        h01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s0, s1));
+        h23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s2, s3));
+        return __builtin_amdgcn_perm(h23, h01, 0x07050301u);  // the four high bytes
+    };
+    // dwords w[r4] = 4 consecutive entries at offset 8 r4 + 4 hi of a line of 32 -> the lane's 16 contiguous bytes (lanes
+    // 0-31: entries 0-15, lanes 32-63: 16-31).  swap(a, b): lanes 0-31 get (own a, upper partner's a), lanes 32-63 (lower
+    // partner's b, own b)
+    auto piece_of = [](const uint32_t (&w)[4]) __attribute__((always_inline)) {
+        const auto P = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+        const auto Q = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+        return u32x4{(uint32_t)P[0], (uint32_t)P[1], (uint32_t)Q[0], (uint32_t)Q[1]};
+    };
+    if (!LOSS) load_targets(0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const int cl = wn * 64 + jj * 32 + l31;
+            if (LOSS) load_targets(i * 2 + jj);  // (the loss-reporting instantiation has no registers for the look-ahead)
             float tv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) tv[r] = tnext[r];
-            if (i * 2 + jj < 3) load_targets(i * 2 + jj + 1);
-            uint32_t sg[4];  // this lane's 16 signs of the block, 4 per dword (rows e .. e + 3 of one column)
+            if (!LOSS && i * 2 + jj < 3) load_targets(i * 2 + jj + 1);
+            uint32_t sg[4], hp[8];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 float s4[4];
@@ -544,24 +567,19 @@ __device__ __forceinline__ float gram_sign_epilogue(const floatx16 (&acc)[2][2],
                     if (LOSS) lsum += fabsf(d);
                     s4[e] = __builtin_amdgcn_fmed3f(d * 0x1p126f, -1.f, 1.f);  // exactly -1, 0 or +1 for d = 0 and every normal d
                 }
-                const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[0], s4[1]));
-                const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s4[2], s4[3]));
-                const uint32_t wv4 = __builtin_amdgcn_perm(h23, h01, 0x07050301u);  // the four high bytes: 0x3C / 0xBC / 0x00
-                sg[r4] = wv4;
-                const int rl = wm * 64 + i * 32 + 8 * r4 + 4 * hi;
-                tr[(rl + 0) * GX_TRS + cl] = (int8_t)(wv4 & 0xff);
-                tr[(rl + 1) * GX_TRS + cl] = (int8_t)((wv4 >> 8) & 0xff);
-                tr[(rl + 2) * GX_TRS + cl] = (int8_t)((wv4 >> 16) & 0xff);
-                tr[(rl + 3) * GX_TRS + cl] = (int8_t)(wv4 >> 24);
+                sg[r4] = bytes_of(s4[0], s4[1], s4[2], s4[3], hp[2 * r4], hp[2 * r4 + 1]);
             }
-            if (wgt == 2) {  // (wave-uniform)
-                // sg[r4] = rows 8 r4 + 4 hi .. + 3.  swap(a, b): lanes 0-31 get (own a, upper partner's a), lanes 32-63
-                // (lower partner's b, own b)
-                const auto P = __builtin_amdgcn_permlane32_swap(sg[0], sg[2], false, false);
-                const auto Q = __builtin_amdgcn_permlane32_swap(sg[1], sg[3], false, false);
-                const u32x4 piece = {(uint32_t)P[0], (uint32_t)P[1], (uint32_t)Q[0], (uint32_t)Q[1]};
-                s_store_piece(sgn_out, piece, b, q0 + cl, p0 + wm * 64 + i * 32 + hi * 16, hw, s_tiled);
-            }
+            const int rowb = wm * 64 + i * 32, colb = wn * 64 + jj * 32;
+            if (wgt == 2) s_store_piece(sgn_out, piece_of(sg), b, q0 + colb + l31, p0 + rowb + hi * 16, hw, s_tiled);
+            floatx16 dt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dt[r] = 0.f;
+            dt = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, u32x4{hp[0], hp[1], hp[2], hp[3]}), bt[0], dt, 0, 0, 0);
+            dt = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, u32x4{hp[4], hp[5], hp[6], hp[7]}), bt[1], dt, 0, 0, 0);
+            uint32_t dg[4], u0, u1;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) dg[r4] = bytes_of(dt[r4 * 4], dt[r4 * 4 + 1], dt[r4 * 4 + 2], dt[r4 * 4 + 3], u0, u1);
+            s_store_piece(sgn_out, piece_of(dg), b, p0 + rowb + l31, q0 + colb + hi * 16, hw, s_tiled);
         }
     return lsum;
 }
@@ -682,22 +700,13 @@ __global__ __launch_bounds__(512, 4) void gram16y_kernel(const half_t* __restric
         }
         slot = slot == GY_NS - 1 ? 0 : slot + 1;
     }
-    // ---- epilogue ---- (gram_sign_epilogue above)
+    // ---- epilogue ---- (gram_sign_epilogue above: registers -> global, nothing shared)
     const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
-    int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
-    const float lsum = gram_sign_epilogue<LOSS>(acc, tgt, hw, wgt, tr, wm, wn, l31, hi, sgn_out, b, p0, q0, s_tiled);
-    __syncthreads();
-    for (int idx = tid; idx < 256 * 8; idx += 512) {
-        const int rl = idx >> 3, ch = idx & 7;
-        const int a = 2 * ti + (rl >> 7);
-        if (a > tj) continue;
-        const int gp = p0 + rl, gq = q0 + ch * 16;
-        s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, gp, gq, hw, s_tiled);
-    }
+    const float lsum = gram_sign_epilogue<LOSS>(acc, tgt, hw, wgt, wm, wn, l31, hi, sgn_out, b, p0, q0, s_tiled);
     if (LOSS) {
-        float* red = reinterpret_cast<float*>(gy_smem + 40960);  // behind the staging area
+        float* red = reinterpret_cast<float*>(gy_smem);
         const float tot = wave_sum((float)wgt * lsum);
-        __syncthreads();
+        __syncthreads();  // (every wave is done reading the ring)
         if (lane == 0) red[wave] = tot;
         __syncthreads();
         if (tid == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7]);
@@ -819,20 +828,14 @@ __global__ __launch_bounds__(256, 3) void gram16z_kernel(const half_t* __restric
         }
         slot = slot == GZ_NS - 1 ? 0 : slot + 1;
     }
-    // ---- epilogue ---- (gram_sign_epilogue above)
+    // ---- epilogue ---- (gram_sign_epilogue above: registers -> global, nothing shared)
     const float* tgt = target + ((int64_t)b * hw + p0 + wm * 64 + 4 * hi) * hw + q0 + wn * 64 + l31;
-    int8_t* tr = reinterpret_cast<int8_t*>(gy_smem);
     const int wgt = mirrored ? 2 : 1;
-    const float lsum = gram_sign_epilogue<LOSS>(acc, tgt, hw, wgt, tr, wm, wn, l31, hi, sgn_out, b, p0, q0, s_tiled);
-    __syncthreads();
-    for (int idx = tid; idx < 128 * 8; idx += 256) {
-        const int rl = idx >> 3, ch = idx & 7;
-        s_store_piece(sgn_out, *reinterpret_cast<const u32x4*>(tr + rl * GX_TRS + ch * 16), b, p0 + rl, q0 + ch * 16, hw, s_tiled);
-    }
+    const float lsum = gram_sign_epilogue<LOSS>(acc, tgt, hw, wgt, wm, wn, l31, hi, sgn_out, b, p0, q0, s_tiled);
     if (LOSS) {
-        float* red = reinterpret_cast<float*>(gy_smem + 40960);  // behind the staging area
+        float* red = reinterpret_cast<float*>(gy_smem);
         const float tot = wave_sum((float)wgt * lsum);
-        __syncthreads();
+        __syncthreads();  // (every wave is done reading the ring)
         if (lane == 0) red[wave] = tot;
         __syncthreads();
         if (tid == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
