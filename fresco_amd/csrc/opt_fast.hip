@@ -802,7 +802,6 @@ __global__ __launch_bounds__(256, 3) void gram16z_kernel(const half_t* __restric
     }
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : GZ_NS - 1);  // the slot chunk kc - 1 was read from
         const char* Ls = gy_smem + slot * GZ_SLOT;
         half8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -820,6 +819,7 @@ __global__ __launch_bounds__(256, 3) void gram16z_kernel(const half_t* __restric
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
             }
+        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : GZ_NS - 1);  // the slot chunk kc - 1 was read from
         if (kc + 1 < nk) {
             if (kc + 2 < nk)
                 gx_wait_barrier<4>();
@@ -1090,7 +1090,6 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
     const int ra = (wm * 64 + l31) * SB_VROW, rs = 2 * VARR + (wn * (32 * NJ) + l31) * SB_SROW;
     int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : NS - 1);  // the slot chunk kc - 1 was read from
         const char* base = sb_smem + slot * SLOT;
 #pragma unroll
         for (int ks = 0; ks < SB_K / 16; ++ks) {
@@ -1119,6 +1118,9 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
+        // (the copies of chunk kc + 2 are requested BEHIND the products of chunk kc, where an LDS-DMA instruction is cheapest to
+        // issue: 482 -> 471 us at (640, 64^2); the same move in gram16y_kernel costs 7 us, in gram16z_kernel it gains 1.5)
+        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : NS - 1);  // the slot chunk kc - 1 was read from
         if (kc + 1 < nk) wait_barrier(kc + 2 < nk ? 1 : 0);
         slot = slot == NS - 1 ? 0 : slot + 1;
     }
