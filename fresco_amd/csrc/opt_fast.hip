@@ -127,16 +127,23 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
     const int sa = pj, sb = L.circular ? (pj + 1) % L.n_loc : pj + 1;
     float lsum = 0.f;
     __shared__ __attribute__((aligned(16))) half_t cmx[4][2][8][64];  // [slice = wave][hi, lo][channel of the octet][pixel]
+    __shared__ float nred[4][64];
+    const bool do_norm = fn >= 0;  // (block-uniform)
+    const int64_t bn = (int64_t)ck * L.n_loc + fn;
+    float n = 1.f;
+    if (do_norm) {
+        // |x[p]|^2 = the NPB partial sums the previous adam launch left behind.  The four slices of the block share the
+        // loads (slice sl adds partials sl, sl + 4, ...) and exchange their sums through LDS: a thread that loads all NPB
+        // (20 at C = 1280) itself spends 5 - 10 us of the small-plane launches on them (profiles/r04_opt_ablation.txt).
+        // Every block adds in the same order.
+        float ss = 0.f;
+        for (int s = sl; s < a.NPB; s += 4) ss += a.part[(bn * a.NPB + s) * hw + p];
+        nred[sl][px] = ss;
+        __syncthreads();
+        n = sqrtf((nred[0][px] + nred[1][px]) + (nred[2][px] + nred[3][px]));
+    }
     if (j < a.NPART) {
-        const bool do_norm = fn >= 0;
-        const int64_t bn = (int64_t)ck * L.n_loc + fn;
-        float n = 1.f;
-        if (do_norm) {
-            float ss = 0.f;
-            for (int s = 0; s < a.NPB; ++s) ss += a.part[(bn * a.NPB + s) * hw + p];  // same order in every thread
-            n = sqrtf(ss);
-            if (j == 0) a.nrm[bn * hw + p] = n;
-        }
+        if (do_norm && j == 0) a.nrm[bn * hw + p] = n;
         OTaps tb, tf;
         float mb = 0.f, mf = 0.f;
         if (a.has_t) {
@@ -245,12 +252,16 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(AdamKArgs k) {
     const int hw = k.hw, C = k.C, C8 = C >> 3;
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int p = xcd_contiguous(blockIdx.x, gridDim.x) * 64 + px, j = blockIdx.y * 4 + sl, b = blockIdx.z;
-    __shared__ float red[4][64];
+    __shared__ float red[4][64], dred[4][64];
     float dot = 0.f, inv_n = 0.f, n = 1.f;
-    if (k.has_s) {
-        for (int s = 0; s < k.NCT; ++s) dot += k.dotp[((int64_t)b * k.NCT + s) * hw + p];
+    if (k.has_s) {  // <V, dV>[p] = the NCT partials of the S V epilogue: the four slices share the loads (as prep does)
+        float d = 0.f;
+        for (int s = sl; s < k.NCT; s += 4) d += k.dotp[((int64_t)b * k.NCT + s) * hw + p];
+        dred[sl][px] = d;
         n = k.nrm[(int64_t)b * hw + p];
         inv_n = 1.f / n;
+        __syncthreads();
+        dot = (dred[0][px] + dred[1][px]) + (dred[2][px] + dred[3][px]);
     }
     TGradPixel tp;
     if (k.has_t) tp.init(k.tg, b, p, hw);

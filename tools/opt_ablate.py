@@ -56,6 +56,23 @@ def edits(name, s):
     if "s_nomfma" in v:
         s = rep(s, "                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j], acc[i][j], 0, 0, 0);\n                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j], acc[i][j], 0, 0, 0);\n                }\n        }\n        if (kc + 1 < nk) wait_barrier(kc + 2 < nk ? 1 : 0);",
                 "                    asm volatile(\"\" ::\"v\"(fa[i][0]), \"v\"(fa[i][1]), \"v\"(fb[j]));\n                }\n        }\n        if (kc + 1 < nk) wait_barrier(kc + 2 < nk ? 1 : 0);")
+    # prep (timing of the small planes: which part of the launch is the latency chain)
+    if "p_notaps" in v:
+        s = rep(s, "                    const float r1 = (q2[p] - osample(q1, tb)) * mb;\n                    const float r2 = (x1[k] - osample(q2, tf)) * mf;",
+                "                    const float r1 = (q2[p] - x1[k]) * mb;\n                    const float r2 = (x1[k] - q2[p]) * mf;")
+    if "p_nocopies" in v:
+        s = rep(s, "            if (do_norm) {\n                half8_t h8, l8;", "            if (do_norm && n == 12345.f) {\n                half8_t h8, l8;")
+    if "p_nopart" in v:
+        s = rep(s, "            for (int s = 0; s < a.NPB; ++s) ss += a.part[(bn * a.NPB + s) * hw + p];  // same order in every thread",
+                "            ss = 1.f + (float)a.NPB;")
+    if "p_nosigns" in v:
+        s = rep(s, "            if (a.has_t) {\n                const float* c2p = frame_plane(a.cs, L, ck, sb, c0, C, hw);", "            if (a.has_t && n == 12345.f) {\n                const float* c2p = frame_plane(a.cs, L, ck, sb, c0, C, hw);")
+    # adam
+    if "a_notgrad" in v:
+        s = rep(s, "        if (k.has_t) tp.values(k.tg, o, p, C8, hw, tgv);", "        if (k.has_t && n == 12345.f) tp.values(k.tg, o, p, C8, hw, tgv);")
+        s = rep(s, "    if (k.has_t) tp.init(k.tg, b, p, hw);", "    if (k.has_t && n == 12345.f) tp.init(k.tg, b, p, hw);")
+    if "a_nodot" in v:
+        s = rep(s, "        for (int s = 0; s < k.NCT; ++s) dot += k.dotp[((int64_t)b * k.NCT + s) * hw + p];", "        dot = 0.5f;")
     return s
 
 
