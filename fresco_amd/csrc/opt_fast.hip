@@ -9,12 +9,18 @@
 //                            (4-tap gathers of the neighbouring frame).  Replaces temporal_sign + chan_partial + normalize_split.
 //   gram   gram16y_kernel    sign(V V^T - T): 256 x 128 workgroup tiles (wave tiles 64 x 64: every LDS fragment feeds two
 //                            MFMAs), two workgroups per CU, operands by LDS-DMA into 3-slot rings of 24 KB slots, swizzled
-//                            32-byte rows (no pad bytes in the stream), upper triangle + mirrored tile.  gram16s_kernel for
-//                            planes <= 256 pixels (64 x 64 tiles, wave-level split K, operands straight from L2 into registers).
+//                            32-byte rows (no pad bytes in the stream), upper triangle + mirrored tile; the epilogue turns
+//                            G - T into sign bytes and stores both positions from registers (mirror pieces after a
+//                            v_permlane32_swap, direct pieces after a transposition on the matrix pipe: no LDS, no barrier).
+//                            gram16z_kernel: the same on 128 x 128 tiles / 4 waves / three workgroups per CU for launches
+//                            that do not fill the chip twice.  gram16s_kernel for planes <= 256 pixels (64 x 64 tiles,
+//                            wave-level split K, operands straight from L2 into registers).
 //   sv     sv16b / sv16      dV^T = 2c V^T S, and in the epilogue the partial sums of <V, dV> per pixel over the workgroup's
-//                            128 channels (the norm backward needs the full sum: one more pass over x and dV before).
+//                            128 channels (the norm backward needs the full sum: one more pass over x and dV before), its V
+//                            operands copied through the free LDS ring.
 //   adam   opt_adam_kernel   temporal gradient from the signs + CSR rows, norm backward, Adam, and the partial sums of
-//                            squares of the UPDATED features for the next prep.
+//                            squares of the UPDATED features for the next prep (m / v / dV non-temporal on the big planes).
+// prep and adam blocks share the loads of the per-pixel partial sums among their four slices (LDS exchange).
 //
 // All reductions have a fixed order: results are bit-reproducible run to run.
 #include "opt_shared.h"
@@ -601,12 +607,12 @@ __device__ __forceinline__ float gram_sign_epilogue(const floatx16 (&acc)[2][2],
 // workgroup per CU (K chunks of 32 in a 3 x 48 KB ring, targets prefetched into 64 registers; removed, see git history)
 // measured 559 us at (640, 64^2) with the matrix pipe busy 44 %: its DMA waits, target stream and 6 us sign / store
 // epilogue overlapped with nothing (ablations: profiles/r04_gram_ablation.txt, PMC: profiles/r04_pmc_opt_gram16x.csv).
-// This form: 478 us.
+// This form: 478 us when written, 447 - 462 us with the epilogue of gram_sign_epilogue (above).
 //   * K chunks of 16 channels: a slot is six 4 KB blocks (24 KB), three slots = 72 KB per workgroup -> two per CU;
 //     operands pre-tiled by prep as [plane][128-pixel tile][16-channel chunk][128][2 x 16 B], the two units of pixel row r
 //     swapped when (r >> 3) & 1 (conflict-free ds_read_b128 on 32-byte rows);
-//   * <= 128 registers: the target values are NOT prefetched (64 registers); the epilogue loads them where it needs
-//     them and the other workgroup's MFMAs cover the latency;
+//   * <= 128 registers: the target values are NOT prefetched into 64 registers; the epilogue requests them one 32 x 32
+//     block ahead and the other workgroup's MFMAs cover the rest of the latency;
 //   * sign bytes by arithmetic: med3(d * 2^64, -1, 1) -> cvt_pkrtz -> v_perm of the two high bytes (3.75 VALU per value
 //     instead of ~10 compares / selects); target loads and sign stores carry the non-temporal hint (streams that
 //     would otherwise evict the operand blocks the tiles of an XCD share in L2).
