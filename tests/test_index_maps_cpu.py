@@ -92,3 +92,76 @@ def test_sv_dot_operand_offsets():
                 rl = rl0 + lr
                 want = lr * 64 + ((((l31 >> 3) ^ (rl >> 2)) & 3) << 4) + (l31 & 7) * 2
                 assert off == want, (rl0, lane, r)
+
+
+def _gx_tile(idx, hw):
+    """tile walk of gram16y_kernel (gx_tile in opt_fast.hip): tiles (ti, tj) of 256 x 128 pixels, tj >= 2 ti in 128-pixel units"""
+    if hw % 1024 == 0:
+        ns = hw // 1024
+        si = 0
+        while True:
+            row_tiles = 20 + 32 * (ns - 1 - si)
+            if idx < row_tiles:
+                break
+            idx -= row_tiles
+            si += 1
+        if idx < 20:
+            r = 0
+            while idx >= 8 - 2 * r:
+                idx -= 8 - 2 * r
+                r += 1
+            return si * 4 + r, si * 8 + 2 * r + idx
+        idx -= 20
+        sj = si + 1 + idx // 32
+        return si * 4 + (idx % 32) // 8, sj * 8 + idx % 8
+    n128 = hw // 128
+    ti = 0
+    while idx >= n128 - 2 * ti:
+        idx -= n128 - 2 * ti
+        ti += 1
+    return ti, 2 * ti + idx
+
+
+def test_gram_tile_walks_write_every_block_once():
+    """Both Gram kernels must write every 64 x 64 block of the sign matrix exactly once -- directly or as the mirror
+    image of the block across the diagonal (blocks ON the diagonal of a 128-pixel unit are computed whole)."""
+    for hw in (512, 768, 1024, 1536, 2048, 2304, 4096):
+        n64, n128, n256 = hw // 64, hw // 128, hw // 256
+        # --- gram16y: 256 x 128 tiles, 8 waves as 4 x 2
+        cnt = np.zeros((n64, n64), dtype=int)
+        ntiles = n256 * n128 - n256 * (n256 - 1)
+        seen = set()
+        for idx in range(ntiles):
+            ti, tj = _gx_tile(idx, hw)
+            assert 0 <= ti < n256 and 2 * ti <= tj < n128 and (ti, tj) not in seen, (hw, idx, ti, tj)
+            seen.add((ti, tj))
+            for wm in range(4):
+                a_sub = 2 * ti + (wm >> 1)
+                wgt = 0 if a_sub > tj else (2 if a_sub < tj else 1)
+                for wn in range(2):
+                    r, c = ti * 4 + wm, tj * 2 + wn  # 64-pixel block coordinates
+                    if wgt >= 1:
+                        cnt[r, c] += 1
+                    if wgt == 2:
+                        cnt[c, r] += 1
+        assert (cnt == 1).all(), (hw, "gram16y", int((cnt != 1).sum()))
+        # --- gram16z: 128 x 128 tiles (ti, tj >= ti), 4 waves as 2 x 2
+        cnt = np.zeros((n64, n64), dtype=int)
+        idx = 0
+        for ti in range(n128):
+            for tj in range(ti, n128):
+                # the kernel's walk: idx -> (ti, tj) row by row
+                t, rem = 0, idx
+                while rem >= n128 - t:
+                    rem -= n128 - t
+                    t += 1
+                assert (t, t + rem) == (ti, tj)
+                idx += 1
+                for wm in range(2):
+                    for wn in range(2):
+                        r, c = ti * 2 + wm, tj * 2 + wn
+                        cnt[r, c] += 1
+                        if ti < tj:
+                            cnt[c, r] += 1
+        assert idx == n128 * (n128 + 1) // 2
+        assert (cnt == 1).all(), (hw, "gram16z", int((cnt != 1).sum()))
