@@ -383,10 +383,99 @@ def timed_workload(N, R, device, shard_args, steps, warmup, barrier, max_over_ra
             run_step(proc, ctrl, layers, SCHEDULE[s % len(SCHEDULE)], refs, paras, masks)
         barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
-    return dict(workload="cfg5's batch (BASELINE.json configs[4]): %d frames %dx%d, frame-sharded" % (N, R, R), steps=steps,
-                value=round(steps / dt, 3), unit="denoising-steps/sec", ms_per_step=round(1e3 * dt / steps, 4),
-                note="weak-scaling companion of `value`: per-frame work 16x config 2's; compare with a one-GPU run of "
-                     "`bench.py --frames %d --res %d`" % (N, R))
+    return dict(workload="cfg5's batch (BASELINE.json configs[4]): %d frames %dx%d, %s" % (N, R, R, "frame-sharded" if shard is not None else "one GPU"),
+                steps=steps, value=round(steps / dt, 3), unit="denoising-steps/sec", ms_per_step=round(1e3 * dt / steps, 4),
+                scaling="strong",
+                note="companion of `value` on the batch whose per-frame work is 16x config 2's; the same leg runs at every "
+                     "--gpus N (N = 1 included), so value(N) / value(1) is this workload's own scaling curve")
+
+
+def rank_census(rank, world, device, backend):
+    """every rank reports who it is: the line then proves that N distinct processes on N distinct devices took part"""
+    import torch.distributed as dist
+
+    me = dict(rank=rank, device=str(device), device_name=torch.cuda.get_device_name(device), pid=os.getpid(),
+              uuid=str(getattr(torch.cuda.get_device_properties(device), "uuid", "")))
+    seen = [None] * world
+    dist.all_gather_object(seen, me)
+    return dict(backend=backend, ranks_seen=len(seen), distinct_devices=len({(r["device"], r["uuid"]) for r in seen}),
+                ranks=seen)
+
+
+def sharded_vs_single(layers, params, N, device, shard, proc, ctrl, refs, paras, masks, rank):
+    """One step per attention mode, frame-sharded over the ranks, against the SAME step evaluated on ONE GPU (rank 0 runs the
+    whole batch through an unsharded processor): max |delta| over rank 0's frames of every layer call.  Every rank
+    takes part in the sharded step (its collectives); only rank 0 evaluates the single-GPU form."""
+    import fresco_amd
+
+    out = {}
+    sel = shard.local_batch_index().to(device)
+    with torch.no_grad():
+        for mode in ("full", "cf_temporal", "cf"):
+            set_mode(ctrl, mode, list(refs), paras, masks)
+            got = [proc(l["attn"], l["hidden_local"]) for l in layers]
+            if rank == 0:
+                c1 = fresco_amd.AttentionControl()
+                p1 = fresco_amd.FRESCOAttnProcessor2_0(2, c1)
+                set_mode(c1, mode, [l["ref"] for l in layers], paras, masks)
+                worst = 0.0
+                for l, g in zip(layers, got):
+                    full = p1(l["attn"], l["hidden"])
+                    worst = max(worst, float((full.index_select(0, sel).float() - g.float()).abs().max()))
+                out[mode] = round(worst, 6)
+    return out
+
+
+def exchange_timing(layers, params, N, device, shard, reps=10):
+    """HIP-event time of the exchanges alone, per layer kind: the cross-frame exchange (launch -> wait) in the form the
+    run uses, and the temporal pass's two all-to-alls around an empty kernel slot (pack -> all-to-all -> all-to-all ->
+    unpack is timed as the two collectives only).  A bad scaling curve is then diagnosable from the JSON alone."""
+    import torch.distributed as dist
+
+    res = {}
+    for l in (layers[0], layers[3]):
+        C, HW = l["C"], l["HW"]
+        mask = params[l["down"]][3].to(device)
+        kv_loc = torch.randn(shard.B_loc, HW, 2 * C, device=device, dtype=torch.float16)
+        plan = shard.cf_plan(mask, HW, device)
+        Pw = HW // shard.world
+        send = torch.randn(shard.world, shard.n_loc, shard.chunk, Pw, 3 * C, device=device, dtype=torch.float16)
+        back = torch.randn(shard.world, shard.n_loc, shard.chunk, Pw, C, device=device, dtype=torch.float16)
+
+        def cf():
+            _, works = shard.exchange_cf(kv_loc, plan)
+            for w in works:
+                w.wait()
+
+        def a2a():
+            shard.all_to_all(send)
+            shard.all_to_all(back)
+
+        t = {}
+        for name, fn in (("cross_frame_exchange_us", cf), ("temporal_all_to_all_pair_us", a2a)):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t[name] = round(1e3 * e0.elapsed_time(e1) / reps, 1)
+        t["cross_frame_bytes_received"] = int(((HW if shard.rank else 0) + (shard.world - 1) * plan["Rmax"]) * shard.chunk * 2 * C * 2)
+        t["all_to_all_bytes_sent"] = int((send.numel() + back.numel()) * 2 * (shard.world - 1) / shard.world)
+        res[l["name"]] = t
+    # slowest rank per entry
+    for name in res:
+        for k in ("cross_frame_exchange_us", "temporal_all_to_all_pair_us"):
+            tt = torch.tensor([res[name][k]], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            res[name][k] = round(float(tt.item()), 1)
+    res["form"] = "grouped point-to-point" if shard.p2p_exchange else "broadcast + all-gather"
+    res["note"] = "max over ranks of the mean of %d back-to-back exchanges, nothing overlapping them" % reps
+    return res
 
 
 def main():
@@ -475,6 +564,12 @@ def main():
             run_step(proc, ctrl, layers, mode, refs, paras, masks)
     torch.cuda.synchronize()
 
+    census = parity = xch = None
+    if world > 1:
+        census = rank_census(rank, world, device, backend)
+        parity = sharded_vs_single(layers, params, N, device, shard, proc, ctrl, refs, paras, masks, rank)
+        xch = exchange_timing(layers, params, N, device, shard)
+
     run_eager(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -546,8 +641,9 @@ def main():
                                 (32, 768): "cfg5's batch (configs[4]: 32 frames at 768^2)"}.get((N, R), "custom batch"),
                                N, R, R, (R // 16) ** 2, HW3),
                 "cross_frame_keys_M": {"L3": M3, "L2": int(params[16][3].sum())},
-                "parallelism": ("frame-shard x%d: frame 0's K|V + the masked rows of the other frames to every rank in one grouped "
-                                "point-to-point launch, trajectory all-to-all for the temporal pass (RCCL)" % world)
+                "parallelism": ("frame-shard x%d: frame 0's K|V (broadcast) + the masked rows of the other frames (all-gather) to "
+                                "every rank, trajectory all-to-all for the temporal pass (RCCL); the grouped point-to-point form "
+                                "of the exchange is timed beside it (`p2p_exchange`)" % world)
                                if world > 1 else "single GPU",
             },
             "roofline": roofline,
@@ -564,9 +660,17 @@ def main():
             res["collective_bytes_received_per_rank"] = collective_bytes_per_step(N, R, world, M_rest)
             # per layer call: ONE grouped point-to-point launch for the cross-frame exchange (round 3: 1 broadcast + 1
             # all-gather), + 2 all-to-alls while the temporal pass is on (8 of 15 steps); 6 layer calls per step
-            cf_coll = sum(3 * (1 if shard.p2p_exchange else 1 + (1 if M_rest[n_] > 0 else 0)) for n_ in ("L2", "L3"))
+            staged = backend != "nccl"
+            cf_coll = sum(3 * (1 if (shard.p2p_exchange and not staged) else 1 + (1 if M_rest[n_] > 0 else 0))
+                          for n_ in ("L2", "L3"))
             res["collectives_per_step"] = dict(cross_frame=cf_coll, temporal_all_to_all=12,
                                                schedule_mean=round(cf_coll + 12 * 8.0 / 15.0, 1))
+            res["rank_census"] = census
+            res["sharded_vs_single_gpu_max_abs_delta"] = dict(
+                per_mode=parity, bar=1e-3,
+                note="one step per attention mode, sharded over the ranks, vs the same step on ONE GPU (rank 0, unsharded "
+                     "processor): max |delta| over rank 0's frames of all six layer calls, before any timing")
+            res["exchange_timing"] = xch
         if world == 1 and not args.no_aux:
             res["cfg2b"] = cfg2b_large_mask(layers, N, R, device, lib)
             rows3 = params[8][3].reshape(-1).nonzero().squeeze(1).to(torch.int32).to(device)
@@ -602,6 +706,15 @@ def main():
             # auxiliary, NOT part of `value`: SURVEY 8 row f3 (flows + occlusions + masks + mappings, once per batch of frames)
             res["f3_gmflow"] = bench_gmflow.measure(N=N, R=R, dev=device)
             res["cfg3"] = bench_opt.measure(N=N, R=R, dev=device)
+            # auxiliary, NOT part of `value`: SURVEY 8d's "(ii) full step" (the hot path inside a stand-in SD-1.5 UNet +
+            # ControlNet; everything outside the six FRESCO layers is PyTorch's own code) and the metric's second half,
+            # max latent delta vs the reference's op sequence over a K-step denoising loop
+            if (N, R) == (8, 512) and os.environ.get("FRESCO_BENCH_FULL_STEP", "1") == "1":
+                import bench_full_step
+
+                fs = bench_full_step.measure(N=N, R=R, dev=device)
+                res["latent_delta"] = fs.pop("latent_delta", None)
+                res["full_step"] = fs
             # the step of BASELINE.json's configs[2] (attention + feature optimisation + warp): what a denoising step costs
             # on the 15 of 20 steps the pipeline optimises features on (run_fresco.py:232)
             tot_ms = res["ms_per_step"] + res["cfg3"]["ms_per_step"]
@@ -612,26 +725,34 @@ def main():
                                                         res["cfg3"]["torch_gpu_baseline"]["ms_per_step"]) / tot_ms, 2))
         elif world == 1:
             res["cpu_baseline"] = None
-    # ---- cfg5 leg (N > 1 only, every rank takes part): 32 frames x 768^2 sharded over the same ranks
-    if world > 1 and (N, R) == (8, 512) and 32 % world == 0 and not args.no_aux:
-        c5 = timed_workload(32, 768, device, (rank, world), max(args.steps // 2, 2), 1, barrier, max_over_ranks)
+    # ---- cfg5 leg (every world size, every rank takes part): 32 frames x 768^2 sharded over the same ranks -- the workload
+    # the frame-parallel claim of BASELINE.json rests on (per-frame work 16x config 2's).  It runs at N = 1 too, so that a
+    # SCALE record of the default command carries this workload's own curve next to config 2's strong-scaling `value`.
+    if (N, R) == (8, 512) and 32 % world == 0 and not args.no_aux:
+        c5 = timed_workload(32, 768, device, (rank, world) if world > 1 else None, max(args.steps // 2, 2), 1, barrier,
+                            max_over_ranks)
         if rank == 0:
             res["cfg5"] = c5
-    # ---- hipGraph replay (N > 1 by default; FRESCO_BENCH_GRAPH=0 / 1 overrides): one graph per attention mode, captured
-    # after the eager measurement above and replayed over the same K steps -- the same kernels (and, sharded, the same RCCL
-    # collectives) without the Python / launch gaps between them.  One GPU: replay is 3 % SLOWER than eager (the step is
-    # GPU-bound, eager launches run ahead), hence off.  N > 1: host time (0.84 ms per step) exceeds a rank's share of the
-    # kernels.  Capture with collectives inside could not be exercised on the single-GPU build boxes, so it is fenced: the
-    # eager result is complete before it starts; a failure on ANY rank (agreed through an all-reduce) keeps the eager
-    # result; a HANG is cut by a watchdog that prints the eager line and exits.  `value` / `ms_per_step` are ALWAYS the eager
-    # figures (the same launch mode at every world size, and the one the baselines are compared with); the replay time
-    # of the same K steps is reported beside them in `ms_per_step_by_mode` and `graph_replay`.
-    want_graph = os.environ.get("FRESCO_BENCH_GRAPH", "1" if (world > 1 and backend == "nccl") else "0") == "1"
-    if want_graph:
+    # ---- optional legs, all AFTER the result above is complete and all fenced by one watchdog (a hang prints the eager
+    # line and exits; the watchdog's line and the normal one are mutually exclusive):
+    #  (i)  N > 1 on RCCL: the cross-frame exchange as ONE grouped launch of point-to-point transfers
+    #       (FrameShard.p2p_exchange = True, FRESCO_BENCH_P2P=0 skips): its outputs must equal the broadcast + all-gather
+    #       form's bit for bit (same rows, same kernels) and its K steps are timed beside `value`.  The grouped form has
+    #       never run on RCCL on the build boxes, hence opt-in in the library and fenced here.
+    #  (ii) hipGraph replay, OPT-IN (FRESCO_BENCH_GRAPH=1) until it has run once on RCCL: one graph per attention mode,
+    #       captured after the eager measurement and replayed over the same K steps.  One GPU: replay is 3 % SLOWER than
+    #       eager (the step is GPU-bound, eager launches run ahead).  N > 1: host time (0.84 ms per step) exceeds a
+    #       rank's share of the kernels, so replay is what a production loop would use -- but capture with collectives
+    #       inside is unverified.  A failure on ANY rank (agreed through an all-reduce) keeps the eager result.
+    # `value` / `ms_per_step` are ALWAYS the eager figures of the default exchange form.
+    want_graph = os.environ.get("FRESCO_BENCH_GRAPH", "0") == "1"
+    want_p2p = world > 1 and backend == "nccl" and os.environ.get("FRESCO_BENCH_P2P", "1") == "1"
+    if want_graph or want_p2p:
         import threading
 
         out_lock = threading.Lock()  # the watchdog's line and the normal one are mutually exclusive
         printed = [False]
+        stage = ["starting"]
 
         def emit():
             with out_lock:
@@ -641,46 +762,95 @@ def main():
 
         def bail():
             if rank == 0:
-                res["graph_replay"] = dict(status="capture / replay did not finish within the watchdog time")
+                res["optional_legs"] = dict(status="did not finish within the watchdog time", stage=stage[0])
             emit()
             os._exit(0)  # (a hung collective cannot be torn down from here; the eager result above is complete)
 
-        dog = threading.Timer(float(os.environ.get("FRESCO_BENCH_GRAPH_TIMEOUT", "120")), bail)
+        dog = threading.Timer(float(os.environ.get("FRESCO_BENCH_GRAPH_TIMEOUT", "180")), bail)
         dog.daemon = True
         dog.start()
-        graphs, err = {}, None
-        try:
-            with torch.no_grad():
-                for mode in sorted(set(SCHEDULE)):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        run_step(proc, ctrl, layers, mode, refs, paras, masks)
-                    graphs[mode] = g
-        except Exception as e:  # noqa: BLE001 -- any capture failure means eager
-            err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
-        torch.cuda.synchronize()
-        ok = 0.0 if err else 1.0
-        if world > 1:
-            t = torch.tensor([ok], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = float(t.item())
-        if ok == 1.0:
-            def run_graph(k0, k):
-                for s_ in range(k0, k0 + k):
-                    graphs[SCHEDULE[s_ % len(SCHEDULE)]].replay()
 
-            run_graph(0, args.warmup)
-            barrier()
-            t0 = time.perf_counter()
-            run_graph(0, args.steps)
-            barrier()
-            dt_g = max_over_ranks(time.perf_counter() - t0)
+        def all_min(x):
+            if world == 1:
+                return x
+            t = torch.tensor([x], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return float(t.item())
+
+        if want_p2p:
+            stage[0] = "p2p exchange: parity"
+            err = None
+            same = 1.0
+            try:
+                with torch.no_grad():
+                    for mode in ("full", "cf_temporal", "cf"):
+                        shard.p2p_exchange = False
+                        set_mode(ctrl, mode, list(refs), paras, masks)
+                        a = [proc(l["attn"], l["hidden_local"]) for l in layers]
+                        shard.p2p_exchange = True
+                        set_mode(ctrl, mode, list(refs), paras, masks)
+                        b = [proc(l["attn"], l["hidden_local"]) for l in layers]
+                        same = min(same, 1.0 if all(torch.equal(x, y) for x, y in zip(a, b)) else 0.0)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+            ok = all_min(0.0 if err else 1.0)
+            same = all_min(same)
+            p2p = dict(outputs_equal_collective_form=bool(same == 1.0))
+            if ok == 1.0:
+                stage[0] = "p2p exchange: timing"
+                shard.p2p_exchange = True
+                run_eager(0, args.warmup)
+                barrier()
+                t0 = time.perf_counter()
+                run_eager(0, args.steps)
+                barrier()
+                dt_p = max_over_ranks(time.perf_counter() - t0)
+                p2p.update(status="ok", value=round(args.steps / dt_p, 3), ms_per_step=round(1e3 * dt_p / args.steps, 4),
+                           exchange_timing=exchange_timing(layers, params, N, device, shard),
+                           note="same K steps with FrameShard.p2p_exchange = True (one grouped launch per layer call); not `value`")
+                if rank == 0:
+                    res["ms_per_step_by_mode"]["eager_p2p_exchange"] = p2p["ms_per_step"]
+            else:
+                p2p.update(status="failed on some rank%s" % (": " + err if err else ""))
+            shard.p2p_exchange = False
             if rank == 0:
-                res["ms_per_step_by_mode"]["graph"] = round(1e3 * dt_g / args.steps, 4)
-                res["graph_replay"] = dict(status="ok", value=round(args.steps / dt_g, 3), ms_per_step=round(1e3 * dt_g / args.steps, 4),
-                                           note="hipGraph replay of the same K steps, one graph per attention mode; not `value`")
-        elif rank == 0:
-            res["graph_replay"] = dict(status="capture failed on some rank%s" % (": " + err if err else ""))
+                res["p2p_exchange"] = p2p
+        if want_graph:
+            stage[0] = "graph capture"
+            graphs, err = {}, None
+            try:
+                with torch.no_grad():
+                    for mode in sorted(set(SCHEDULE)):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            run_step(proc, ctrl, layers, mode, refs, paras, masks)
+                        graphs[mode] = g
+            except Exception as e:  # noqa: BLE001 -- any capture failure means eager
+                err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+            torch.cuda.synchronize()
+            ok = all_min(0.0 if err else 1.0)
+            if ok == 1.0:
+                stage[0] = "graph replay"
+
+                def run_graph(k0, k):
+                    for s_ in range(k0, k0 + k):
+                        graphs[SCHEDULE[s_ % len(SCHEDULE)]].replay()
+
+                run_graph(0, args.warmup)
+                barrier()
+                t0 = time.perf_counter()
+                run_graph(0, args.steps)
+                barrier()
+                dt_g = max_over_ranks(time.perf_counter() - t0)
+                if rank == 0:
+                    res["ms_per_step_by_mode"]["graph"] = round(1e3 * dt_g / args.steps, 4)
+                    res["graph_replay"] = dict(status="ok", value=round(args.steps / dt_g, 3), ms_per_step=round(1e3 * dt_g / args.steps, 4),
+                                               note="hipGraph replay of the same K steps, one graph per attention mode; not `value`")
+            elif rank == 0:
+                res["graph_replay"] = dict(status="capture failed on some rank%s" % (": " + err if err else ""))
+        elif rank == 0 and world > 1:
+            res["graph_replay"] = dict(status="not attempted (opt-in: FRESCO_BENCH_GRAPH=1)")
         dog.cancel()
         emit()
     elif rank == 0:

@@ -23,7 +23,11 @@ namespace fresco {
 template <int D, int DV>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, float* __restrict__ out,
-                                                        int Lq, int Lk, int dv_real, float scale_log2) {
+                                                        int Lq, int Lk, int dv_real, float scale_log2,
+                                                        const int* __restrict__ only_if) {
+    // guarded launches (fresco_attn_f32_guarded): this exact-fp32 form only runs -- and overwrites the split-fp16 result --
+    // when the range pass found an operand outside what the fp16 pieces can hold (uniform branch, one scalar load)
+    if (only_if && __builtin_amdgcn_readfirstlane(*only_if) == 0) return;
     constexpr int KR = D + 4;    // LDS row strides (floats)
     constexpr int VR = DV + 4;
     constexpr int NDB = DV / 32;  // 32-row blocks of O^T
@@ -585,10 +589,33 @@ static int launch_attn32(const float* q, const float* k, const float* v, float* 
                            dv, scale * 1.4426950408889634f);
     else if (use_f32_mfma)
         hipLaunchKernelGGL((attn_f32_kernel<D, DV>), dim3((Lq + 127) / 128, B), dim3(256), 0, st, q, k, v, out, Lq, Lk,
-                           dv, scale * 1.4426950408889634f);
+                           dv, scale * 1.4426950408889634f, (const int*)nullptr);
     else
         hipLaunchKernelGGL((attn_f32s_kernel<D, DV, 3>), dim3((Lq + 127) / 128, B), dim3(256), 0, st, q, k, v, out, Lq, Lk,
                            dv, scale * 1.4426950408889634f);
+    return check_launch();
+}
+
+// Range pass of the guarded entry: the split-fp16 kernels scale every operand by 2^6 before the split (see above), so
+// |q * scale * log2(e)|, |k|, |v| must stay below ~1000 or the hi piece overflows fp16 (inf -> NaN out of the MFMA).
+// One grid-stride pass over q, k, v (a few MB in the flow network) raises *flag when any element is beyond its limit
+// or not finite; the exact-fp32 kernel behind it then recomputes the launch.
+__global__ __launch_bounds__(256) void a32_range_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, int64_t nq, int64_t nk, int64_t nv,
+                                                         float lim_q, float lim_kv, int* __restrict__ flag) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) bad |= !(fabsf(q[i]) < lim_q);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += stride) bad |= !(fabsf(k[i]) < lim_kv);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) bad |= !(fabsf(v[i]) < lim_kv);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+template <int D, int DV>
+static int launch_attn32_fallback(const float* q, const float* k, const float* v, float* out, int B, int Lq, int Lk, int dv,
+                                  float scale, const int* flag, hipStream_t st) {
+    hipLaunchKernelGGL((attn_f32_kernel<D, DV>), dim3((Lq + 127) / 128, B), dim3(256), 0, st, q, k, v, out, Lq, Lk, dv,
+                       scale * 1.4426950408889634f, flag);
     return check_launch();
 }
 
@@ -660,3 +687,36 @@ extern "C" int fresco_attn_f32_ws(const float* q, const float* k, const float* v
     return FRESCO_EUNSUPPORTED;
 }
 
+// ---- guarded form: no range limit on the operands.  `flag` = one int32 of device memory owned by the caller
+// for the duration of the call.  Range pass -> split-fp16 kernels (with the workspace when one is given, else the
+// per-workgroup staging form) -> the exact-fp32 MFMA kernel, which returns at once unless the range pass raised the flag.
+// In range (every call of the flow network): the results of fresco_attn_f32 / _ws bit for bit, + ~2 short launches. ----
+extern "C" int fresco_attn_f32_guarded(const float* q, const float* k, const float* v, float* out, void* workspace,
+                                       size_t workspace_bytes, int* flag, int B, int Lq, int Lk, int D, int Dv, float scale,
+                                       void* stream) {
+    if (!flag) return FRESCO_EINVAL;
+    if (!q || !k || !v || !out || B <= 0 || Lq <= 0 || Lk <= 0 || D <= 0 || Dv <= 0 || !(scale > 0.f)) return FRESCO_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return FRESCO_ELAUNCH;
+    const int64_t nq = (int64_t)B * Lq * D, nk = (int64_t)B * Lk * D, nv = (int64_t)B * Lk * Dv;
+    const int64_t nmax = nq > nk ? (nq > nv ? nq : nv) : (nk > nv ? nk : nv);
+    int blocks = (int)((nmax + 256 * 8 - 1) / (256 * 8));
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    const float lim = 1000.f;
+    hipLaunchKernelGGL(a32_range_kernel, dim3(blocks), dim3(256), 0, st, q, k, v, nq, nk, nv,
+                       lim / (scale * 1.4426950408889634f), lim, flag);
+    int rc = workspace ? fresco_attn_f32_ws(q, k, v, out, workspace, workspace_bytes, B, Lq, Lk, D, Dv, scale, stream)
+                       : fresco_attn_f32(q, k, v, out, B, Lq, Lk, D, Dv, scale, stream);
+    if (rc != FRESCO_OK) return rc;
+#define FRESCO_A32G(DD)                                                                                     \
+    if (D == DD) {                                                                                          \
+        if (Dv <= 32) return launch_attn32_fallback<DD, 32>(q, k, v, out, B, Lq, Lk, Dv, scale, flag, st);  \
+        if (Dv <= 64) return launch_attn32_fallback<DD, 64>(q, k, v, out, B, Lq, Lk, Dv, scale, flag, st);  \
+        return launch_attn32_fallback<DD, 128>(q, k, v, out, B, Lq, Lk, Dv, scale, flag, st);               \
+    }
+    FRESCO_A32G(32)
+    FRESCO_A32G(64)
+    FRESCO_A32G(128)
+#undef FRESCO_A32G
+    return FRESCO_EUNSUPPORTED;
+}

@@ -1009,18 +1009,37 @@ static SideStream* side_stream() {  // (the slot of the current device; its stre
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
     return &tab[dev];
 }
+static void side_stream_destroy(SideStream& t) {  // call with t.busy held
+    auto drop = [](hipEvent_t& e) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    };
+    drop(t.fork);
+    drop(t.mid);
+    drop(t.join);
+    for (int i = 0; i < 4; ++i) drop(t.sv_done[i >> 1][i & 1]);
+    for (int i = 0; i < 4; ++i) drop(t.gram_done[i >> 1][i & 1]);
+    if (t.s) (void)hipStreamDestroy(t.s);
+    t.s = nullptr;
+}
 static bool side_stream_ready(SideStream& t) {  // call with t.busy held
     if (t.s) return true;
     if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) {
         t.s = nullptr;
         return false;
     }
-    (void)hipEventCreateWithFlags(&t.fork, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&t.mid, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&t.join, hipEventDisableTiming);
-    for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&t.sv_done[i >> 1][i & 1], hipEventDisableTiming);
-    for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&t.gram_done[i >> 1][i & 1], hipEventDisableTiming);
-    return true;
+    // every event is needed: a null fork / join would leave half 1 unordered with the caller's stream (cs and the
+    // workspace would race silently).  Any failure tears the slot down; the caller then runs the one-stream form.
+    bool ok = hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&t.mid, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&t.sv_done[i >> 1][i & 1], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&t.gram_done[i >> 1][i & 1], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        side_stream_destroy(t);
+    }
+    return ok;
 }
 static int opt_split_mode(int planes_hw) {
     const char* e = getenv("FRESCO_OPT_SPLIT");  // (read per call: the tests switch it)
@@ -1059,6 +1078,12 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
             }
         } release{split ? sd : nullptr};
         if (split && !side_stream_ready(*sd)) split = 0;
+        // fork: half 1's stream must see the memsets / CSR build above.  If the record or the wait fails the two-stream form
+        // is not entered at all.
+        if (split && (hipEventRecord(sd->fork, st) != hipSuccess || hipStreamWaitEvent(sd->s, sd->fork, 0) != hipSuccess)) {
+            (void)hipGetLastError();
+            split = 0;
+        }
         if (!split) {
             opt_fast_begin(ws, cs, chunk * N, C, hw, chunk * N, st);
             for (int it = 1; it <= iters; ++it)
@@ -1068,9 +1093,7 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
             const OptWs w1 = ws_half(ws, 1, N, N, C, hw);
             float* cs1 = cs + (size_t)N * C * hw;
             const float* tg1 = target + (size_t)N * hw * hw;
-            (void)hipEventRecord(sd->fork, st);  // (memsets + CSR are behind this)
-            (void)hipStreamWaitEvent(sd->s, sd->fork, 0);
-            opt_fast_begin(ws, cs, N, C, hw, chunk * N, st);
+            opt_fast_begin(ws, cs, N, C, hw, chunk * N, st);  // (fork recorded above: memsets + CSR are behind it)
             if (split == 4) {
                 // host issue order: front0(1) front1(1) | back0(1) front0(2) | back1(1) front1(2) | back0(2) front0(3) | ...
                 auto issue = [&](int half, int it, int parts) {
@@ -1121,8 +1144,12 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
                 opt_fast_closure(w1, cs1, fwd_flow, bwd_flow, fwd_occ, bwd_occ, tg1, 1, C, h, w, intra_weight, has_t, 0,
                                  nullptr, nullptr, a, sd->s, L, chunk * N, &y1);
             }
-            (void)hipEventRecord(sd->join, sd->s);
-            (void)hipStreamWaitEvent(st, sd->join, 0);
+            // join: the caller's stream must not run past half 1.  If the event path fails, fall back to a host-side wait
+            // for the side stream (correct, merely slower) and report the launch error
+            if (hipEventRecord(sd->join, sd->s) != hipSuccess || hipStreamWaitEvent(st, sd->join, 0) != hipSuccess) {
+                (void)hipStreamSynchronize(sd->s);
+                return FRESCO_ELAUNCH;
+            }
         }
         return check_launch();
     }

@@ -11,7 +11,8 @@ not read):
      occluded tokens of the other frames (controller.attn_mask, src/diffusion_hacked.py:935-938).  Frame 0's fused
      K|V rows go from their owner to every rank; the other frames' selected rows are compacted per rank, padded
      to the largest rank's count (the mask is replicated, so every rank knows the counts) and sent to every rank --
-     since round 4 as ONE grouped launch of point-to-point transfers (before: one broadcast + one all-gather).
+     as one broadcast + one all-gather (default), or as ONE grouped launch of point-to-point transfers
+     (`p2p_exchange = True`; opt-in until it has been validated on RCCL).
      Both land in one (HW + world*Rmax, chunk, 2C) buffer -- the CFG halves side by side in a row, so that frame 0's
      rows of BOTH halves are one contiguous block and every rank's selected rows another: one transfer each per
      peer, all of them in one launch.  The kernel addresses the buffer through the remapped row table of
@@ -93,9 +94,11 @@ class FrameShard:
         self.f0 = rank * self.n_loc
         self.B_loc = chunk * self.n_loc
         self._rows_cache = {}
-        # cross-frame exchange as ONE grouped launch of point-to-point transfers (exchange_cf); False: one broadcast +
-        # one all-gather (round-3 form)
-        self.p2p_exchange = True
+        # cross-frame exchange form (exchange_cf).  False (default): one broadcast + one all-gather -- the two stock
+        # collectives.  True: ONE grouped launch of point-to-point transfers (dist.batch_isend_irecv).  The grouped form
+        # has only ever run on gloo / emulated ranks (the build boxes have one GPU), so it stays opt-in until an RCCL
+        # run has shown parity and timing: `bench.py --gpus N` checks and times BOTH forms and reports them side by side.
+        self.p2p_exchange = False
 
     def local_batch_index(self):
         return local_batch_index(self.N, self.chunk, self.rank, self.world)
@@ -194,11 +197,11 @@ class FrameShard:
         frame 0's rows of both CFG halves (from their owner, rank 0) and every rank's selected rows of its other frames;
         returns (buffer, [works]) -- wait on the works before the kernel reads the buffer through plan["kv_table"] /
         plan["kv_group_rows"].
-        Round 4: ONE grouped launch of point-to-point transfers (dist.batch_isend_irecv: the owner of frame 0 sends its
-        block to every peer, every rank sends its selected rows to every peer) instead of one broadcast + one
-        all-gather: xGMI is point-to-point -- the owner drives its 7 links in parallel either way -- and a layer call
-        pays ONE collective launch (12 -> 6 per step at 8 x 512^2).  `p2p_exchange = False`, or a host-staged test
-        backend, keeps the two-collective form."""
+        Default: one broadcast + one all-gather.  `p2p_exchange = True` (round 4, opt-in): ONE grouped launch of
+        point-to-point transfers (dist.batch_isend_irecv: the owner of frame 0 sends its block to every peer, every
+        rank sends its selected rows to every peer): xGMI is point-to-point -- the owner drives its 7 links in
+        parallel either way -- and a layer call pays ONE collective launch (12 -> 6 per step at 8 x 512^2); a
+        host-staged test backend always takes the two-collective form."""
         Bl, HW, C2 = kv_loc.shape
         Rmax = plan["Rmax"]
         buf = torch.empty(HW + self.world * Rmax, self.chunk, C2, dtype=kv_loc.dtype, device=kv_loc.device)
@@ -227,9 +230,13 @@ class FrameShard:
             works.append(self.all_gather_into(buf[HW:], mine, async_op=True))
         return buf, [w for w in works if w is not None]
 
-    # collectives one layer call issues (bench.py reports the count per step)
-    def cf_collectives(self, plan):
-        return 1 if self.p2p_exchange else 1 + (1 if plan["Rmax"] > 0 else 0)
+    def cf_collectives(self, plan, device_tensor=None):
+        """collective launches one cross-frame exchange issues in the branch `exchange_cf` actually takes (bench.py reports
+        the count per step): 1 for the grouped point-to-point form, else broadcast + (all-gather when any rank has rows)"""
+        staged = device_tensor is not None and self._host_staged(device_tensor)
+        if self.p2p_exchange and self.world > 1 and not staged:
+            return 1
+        return 1 + (1 if plan["Rmax"] > 0 else 0)
 
     def temporal(self, q, k, v, fwd_map, mask, heads, scale):
         """trajectory-sharded temporal-guided pass: q, k, v local (chunk*n_loc, HW, C); returns the local rows"""

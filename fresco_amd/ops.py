@@ -229,14 +229,13 @@ def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, gro
     return out
 
 
-_a32_ws = {}
-
-
 def attention_f32(q, k, v, scale):
-    """softmax(scale * q k^T) v at fp32 accuracy (fresco_attn_f32 / fresco_attn_f32_ws): q (B,Lq,D), k (B,Lk,D),
-    v (B,Lk,Dv) -> (B,Lq,Dv).  One head; batch entries are independent problems (windows).  When several 128-query
-    workgroups share a key set (Lq >= 256) K and V are converted to the kernel's operand images once per launch, into a
-    workspace cached per device (grown on demand)."""
+    """softmax(scale * q k^T) v at fp32 accuracy (fresco_attn_f32_guarded): q (B,Lq,D), k (B,Lk,D), v (B,Lk,Dv) ->
+    (B,Lq,Dv).  One head; batch entries are independent problems (windows).  When several 128-query workgroups share a
+    key set (Lq >= 256) K and V are converted to the kernel's operand images once per launch, into a workspace taken from
+    the caching allocator PER CALL (stream-safe: two streams running the flow network never share it; nothing is kept).
+    No range limit: the split-fp16 kernels need |q scale log2 e|, |k|, |v| < 1000; a range pass on the device raises a
+    flag otherwise and the exact-fp32 MFMA kernel recomputes the launch (no host sync either way)."""
     _need_gpu(q, k, v)
     q, k, v = _f32c(q), _f32c(k), _f32c(v)
     B, Lq, D = q.shape
@@ -246,17 +245,11 @@ def attention_f32(q, k, v, scale):
     out = torch.empty(B, Lq, Dv, dtype=torch.float32, device=q.device)
     lib = _lib.load()
     need = lib.fresco_attn_f32_workspace_bytes(B, Lk, D, Dv) if Lq >= 256 else 0
-    if need:
-        ws = _a32_ws.get(q.device)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(need, dtype=torch.uint8, device=q.device)
-            _a32_ws[q.device] = ws
-        rc = lib.fresco_attn_f32_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B,
-                                    Lq, Lk, D, Dv, float(scale), _stream())
-    else:
-        rc = lib.fresco_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, Lk, D, Dv,
-                                 float(scale), _stream())
-    _lib.check(rc, "fresco_attn_f32(B=%d,Lq=%d,Lk=%d,D=%d,Dv=%d)" % (B, Lq, Lk, D, Dv))
+    ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need else None
+    flag = torch.empty(1, dtype=torch.int32, device=q.device)
+    rc = lib.fresco_attn_f32_guarded(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(ws), need,
+                                     flag.data_ptr(), B, Lq, Lk, D, Dv, float(scale), _stream())
+    _lib.check(rc, "fresco_attn_f32_guarded(B=%d,Lq=%d,Lk=%d,D=%d,Dv=%d)" % (B, Lq, Lk, D, Dv))
     return out
 
 

@@ -16,8 +16,34 @@ def flow_warp(feature, flow, mask=False, padding_mode="zeros"):
     return ops.flow_warp(feature, flow).to(feature.dtype)
 
 
+# flows / occs / saliency are constants of a batch of frames, but the hook calls optimize_feature + warp_tensor at 4
+# layers x 15 steps with them: the derived tensors (resized flows, pooled occlusions, resized + warped saliency) are kept
+# per (tensor identities, feature height).  An entry holds weak references to its source tensors and their versions: a
+# new tensor at a recycled address, or an in-place update, misses.
+_derived = {}
+
+
+def _cached(kind, srcs, extra, build):
+    import weakref
+    key = (kind, extra) + tuple((t.data_ptr(), tuple(t.shape), t._version, str(t.device)) for t in srcs)
+    hit = _derived.get(key)
+    if hit is not None and all(r() is t for r, t in zip(hit[0], srcs)):
+        return hit[1]
+    if len(_derived) > 32:
+        _derived.clear()
+    val = build()
+    _derived[key] = ([weakref.ref(t) for t in srcs], val)
+    return val
+
+
 def _prep_flow_occ(h, flows, occs, with_dilate):
-    """flow_utils.py:24-31 / diffusion_hacked.py:437-442: flows, occs at feature height h."""
+    """flow_utils.py:24-31 / diffusion_hacked.py:437-442: flows, occs at feature height h (cached per batch of frames:
+    the results are read-only for every consumer)."""
+    return _cached("flow_occ", (flows[0], flows[1], occs[0], occs[1]), (int(h), bool(with_dilate)),
+                   lambda: _prep_flow_occ_build(h, flows, occs, with_dilate))
+
+
+def _prep_flow_occ_build(h, flows, occs, with_dilate):
     H = flows[0].shape[2]
     scale = h * 1.0 / H
     kernel = int(1 / scale)
@@ -50,11 +76,15 @@ def warp_tensor(sample, flows, occs, saliency, unet_chunk_size, shard=None):
         return out.index_select(0, shard.local_batch_index().to(out.device)).contiguous()
     h = sample.shape[2]
     fwd_flow, bwd_flow, fwd_occ, bwd_occ = _prep_flow_occ(h, flows, occs, with_dilate=True)
-    scale2 = h * 1.0 / saliency.shape[2]
-    sal = ops.resize_bilinear(saliency, scale2)
     n = sample.shape[0] // unet_chunk_size
-    warp_sal = ops.flow_warp(sal, bwd_flow)
-    warp_sal_last = ops.flow_warp(sal[0:1], fwd_flow[n - 1:n])
+
+    def sal_terms():
+        scale2 = h * 1.0 / saliency.shape[2]
+        sal = ops.resize_bilinear(saliency, scale2)
+        return sal, ops.flow_warp(sal, bwd_flow), ops.flow_warp(sal[0:1], fwd_flow[n - 1:n])
+
+    sal, warp_sal, warp_sal_last = _cached("saliency", (saliency, flows[0], flows[1], occs[0], occs[1]), (int(h), int(n)),
+                                           sal_terms)
     lat = sample.to(torch.float32).contiguous().clone()
     ops.warp_fuse_chain(lat, bwd_flow, fwd_flow, bwd_occ, fwd_occ, sal, warp_sal, warp_sal_last,
                         unet_chunk_size)
@@ -63,9 +93,14 @@ def warp_tensor(sample, flows, occs, saliency, unet_chunk_size, shard=None):
 
 def calc_mean_std(feat, eps=1e-5, chunk=1):
     """utils.py:58-67: per-(sample, channel) mean and sqrt(unbiased variance + eps) over the plane, both (N, C, 1, 1).
-    (`chunk` is unused by the reference too.)  Runs on adain_kernel's reduction: fresco_chan_mean_std."""
+    Runs on adain_kernel's reduction: fresco_chan_mean_std.  chunk = 1 only (all the pipeline ever passes: AdaIN's
+    `chunk` lands in `eps`, utils.py:73): the reference's chunk = 2 branch concatenates the two CFG halves along the
+    width, takes joint statistics over N // 2 rows and then fails at its own `.view(N, C, 1, 1)` (utils.py:61-65)."""
     size = feat.size()
     assert len(size) == 4
+    if chunk != 1:
+        raise NotImplementedError("fresco_amd.calc_mean_std: chunk = 1 only (the reference's chunk = 2 branch raises at its "
+                                  "own view, src/utils.py:61-65)")
     mean, std = ops.chan_mean_std(feat, float(eps))
     return mean.view(size[0], size[1], 1, 1).to(feat.dtype), std.view(size[0], size[1], 1, 1).to(feat.dtype)
 

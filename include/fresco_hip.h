@@ -212,6 +212,15 @@ size_t fresco_attn_f32_workspace_bytes(int B, int Lk, int D, int Dv);
 int fresco_attn_f32_ws(const float* q, const float* k, const float* v, float* out, void* workspace,
                        size_t workspace_bytes, int B, int Lq, int Lk, int D, int Dv, float scale, void* stream);
 
+/* The same WITHOUT the range limit: a range pass over q, k, v raises *flag (one int32 of device memory the caller lends
+ * for the call) when any operand is beyond what the fp16 pieces can hold (|q scale log2 e|, |k|, |v| >= 1000) or not
+ * finite, and an exact-fp32 MFMA kernel behind the split-fp16 one then recomputes the launch (it returns at once when the
+ * flag is clear: in range the results are fresco_attn_f32's bit for bit).  workspace may be NULL (per-workgroup staging
+ * form).  This is the entry fresco_amd.ops.attention_f32 -- and with it the flow network -- uses. */
+int fresco_attn_f32_guarded(const float* q, const float* k, const float* v, float* out, void* workspace,
+                            size_t workspace_bytes, int* flag, int B, int Lq, int Lk, int D, int Dv, float scale,
+                            void* stream);
+
 /* forward_backward_consistency_check (gmflow/geometry.py:75-96) fused with the colour-difference
  * occlusion refinement of get_flow_and_interframe_paras (DH:919-926).  Pair n couples frame n with frame
  * (n+1) mod N: fwd_flow[n] maps frame n onto n+1, bwd_flow[n] the reverse; all fp32.

@@ -35,7 +35,7 @@ def _worker(rank, world, port, N, chunk, HW, C, ret):
         sel = sh.local_batch_index()
         kv_loc = torch.cat((K[sel], V[sel]), dim=-1).contiguous()  # fused K|V rows, the exchange layout
         ok = True
-        # (1) sparse cross-frame exchange, in both forms: ONE grouped launch of point-to-point transfers (default) and ONE
+        # (1) sparse cross-frame exchange, in both forms: ONE grouped launch of point-to-point transfers (opt-in) and ONE
         # broadcast of frame 0 (both CFG halves) + ONE all-gather of the other frames' selected rows; C-ABI addressing g*kv_group_rows + kv_table[m] into the flat (rows*chunk, 2C) exchange
         # buffer must give the reference's key rows
         rows = mask.reshape(-1).nonzero().squeeze(1)
@@ -55,7 +55,8 @@ def _worker(rank, world, port, N, chunk, HW, C, ret):
             # what crosses the fabric: frame 0 once + the padded selected rows, not every frame
             n_rest = int(mask[1:].sum()) if m_ is not None else 0
             assert buf.shape[0] <= HW + world * max(n_rest, 1) and buf.shape[0] < N * HW
-            assert sh.cf_collectives(plan) == (1 if p2p else (2 if plan["Rmax"] > 0 else 1))
+            assert sh.cf_collectives(plan, kv_loc) == (1 if p2p else (2 if plan["Rmax"] > 0 else 1))
+        assert FrameShard(N, chunk, rank, world).p2p_exchange is False  # the grouped form is opt-in until validated on RCCL
         sh.p2p_exchange = True
         # a NEW mask object at a recycled address must not hit the cached plan of the old one
         m1 = mask.clone()

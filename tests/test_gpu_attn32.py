@@ -69,3 +69,33 @@ def test_attention_f32_workspace_form_is_bit_identical():
         assert torch.equal(a, b), (B, Lq, Lk, D, Dv, float((a - b).abs().max()))
         assert float((a.cpu().double() - _ref(q.cpu(), k.cpu(), v.cpu(), 1.0 / math.sqrt(D))).abs().max()) < 2e-5 * max(1.0, float(a.abs().max()))
 
+
+
+@pytest.mark.parametrize("what", ["k", "v", "q"])
+@pytest.mark.parametrize("Lq", [96, 700])
+def test_attention_f32_operands_beyond_fp16_range(what, Lq):
+    """the split-fp16 kernels scale operands by 2^6 before the split, so |k|, |v|, |q scale log2 e| >= ~1000
+    overflow the hi piece to inf (NaN out of the MFMA).  The guarded entry's range pass must hand such a launch to the
+    exact-fp32 MFMA kernel: finite, fp32-accurate results for pixel-grid-like values of 5000 and features of 2000, in the
+    per-workgroup form (Lq < 256) and the workspace form; the same operands scaled into range take the split-fp16
+    kernels (bit-identical to fresco_attn_f32, test above)."""
+    import fresco_amd.ops as ops
+    g = synth.gen(123 + Lq)
+    B, Lk, D, Dv = 2, 300, 128, 2 if what == "v" else 64
+    q = torch.randn(B, Lq, D, generator=g)
+    k = torch.randn(B, Lk, D, generator=g)
+    v = torch.randn(B, Lk, Dv, generator=g)
+    scale = 1.0 / math.sqrt(D)
+    if what == "v":
+        v = v * 2000.0 + 5000.0
+    elif what == "k":   # one huge key coordinate, met by a tiny query coordinate: logits stay moderate
+        k[:, :, 0] = 2000.0
+        q[:, :, 0] *= 1e-3
+    else:
+        q[:, :, 1] = 9000.0
+        k[:, :, 1] *= 1e-3
+    out = ops.attention_f32(q.to(DEV), k.to(DEV), v.to(DEV), scale)
+    ref = _ref(q, k, v, scale)
+    assert bool(torch.isfinite(out).all())
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err

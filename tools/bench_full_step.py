@@ -1,10 +1,19 @@
-"""SURVEY.md 8d's second number: one FULL denoising step = the FRESCO hot path embedded in a stand-in SD-1.5 UNet +
-ControlNet (tools/standin_unet.py: diffusers' module tree and shapes, random fp16 weights) + classifier-free-guidance
-combine + a DDPM update, 8 frames x 512^2 (batch 16 with CFG), one MI355X.  Everything outside the hot path is
-PyTorch's own conv / GEMM / SDPA code, exactly as with the real model; the number says how much of a real step the
-hot path is, and what the step costs with (a) stock attention everywhere, (b) the reference's PyTorch op sequence in the
-six FRESCO layers (oracle/torch_path.py, the `torch_gpu_baseline` of bench.py), (c) fresco_amd's processor, (d) (c) +
-feature optimisation / warp at the four up-block inputs (config 3).
+"""SURVEY.md 8d's second number and the metric's second half, on a stand-in model (TEST / BENCH infrastructure):
+
+(1) one FULL denoising step = the FRESCO hot path embedded in a stand-in SD-1.5 UNet + ControlNet (tools/standin_unet.py:
+    diffusers' module tree and shapes, random fp16 weights) + classifier-free-guidance combine + the DDPM update,
+    8 frames x 512^2 (batch 16 with CFG), one MI355X, timed with (a) stock attention everywhere, (b) the reference's
+    PyTorch op sequence in the six FRESCO layers (oracle/torch_path.py), (c) fresco_amd's processor, (d) (c) + feature
+    optimisation / warp at the four up-block inputs (config 3);
+(2) `latent_delta`: BASELINE.json's "max latent delta vs ref" over the denoising loop of src/pipe_FRESCO.py:166-228 --
+    K steps of the reference's schedule (spatial+cf+temporal, then cf+temporal, then cf) from IDENTICAL initial latents,
+    weights, FRESCO parameters and per-step noise, once with fresco_amd's processor + fresco_amd.step and once with the
+    reference's op sequence (oracle/torch_path.processor_call + a plain-torch restatement of step(), :14-77) in the same
+    six layers.  Feature optimisation is off (it is chaotic by construction).  Reported for fp16
+    latents (the pipeline's dtype: ONE fp16 ulp of a latent in [2, 4) is already 1.95e-3, so any last-bit disagreement of
+    the two UNet outputs shows up as >= 1 ulp) and with the scheduler arithmetic kept in fp32 (isolates the hot path);
+    the yardstick beside it is the reference path against ITSELF with the six layers evaluated in fp32 (its own fp16
+    rounding noise through the same stand-in network).
 
     python tools/bench_full_step.py [frames] [res]
 """
@@ -28,10 +37,12 @@ from standin_unet import ControlNet, UNet  # noqa: E402
 
 
 class TorchPathProcessor:
-    """the reference's op sequence (oracle/torch_path.processor_call) behind the processor call protocol"""
+    """the reference's op sequence (oracle/torch_path.processor_call) behind the processor call protocol.
+    compute_dtype = torch.float32: the same sequence with the six layers evaluated in fp32 (noise yardstick)."""
 
-    def __init__(self, ctrl_state):
+    def __init__(self, ctrl_state, compute_dtype=None):
         self.s = ctrl_state
+        self.dt = compute_dtype
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, **kw):
         from oracle import torch_path as TP
@@ -40,11 +51,44 @@ class TorchPathProcessor:
         i = 0 if hw == s["hw"][0] else 1
         ref = s["refs"].pop(0) if s["mode"] == "full" else None
         temporal = s["mode"] in ("full", "cf_temporal")
-        return TP.processor_call(hidden_states, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
-                                 attn.to_out[0].weight, attn.to_out[0].bias, attn.heads, ref=ref, use_cf=True,
-                                 cf_mask=s["masks"][i], fwd_map=s["fwd"][i][:, 0] if temporal else None,
-                                 bwd_map=s["bwd"][i][:, 0] if temporal else None,
-                                 tmask=s["tmask"][i][:, 0] if temporal else None)
+        cast = (lambda t: t) if self.dt is None else (lambda t: None if t is None else t.to(self.dt))
+        out = TP.processor_call(cast(hidden_states), cast(attn.to_q.weight), cast(attn.to_k.weight), cast(attn.to_v.weight),
+                                cast(attn.to_out[0].weight), cast(attn.to_out[0].bias), attn.heads, ref=cast(ref), use_cf=True,
+                                cf_mask=s["masks"][i], fwd_map=s["fwd"][i][:, 0] if temporal else None,
+                                bwd_map=s["bwd"][i][:, 0] if temporal else None,
+                                tmask=s["tmask"][i][:, 0] if temporal else None)
+        return out.to(hidden_states.dtype)
+
+
+class Sched:
+    """what step() reads of diffusers' DDPMScheduler with SD-1.5's config (scaled-linear betas, 1000 training steps,
+    set_timesteps(20), steps_offset 1): previous_timestep, alphas_cumprod, one"""
+
+    def __init__(self):
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.one = torch.tensor(1.0)
+        self.timesteps = [951 - 50 * i for i in range(20)]
+
+    def previous_timestep(self, t):
+        return t - 50
+
+
+def reference_step(sched, model_output, timestep, sample, generator):
+    """src/pipe_FRESCO.py:14-77 in the reference's own torch ops (no background smoothing: saliency None), on whatever
+    dtype `sample` has: 0-dim fp32 coefficients times fp16 tensors stay fp16, as in the reference."""
+    prev_t = sched.previous_timestep(timestep)
+    a_t = sched.alphas_cumprod[timestep]
+    a_prev = sched.alphas_cumprod[prev_t] if prev_t >= 0 else sched.one
+    b_t, b_prev = 1 - a_t, 1 - a_prev
+    cur_a = a_t / a_prev
+    cur_b = 1 - cur_a
+    x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+    prev = (a_prev ** 0.5 * cur_b) / b_t * x0 + cur_a ** 0.5 * b_prev / b_t * sample
+    var = torch.clamp(b_prev / b_t * cur_b, min=1e-20)
+    var = (var ** 0.5) * torch.randn(model_output.shape, generator=generator, device=model_output.device,
+                                     dtype=model_output.dtype)
+    return prev + var
 
 
 def timed(fn, reps=3):
@@ -59,98 +103,174 @@ def timed(fn, reps=3):
     return 1e3 * sum(t) / len(t)
 
 
-def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    R = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-    dev = torch.device("cuda", 0)
-    torch.manual_seed(0)
-    B, lat = 2 * N, R // 8
-    unet = UNet().to(dev).half().eval()
-    cnet = ControlNet().to(dev).half().eval()
-    g = torch.Generator().manual_seed(0)
-    latents = torch.randn(N, 4, lat, lat, generator=g).half().to(dev)
-    ctx = torch.randn(B, 77, 768, generator=g).half().to(dev)
-    cond = torch.rand(B, 3, R, R, generator=g).half().to(dev)
-    params = {d: bench.synth_params(N, R // d, g, 0.004) for d in (8, 16)}
-    refs = [torch.randn(B, (R // 16) ** 2, 640, generator=g).half().to(dev) for _ in range(3)] + \
-           [torch.randn(B, (R // 8) ** 2, 320, generator=g).half().to(dev) for _ in range(3)]
-    paras = dict(fwd_mappings=[params[8][0].to(dev), params[16][0].to(dev)],
-                 bwd_mappings=[params[8][1].to(dev), params[16][1].to(dev)],
-                 interattn_masks=[params[8][2].to(dev), params[16][2].to(dev)])
-    masks = [params[8][3].to(dev), params[16][3].to(dev)]
-    fresco_layers = unet.fresco_self_attentions()
-    stock = [a.processor for a in fresco_layers]
+class Harness:
+    """stand-in UNet + ControlNet (initialised ON the GPU from a fixed seed) + the synthetic FRESCO parameters of bench.py"""
 
-    def one_step(t=900):
+    def __init__(self, N=8, R=512, dev="cuda", seed=0):
+        self.N, self.R, self.dev = N, R, torch.device(dev)
+        B, lat = 2 * N, R // 8
+        torch.manual_seed(seed)
+        with torch.device(self.dev):
+            self.unet = UNet().half().eval()
+            self.cnet = ControlNet().half().eval()
+        g = torch.Generator().manual_seed(seed)
+        self.g = g
+        lat0 = torch.randn(1, 4, lat, lat, generator=g).repeat(N, 1, 1, 1)  # repeat_noise: one initial latent for all frames (:152-153)
+        self.latents = lat0.half().to(self.dev)
+        self.ctx = torch.randn(B, 77, 768, generator=g).half().to(self.dev)
+        self.cond = torch.rand(B, 3, R, R, generator=g).half().to(self.dev)
+        params = {d: bench.synth_params(N, R // d, g, 0.004) for d in (8, 16)}
+        self.refs = [torch.randn(B, (R // 16) ** 2, 640, generator=g).half().to(self.dev) for _ in range(3)] + \
+                    [torch.randn(B, (R // 8) ** 2, 320, generator=g).half().to(self.dev) for _ in range(3)]
+        d = self.dev
+        self.paras = dict(fwd_mappings=[params[8][0].to(d), params[16][0].to(d)],
+                          bwd_mappings=[params[8][1].to(d), params[16][1].to(d)],
+                          interattn_masks=[params[8][2].to(d), params[16][2].to(d)])
+        self.masks = [params[8][3].to(d), params[16][3].to(d)]
+        self.layers = self.unet.fresco_self_attentions()
+        self.stock = [a.processor for a in self.layers]
+        self.ctrl = fresco_amd.AttentionControl()
+        self.proc = fresco_amd.FRESCOAttnProcessor2_0(2, self.ctrl)
+        self.st = dict(mode="cf", refs=[], masks=self.masks, hw=[(R // 8) ** 2, (R // 16) ** 2],
+                       fwd=self.paras["fwd_mappings"], bwd=self.paras["bwd_mappings"], tmask=self.paras["interattn_masks"])
+        self.sched = Sched()
+        self.pipe = types.SimpleNamespace(unet=self.unet, scheduler=self.sched)
+
+    def use(self, kind):
+        p = {"ours": self.proc, "ref": TorchPathProcessor(self.st), "ref32": TorchPathProcessor(self.st, torch.float32)}.get(kind)
+        for a, s in zip(self.layers, self.stock):
+            a.processor = p if p is not None else s
+        self.kind = kind
+
+    def set_mode(self, mode):
+        if self.kind == "ours":
+            bench.set_mode(self.ctrl, mode, list(self.refs), self.paras, self.masks)
+        else:
+            self.st["mode"], self.st["refs"] = mode, list(self.refs)
+
+    def eps(self, latents, t):
+        """controlnet + unet + classifier-free guidance (pipe_FRESCO.py:176-214)"""
+        x = torch.cat([latents] * 2)
+        down, mid = self.cnet(x, t, self.ctx, self.cond)
+        out = self.unet(x, t, self.ctx, down_block_additional_residuals=down, mid_block_additional_residual=mid,
+                        return_dict=False)[0]
+        eu, et = out.chunk(2)
+        return eu + 7.5 * (et - eu)
+
+    @torch.no_grad()
+    def loop(self, kind, modes, fp32_latents=False, noise_seed=1234):
+        """K = len(modes) steps of pipe_FRESCO.py:166-228 from self.latents; returns the latents after every step"""
+        self.use(kind)
+        gen = torch.Generator(device=self.dev).manual_seed(noise_seed)
+        lat = self.latents.float() if fp32_latents else self.latents.clone()
+        traj = []
+        for i, mode in enumerate(modes):
+            t = self.sched.timesteps[i]
+            self.set_mode(mode)
+            e = self.eps(lat.half(), t)
+            if fp32_latents:
+                e = e.float()
+            if kind == "ours":
+                lat = fresco_amd.step(self.pipe, e, t, lat, gen)[0]
+            else:
+                lat = reference_step(self.sched, e, t, lat, gen)
+            traj.append(lat.float().clone())
+        return traj
+
+
+LOOP_MODES = ["full", "cf_temporal", "cf_temporal", "cf", "cf", "cf"]
+
+
+def measure_latent_delta(h, modes=LOOP_MODES):
+    """max |latent(ours) - latent(reference op sequence)| after every step, fp16 and fp32 latents, + the reference path's
+    own fp16 noise (same op sequence with the six layers in fp32) as the yardstick"""
+    out = {}
+    for tag, f32 in (("fp16_latents", False), ("fp32_latents", True)):
+        ours = h.loop("ours", modes, f32)
+        ref = h.loop("ref", modes, f32)
+        ref32 = h.loop("ref32", modes, f32)
+        d = [float((a - b).abs().max()) for a, b in zip(ours, ref)]
+        dn = [float((a - b).abs().max()) for a, b in zip(ref, ref32)]
+        d32 = [float((a - b).abs().max()) for a, b in zip(ours, ref32)]
+        mean = float((ours[-1] - ref[-1]).abs().mean())
+        out[tag] = dict(max_abs_delta_per_step=[round(v, 6) for v in d], max_abs_delta=round(max(d), 6),
+                        mean_abs_delta_last_step=round(mean, 8),
+                        differing_elements_last_step=round(float((ours[-1] != ref[-1]).double().mean()), 6),
+                        reference_own_fp16_noise_per_step=[round(v, 6) for v in dn],
+                        ours_vs_reference_with_fp32_layers_per_step=[round(v, 6) for v in d32],
+                        latent_abs_max=round(float(ref[-1].abs().max()), 3))
+    out["steps"] = len(modes)
+    out["modes"] = modes
+    out["bar"] = 1e-3
+    out["note"] = ("ours = FRESCOAttnProcessor2_0 + fresco_amd.step; reference = oracle/torch_path.processor_call + the "
+                   "reference's step() in torch ops; same stand-in UNet + ControlNet (random fp16 weights), latents, "
+                   "FRESCO parameters and noise; feature optimisation off.  fp16 latents quantise to 9.8e-4 in [1, 2) and "
+                   "1.95e-3 in [2, 4): a last-bit difference of the UNet output is >= 1 ulp there; the fp32-latent rows keep "
+                   "the scheduler arithmetic in fp32 on both sides.  `reference_own_fp16_noise` = the reference op sequence "
+                   "against itself with the six layers in fp32")
+    h.use("stock")
+    return out
+
+
+def measure(N=8, R=512, dev="cuda", with_opt=True, with_delta=True, verbose=False):
+    h = Harness(N, R, dev)
+    B = 2 * N
+    g = h.g
+
+    def one_step(t=901):
         with torch.no_grad():
-            x = torch.cat([latents] * 2)  # classifier-free guidance: batch (cfg_half, frame)
-            down, mid = cnet(x, t, ctx, cond)
-            out = unet(x, t, ctx, down_block_additional_residuals=down, mid_block_additional_residual=mid,
-                       return_dict=False)[0]
-            eu, et = out.chunk(2)
-            eps = eu + 7.5 * (et - eu)
-            return latents - 0.1 * eps  # stand-in for the scheduler's elementwise update (pipe_FRESCO.step: ours in fresco_amd.step)
+            e = h.eps(h.latents, t)
+            return fresco_amd.step(h.pipe, e, t, h.latents, None)[0]
 
-    res = dict(workload="full denoising step: stand-in SD-1.5 UNet + ControlNet (random fp16 weights), %d frames %dx%d, "
-                        "CFG batch %d" % (N, R, R, B))
-    # (a) stock attention everywhere
+    res = dict(workload="full denoising step: stand-in SD-1.5 UNet + ControlNet (random fp16 weights; everything outside "
+                        "the six FRESCO layers is PyTorch / MIOpen / hipBLASLt), %d frames %dx%d, CFG batch %d, CFG combine "
+                        "+ fresco_amd.step" % (N, R, R, B))
+    h.use("stock")
     res["stock_attention_ms"] = round(timed(one_step), 2)
-
-    # (c) fresco_amd processor on the six decoder self-attentions, per attention mode of the schedule
-    ctrl = fresco_amd.AttentionControl()
-    proc = fresco_amd.FRESCOAttnProcessor2_0(2, ctrl)
-    for a in fresco_layers:
-        a.processor = proc
-    ours = {}
-    for mode in ("full", "cf_temporal", "cf"):
-        def run(mode=mode):
-            bench.set_mode(ctrl, mode, list(refs), paras, masks)
-            return one_step()
-        ours[mode] = timed(run)
     sched = bench.SCHEDULE
-    res["fresco_amd_ms"] = {k: round(v, 2) for k, v in ours.items()}
-    res["fresco_amd_schedule_mean_ms"] = round(sum(ours[m] for m in sched) / len(sched), 2)
-
-    # (b) the reference's PyTorch op sequence in the same six layers
-    st = dict(mode="cf", refs=[], masks=masks, hw=[(R // 8) ** 2, (R // 16) ** 2],
-              fwd=paras["fwd_mappings"], bwd=paras["bwd_mappings"], tmask=paras["interattn_masks"])
-    tproc = TorchPathProcessor(st)
-    for a in fresco_layers:
-        a.processor = tproc
-    theirs = {}
-    for mode in ("full", "cf_temporal", "cf"):
-        def run(mode=mode):
-            st["mode"], st["refs"] = mode, list(refs)
-            return one_step()
-        theirs[mode] = timed(run, reps=2)
-    res["reference_torch_path_ms"] = {k: round(v, 2) for k, v in theirs.items()}
-    res["reference_torch_path_schedule_mean_ms"] = round(sum(theirs[m] for m in sched) / len(sched), 2)
+    for kind, key, reps in (("ours", "fresco_amd", 3), ("ref", "reference_torch_path", 2)):
+        h.use(kind)
+        t_mode = {}
+        for mode in ("full", "cf_temporal", "cf"):
+            def run(mode=mode):
+                h.set_mode(mode)
+                return one_step()
+            t_mode[mode] = timed(run, reps=reps)
+        res[key + "_ms"] = {k: round(v, 2) for k, v in t_mode.items()}
+        res[key + "_schedule_mean_ms"] = round(sum(t_mode[m] for m in sched) / len(sched), 2)
     res["full_step_speedup_vs_reference_path"] = round(res["reference_torch_path_schedule_mean_ms"]
                                                        / res["fresco_amd_schedule_mean_ms"], 2)
+    res["hot_path_share_ms"] = dict(
+        ours=round(res["fresco_amd_schedule_mean_ms"] - res["stock_attention_ms"], 2),
+        reference=round(res["reference_torch_path_schedule_mean_ms"] - res["stock_attention_ms"], 2),
+        note="difference to the same step with stock SDPA in the six layers (which itself costs ~2 ms there)")
+    if with_opt:
+        # (d) ours + feature optimisation / warp at the four up-block inputs (config 3: every layer, 20 iterations)
+        h.use("ours")
+        flows, occs, sal = bench_opt._inputs(N, R, h.dev, g)
+        targets = []
+        for (C, hh) in bench_opt.LAYERS:
+            targets.append(ops.gram_target(torch.randn(B, C, hh * R // 512, hh * R // 512, generator=g).to(h.dev)))
+        fresco_amd.apply_FRESCO_opt(h.pipe, steps=torch.tensor([901]), layers=[0, 1, 2, 3], flows=flows, occs=occs,
+                                    correlation_matrix=targets, saliency=sal)
 
-    # (d) ours + feature optimisation / warp at the four up-block inputs (config 3: every layer, 20 iterations)
-    for a in fresco_layers:
-        a.processor = proc
-    flows, occs, sal = bench_opt._inputs(N, R, dev, g)
-    targets = []
-    for (C, h) in bench_opt.LAYERS:
-        targets.append(ops.gram_target(torch.randn(B, C, h * R // 512, h * R // 512, generator=g).to(dev)))
-    pipe = types.SimpleNamespace(unet=unet)
-    fresco_amd.apply_FRESCO_opt(pipe, steps=torch.tensor([900]), layers=[0, 1, 2, 3], flows=flows, occs=occs,
-                                correlation_matrix=targets, saliency=sal)
-
-    def run_opt():
-        bench.set_mode(ctrl, "cf_temporal", list(refs), paras, masks)
-        return one_step(900)
-    res["fresco_amd_with_optimisation_ms"] = round(timed(run_opt, reps=2), 2)
-    fresco_amd.disable_FRESCO_opt(pipe)
-    for a, p in zip(fresco_layers, stock):
-        a.processor = p
-    res["note"] = ("the hot-path step of bench.py (2.2 ms at 8 x 512^2) is the difference between fresco_amd_ms and what "
-                   "the same six layers cost otherwise; everything else in these numbers is PyTorch / MIOpen / hipBLASLt "
-                   "running a random-weight model of SD-1.5's shapes")
-    print(json.dumps(res))
+        def run_opt():
+            h.set_mode("cf_temporal")
+            return one_step(901)
+        res["fresco_amd_with_optimisation_ms"] = round(timed(run_opt, reps=2), 2)
+        fresco_amd.disable_FRESCO_opt(h.pipe)
+        if "forward" in h.unet.__dict__:
+            del h.unet.__dict__["forward"]
+        del targets
+    if with_delta:
+        res["latent_delta"] = measure_latent_delta(h)
+    h.use("stock")
+    if verbose:
+        print(json.dumps(res, indent=1))
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    print(json.dumps(measure(N, R)))
