@@ -77,6 +77,9 @@ def build_workload(N, R, device, seed=0):
     import synth
 
     gen = torch.Generator().manual_seed(seed)
+    # the projection weights come from torch's GLOBAL generator (nn.Linear's default init): seed it, or every rank of a
+    # multi-process run projects with its own weights (found by the sharded-vs-single-GPU check of round 5: deltas of 2e-2)
+    torch.manual_seed(seed)
     B = 2 * N
     params = {}
     for down in (8, 16):

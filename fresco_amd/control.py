@@ -1,9 +1,10 @@
 """AttentionControl: mode flags + reference-feature store of FRESCO-guided attention.
 
-Same public attributes, methods and state transitions as the reference class
-(src/diffusion_hacked.py:23-137): the denoising loop (src/pipe_FRESCO.py:171-174) and the batch driver
-(run_fresco.py:231) toggle it by name, and the shared processor relies on the cyclic read index that
-advances once per self-attention layer.
+This file is a RESTATEMENT of the reference class (src/diffusion_hacked.py:23-137), method for method: SURVEY.md row a5
+asks for the state machine verbatim, because it IS the plugin surface -- the denoising loop (src/pipe_FRESCO.py:171-174)
+and the batch driver (run_fresco.py:231) toggle it by attribute and method name, and the shared processor relies on the
+cyclic read index that advances once per self-attention layer.  Nothing here computes;
+it is checked against a trace recorded from the reference class (tests/golden/control_trace.json).
 """
 import gc
 

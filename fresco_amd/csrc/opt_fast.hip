@@ -606,7 +606,7 @@ __device__ __forceinline__ float gram_sign_epilogue(const floatx16 (&acc)[2][2],
 // LDS fragments for 12 MFMAs; round 3's 128 x 128 / 64 x 32 form: 6 for 6), TWO workgroups per CU.  A first form with one
 // workgroup per CU (K chunks of 32 in a 3 x 48 KB ring, targets prefetched into 64 registers; removed, see git history)
 // measured 559 us at (640, 64^2) with the matrix pipe busy 44 %: its DMA waits, target stream and 6 us sign / store
-// epilogue overlapped with nothing (ablations: profiles/r04_gram_ablation.txt, PMC: profiles/r04_pmc_opt_gram16x.csv).
+// epilogue overlapped with nothing (ablations: profiles/r04_gram_ablation.txt, PMC of that removed kernel: profiles/r04_pmc_removed_gram16x_kernel.csv; the shipped kernels: profiles/r05_pmc_opt_*.csv).
 // This form: 478 us when written, 447 - 462 us with the epilogue of gram_sign_epilogue (above).
 //   * K chunks of 16 channels: a slot is six 4 KB blocks (24 KB), three slots = 72 KB per workgroup -> two per CU;
 //     operands pre-tiled by prep as [plane][128-pixel tile][16-channel chunk][128][2 x 16 B], the two units of pixel row r
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
 // Round 4: LDS rows WITHOUT pad bytes (V 64 B, S 32 B): the producers store both operands swizzled -- 16-byte unit u
 // of V row c at u ^ ((c >> 2) & 3), 8-byte unit u of S row p at u ^ ((p >> 3) & 3) -- so a slot is 24 linear 1 KiB DMA
 // pieces (3 per wave; 32 with the pad chunks before: -25 % bytes and DMA issues per MFMA), fragment reads stay
-// conflict-free (the padded S rows had 2-way conflicts: 25 % of the LDS cycles, profiles/r04_pmc_opt_gram16x.csv), and
+// conflict-free (the padded S rows had 2-way conflicts: 25 % of the LDS cycles, profiles/r04_pmc_removed_gram16x_kernel.csv), and
 // three slots (72 KB) fit twice per CU: chunks arrive two steps ahead.
 // ------------------------------------------------------------------------------------------------
 constexpr int SB_TC = 128, SB_K = 32;

@@ -54,7 +54,11 @@ def test_opt_closure_and_20_iterations_at_cfg4_cfg5_shapes(N, R, C, h):
     scale = float(grad_ref.abs().max())
     frac_bad = float((err > 1e-3 * scale).double().mean())
     assert frac_bad <= 2e-4 * max(h * h / 256.0, 1.0), frac_bad
-    assert float(err.max()) <= 5e-2 * scale, (float(err.max()), scale)
+    # worst element: a flipped Gram sign moves an element by a few per cent of the scale at most; ONE flipped residual sign of
+    # the temporal term (a residual within fp32 rounding of zero: ~3 of the 94 M elements at 96 x 96) moves its element by
+    # 2 * 2 / (B C hw) whatever the scale is -- at hw = 9216 the Gram gradient is so small (1 / hw^2) that this is 30 % of it
+    flip_t = 2.0 * 2.0 / (2 * N * C * h * h)
+    assert float(err.max()) <= max(5e-2 * scale, 2.1 * flip_t), (float(err.max()), scale, flip_t)
     del grad_ref, err
     # (ii) the pipeline's 20 Adam iterations: loss reached within 1 % of the oracle's loop (fp32, analytic gradients,
     # evaluated by torch on the GPU), both end points scored by the oracle's fp64 loss; two runs bit-identical

@@ -105,9 +105,9 @@ def test_closure_odd_plane_sizes(h, w):
 @pytest.mark.parametrize("C,h,w", [(128, 16, 16), (128, 16, 32), (96, 16, 24), (256, 24, 32), (64, 8, 16), (256, 32, 32)])
 def test_closure_whole_tile_planes(C, h, w, env, monkeypatch):
     """the four-launch pipeline (opt_fast.hip) on its kernel variants: hw = 256 -> gram16s (64 x 64 tiles, split K) +
-    the tiled 128 x 256 S V kernel; hw = 512, C = 128 -> gram16x (256 x 128 tiles, LDS-DMA ring) with a K loop too short
+    the tiled 128 x 256 S V kernel; hw = 512, C = 128 -> gram16y (256 x 128 tiles, LDS-DMA ring) with a K loop too short
     for its counted-wait schedule + tiled S V; hw = 384 -> the generic plain-layout Gram kernel + the 128 x 128 S V kernel;
-    hw = 768, C = 256 -> gram16x with the counted schedule on a plane that is not whole super-tiles; hw = 128 -> gram16s
+    hw = 768, C = 256 -> gram16y with the counted schedule on a plane that is not whole super-tiles; hw = 128 -> gram16s
     with 8 waves (the full-size grids are covered at the shipping shapes, test_gpu_fullsize.py); hw = 1024 -> the super-tile
     walk.  `env`: default (launches this small take the 128 x 128 Gram tiles of gram16z) and the 256-row Gram kernel forced."""
     for k, v in env.items():

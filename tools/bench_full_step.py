@@ -194,6 +194,7 @@ def measure_latent_delta(h, modes=LOOP_MODES):
         d32 = [float((a - b).abs().max()) for a, b in zip(ours, ref32)]
         mean = float((ours[-1] - ref[-1]).abs().mean())
         out[tag] = dict(max_abs_delta_per_step=[round(v, 6) for v in d], max_abs_delta=round(max(d), 6),
+                        ratio_to_reference_own_fp16_noise_per_step=[round(a / max(b, 1e-12), 3) for a, b in zip(d, dn)],
                         mean_abs_delta_last_step=round(mean, 8),
                         differing_elements_last_step=round(float((ours[-1] != ref[-1]).double().mean()), 6),
                         reference_own_fp16_noise_per_step=[round(v, 6) for v in dn],
@@ -201,7 +202,9 @@ def measure_latent_delta(h, modes=LOOP_MODES):
                         latent_abs_max=round(float(ref[-1].abs().max()), 3))
     out["steps"] = len(modes)
     out["modes"] = modes
-    out["bar"] = 1e-3
+    out["bar"] = ("per step: delta <= 1.5 x the reference path's own fp16 noise + 1e-3 (tests/test_gpu_latent_delta.py); the north "
+                  "star's absolute 1e-3 holds per layer call (torch_gpu_baseline.max_abs_delta), not over a loop: the reference op "
+                  "sequence against itself with the six layers in fp32 is 1.3e-2 apart after ONE step on this network")
     out["note"] = ("ours = FRESCOAttnProcessor2_0 + fresco_amd.step; reference = oracle/torch_path.processor_call + the "
                    "reference's step() in torch ops; same stand-in UNet + ControlNet (random fp16 weights), latents, "
                    "FRESCO parameters and noise; feature optimisation off.  fp16 latents quantise to 9.8e-4 in [1, 2) and "

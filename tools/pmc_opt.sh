@@ -1,6 +1,7 @@
 #!/bin/bash
-# PMC counter passes over optimize_feature (config 3) at the largest decoder layer (C = 640, 64 x 64, 8 frames): HBM-side
-# bytes per launch of every opt kernel (separate passes, kernel-trace only).  usage: bash tools/pmc_opt.sh <tag>
+# PMC counter passes over optimize_feature (config 3) at one decoder layer (LAYER=3: C = 640, 64 x 64 (default); 2: C = 1280,
+# 32 x 32; 1: 16 x 16; 0: 8 x 8; 8 frames): HBM-side bytes, matrix-pipe / LDS counters per launch of every opt kernel
+# (separate passes, kernel-trace only).  usage: LAYER=3 bash tools/pmc_opt.sh <tag>
 TAG=${1:-p}
 REPO=$PWD
 OUT=$PWD/gpurun_out/pmco_$TAG
@@ -13,8 +14,10 @@ from fresco_amd import ops
 g = torch.Generator().manual_seed(0)
 N, R, dev = 8, 512, "cuda"
 flows, occs, sal = bench_opt._inputs(N, R, dev, g)
-x = torch.randn(2 * N, 640, 64, 64, generator=g).half().to(dev)
-tgt = ops.gram_target(torch.randn(2 * N, 640, 64, 64, generator=g).to(dev))
+import os
+C, h = bench_opt.LAYERS[int(os.environ.get("LAYER", "3"))]
+x = torch.randn(2 * N, C, h, h, generator=g).half().to(dev)
+tgt = ops.gram_target(torch.randn(2 * N, C, h, h, generator=g).to(dev))
 for _ in range(2):
     fresco_amd.optimize_feature(x, flows, occs, [tgt], iters=5)
 torch.cuda.synchronize()
@@ -23,6 +26,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 export FRESCO_OPT_SPLIT=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  [ $i -ge ${PASSES:-5} ] && break
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python $OUT/run.py $REPO > $OUT/pass$i.log 2>&1
 done
