@@ -201,7 +201,7 @@ class FRESCOAttnProcessor2_0:
                     raise ValueError("fresco_amd: attention_mask is not supported in the frame-sharded FRESCO branch")
                 return self._sharded_self_attention(attn, hidden_states, residual, input_ndim)
             sparse_kv = (self.sparse_kv_projection and bool(ctrl) and ctrl.use_cfattn and not ctrl.use_interattn
-                         and hidden_states.shape[0] % self.unet_chunk_size == 0)
+                         and mask_bias is None and hidden_states.shape[0] % self.unet_chunk_size == 0)
             if sparse_kv:
                 # (the row table below is built from the mask's own (frame, pixel) grid and handed to the kernel
                 # unchecked: a mask of another batch size takes the general path, whose row table IS bounds-checked)
@@ -256,14 +256,21 @@ class FRESCOAttnProcessor2_0:
         # main pass: efficient cross-frame attention (225-247, 303-305) or plain attention
         if mask_bias is not None:
             if fresco and ctrl.use_cfattn:
-                # DELIBERATE NARROWING: with controller.attn_mask set the reference hands SDPA a mask shaped for
-                # `sequence_length` keys next to M != sequence_length cross-frame keys (:303-305) and cannot run either;
-                # with controller.attn_mask None (every frame attends to frame 0's HW keys, :227-234) its SDPA would accept
-                # the mask -- a combination the pipeline never produces (src/pipe_FRESCO.py:201-209) and this side path
-                # does not implement
-                raise ValueError("fresco_amd: attention_mask cannot be combined with cross-frame attention "
-                                 "(the mask addresses %d keys, the cross-frame pass has another key set)" % mask_bias.shape[-1])
-            hs = self._masked_attention(q_att, key, value, heads, sm_scale, mask_bias)
+                if self._cf_mask(ctrl, key.shape[1]) is not None or sparse_kv:
+                    # with a controller.attn_mask of this scale the reference hands SDPA a mask shaped for
+                    # `sequence_length` keys next to M != sequence_length cross-frame keys (:239-247, 303-305) and cannot
+                    # run either
+                    raise ValueError("fresco_amd: attention_mask cannot be combined with the masked cross-frame key set "
+                                     "(the mask addresses %d keys, the cross-frame pass has another key set)" % mask_bias.shape[-1])
+                # controller.attn_mask None (or no mask of this scale): every frame attends to frame 0's HW keys
+                # (former_frame_index = [0] * N, :227, 237, 244) and the mask addresses exactly those: the reference's
+                # SDPA accepts it, so do we (a combination the pipeline never produces, src/pipe_FRESCO.py:201-209)
+                nf = key.shape[0] // chunk
+                k0 = key.view(chunk, nf, key.shape[1], -1)[:, :1].expand(-1, nf, -1, -1).reshape(key.shape)
+                v0 = value.view(chunk, nf, value.shape[1], -1)[:, :1].expand(-1, nf, -1, -1).reshape(value.shape)
+                hs = self._masked_attention(q_att, k0, v0, heads, sm_scale, mask_bias)
+            else:
+                hs = self._masked_attention(q_att, key, value, heads, sm_scale, mask_bias)
         elif fresco and ctrl.use_cfattn and sparse_kv:
             hs = ops.attention(q_att, key, value, heads, sm_scale, n_groups=chunk, M=key.shape[1],
                                group_rows=key.shape[1], workspace=self._ws)

@@ -427,12 +427,34 @@ def test_processor_attention_mask(C, heads, kind):
                        attention_mask=mask.to(DEV))
             ref = ref_call(x, enc, bias)
         _check(out, ref, atol=1e-3, rtol=2e-3, what="mask %s cross=%d D=%d" % (kind, cross, D))
-    # together with cross-frame attention the reference cannot use a mask either: rejected
+    # together with a cross-frame key MASK of this scale the reference cannot use an attention_mask either: rejected
     ctrl = fresco_amd.AttentionControl()
     ctrl.enable_cfattn([torch.ones(1, L, dtype=torch.bool, device=DEV)])
     procf = fresco_amd.FRESCOAttnProcessor2_0(1, ctrl)
     with pytest.raises(ValueError):
         procf(dev_attn, torch.randn(1, L, C).half().to(DEV), attention_mask=torch.zeros(1, L, device=DEV))
+    # ... but with controller.attn_mask None every frame attends to frame 0's keys and the mask addresses exactly those
+    # (reference :227-247, 303-305: its SDPA accepts it): frame f's output = masked attention of its queries over frame 0's
+    # K / V of the same CFG half
+    ctrl0 = fresco_amd.AttentionControl()
+    ctrl0.use_cfattn = True
+    assert ctrl0.attn_mask is None
+    proc0 = fresco_amd.FRESCOAttnProcessor2_0(2, ctrl0)
+    nf = 3
+    x = torch.randn(2 * nf, L, C, generator=g).half()
+    keep = torch.rand(2 * nf, L, generator=g) < 0.7
+    keep[:, 0] = True
+    bias = (1 - keep.float()) * -10000.0 + 0.5 * torch.randn(2 * nf, L, generator=g)
+    with torch.no_grad():
+        out = proc0(dev_attn, x.to(DEV), attention_mask=bias.to(DEV))
+    q = (x.float() @ attn.to_q.weight.T).half().float()
+    k = (x.float() @ attn.to_k.weight.T).half().float().view(2, nf, L, C)[:, :1].expand(-1, nf, -1, -1).reshape(2 * nf, L, C)
+    v = (x.float() @ attn.to_v.weight.T).half().float().view(2, nf, L, C)[:, :1].expand(-1, nf, -1, -1).reshape(2 * nf, L, C)
+    qh, kh, vh = (t.view(2 * nf, L, heads, D).transpose(1, 2) for t in (q, k, v))
+    sc = qh @ kh.transpose(-1, -2) / math.sqrt(D) + bias[:, None, None, :]
+    o = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(2 * nf, L, C).half().float()
+    ref0 = o @ attn.to_out[0].weight.T + attn.to_out[0].bias
+    _check(out, ref0, atol=1e-3, rtol=2e-3, what="mask + cross-frame (frame 0 keys) D=%d" % D)
 
 
 @pytest.mark.parametrize("C,heads", [(256, 8), (512, 8), (320, 8)])
