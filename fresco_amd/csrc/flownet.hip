@@ -1,0 +1,503 @@
+// The flow network's dense layers: GMFlow's CNN encoder, transformer projections / FFN / LayerNorms and
+// upsampler head (reference: src/ebsynth/deps/gmflow/gmflow/backbone.py:7-117, transformer.py:111-237, gmflow.py:44-90),
+// which rounds 1-4 left to MIOpen / rocBLAS (85 % of the forward).  Everything is fp32 in and fp32 out -- the flows feed
+// integer decisions (occlusion thresholds, pixel correspondences) -- but the products run on the fp16 matrix pipe the way
+// attn32.hip's do: every fp32 operand x is split x = xh + xl into two halfs and a b is taken as ah bh + ah bl + al bh
+// (three v_mfma_f32_32x32x16_f16 per 16 contraction steps; the dropped al bl term is < 2^-22 relative; fp32 accumulation).
+//
+// Data layout: activations are NHWC = (rows m = (image, y, x), channels) row-major, which IS the token layout (B, L, C) of
+// the transformer -- no transposes between the encoder and the attention layers.  A tensor that feeds a product exists as a
+// PAIR of fp16 planes (hi, lo) written by its producer (fn_prep_kernel / fn_layernorm_kernel / the GEMM epilogue), so the
+// GEMM's loaders move 16-byte pieces of ready operands and no conversion sits between the loads and the MFMAs.
+//
+//   fn_gemm_kernel<BN>   out[m][n] = sum_k A(m, k) W[n][k] (+ bias, GELU / ReLU), A either row-major (linear layers) or the
+//                        implicit im2col view of an NHWC tensor (k = (ky, kx, ci), zero padding): 128 x BN x 32 tiles,
+//                        4 waves, operands double-buffered in LDS (80-byte rows: conflict-free ds_read_b128), fp32 result
+//                        and / or its (hi, lo) split written by the epilogue
+//   fn_colstats_kernel   InstanceNorm2d statistics: mean and 1 / sqrt(biased var + eps) per (image, channel), fp64 partial
+//                        sums in a fixed order (deterministic)
+//   fn_prep_kernel       y = [relu]( [relu]((x - mean) rstd) + residual ) -> fp32 and / or (hi, lo), channel-padded rows
+//   fn_layernorm_kernel  LayerNorm over 128 channels (+ residual), one wave per row
+//   fn_conv7_rgb_kernel  the 7 x 7 / stride 2 stem on 3 input channels: direct fp32 FMAs (K = 147 is no MFMA shape)
+#include "common.h"
+
+namespace fresco {
+
+// x * scale = h + l.  The matrix pipe FLUSHES fp16 subnormals (attn32.hip), so a lo piece below 6.1e-5 would be lost and the
+// operand would be no better than fp16: every plane is written pre-scaled by a power of two -- activations by 2^6 (lo pieces
+// stay normal down to |x| = 2e-3, values up to 1000 fit), weights by 2^10 (|w| from 1.2e-4 to 60) -- and the GEMM scales its
+// fp32 accumulators back exactly.  Beyond the range the scaled value saturates (finite, wrong) instead of becoming inf / NaN.
+__device__ __forceinline__ void fn_split(float x, float scale, half_t& h, half_t& l) {
+    x = fminf(fmaxf(x * scale, -65000.f), 65000.f);
+    h = (half_t)x;
+    l = (half_t)(x - (float)h);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+struct FnConv {  // implicit-GEMM view of an NHWC tensor; kh == 0: A is a plain row-major matrix
+    int kh, kw, stride, pad, H, W, OH, OW, cin;  // cin = channels per pixel of the (padded) input rows
+};
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restrict__ a_hi, const half_t* __restrict__ a_lo,
+                                                         int64_t lda, FnConv cv, const half_t* __restrict__ w_hi,
+                                                         const half_t* __restrict__ w_lo, const float* __restrict__ bias,
+                                                         float* __restrict__ out, half_t* __restrict__ o_hi,
+                                                         half_t* __restrict__ o_lo, int64_t ldc, int64_t ldo, int M, int N,
+                                                         int K, int act, float acc_scale, float split_scale) {
+    constexpr int BM = 128, BK = 32;
+    constexpr int ROW = BK * 2 + 16;            // LDS bytes per operand row (5 x 16 B: conflict-free b128 reads)
+    constexpr int A_BYTES = BM * ROW, W_BYTES = BN * ROW;
+    constexpr int STAGE = 2 * A_BYTES + 2 * W_BYTES;
+    constexpr int WN = BN / 2;                  // wave tile: 64 rows x WN columns (waves 2 x 2)
+    constexpr int NB = WN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- loaders: 16-byte pieces.  A tile: 128 rows x 4 pieces (x hi, lo); W tile: BN rows x 4 pieces
+    constexpr int APT = BM * 4 / 256;           // A pieces per thread and plane (2)
+    constexpr int WPT = BN * 4 / 256;           // W pieces per thread and plane (2 or 1)
+    int a_row[APT], a_pc[APT];
+    int64_t a_base[APT];                        // row-major: element offset of the row; conv: pixel (img, oy*s - p, ox*s - p)
+    int a_iy[APT], a_ix[APT];
+    bool a_ok[APT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int id = tid + i * 256;
+        a_row[i] = id >> 2;
+        a_pc[i] = id & 3;
+        const int m = m0 + a_row[i];
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        if (cv.kh == 0) {
+            a_base[i] = (int64_t)mm * lda;
+            a_iy[i] = a_ix[i] = 0;
+        } else {
+            const int ohw = cv.OH * cv.OW;
+            const int img = mm / ohw, r = mm - img * ohw;
+            const int oy = r / cv.OW, ox = r - oy * cv.OW;
+            a_iy[i] = oy * cv.stride - cv.pad;
+            a_ix[i] = ox * cv.stride - cv.pad;
+            a_base[i] = (int64_t)img * cv.H * cv.W;
+        }
+    }
+    int w_row[WPT], w_pc[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int id = tid + i * 256;
+        w_row[i] = id >> 2;
+        w_pc[i] = id & 3;
+    }
+    const int nk = K / BK;
+    half8_t ra_h[APT], ra_l[APT], rw_h[WPT], rw_l[WPT];
+    const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto gload = [&](int kc) __attribute__((always_inline)) {
+        const int k0 = kc * BK;
+        int ky = 0, kx = 0, c0 = k0;
+        if (cv.kh != 0) {  // a 32-channel chunk lies inside one (ky, kx): cin % 32 == 0
+            const int t = k0 / cv.cin;
+            c0 = k0 - t * cv.cin;
+            ky = t / cv.kw;
+            kx = t - ky * cv.kw;
+        }
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            bool ok = a_ok[i];
+            int64_t off;
+            if (cv.kh == 0) {
+                off = a_base[i] + k0 + a_pc[i] * 8;
+            } else {
+                const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+                ok = ok && iy >= 0 && iy < cv.H && ix >= 0 && ix < cv.W;
+                off = (a_base[i] + (int64_t)iy * cv.W + ix) * lda + c0 + a_pc[i] * 8;
+            }
+            ra_h[i] = ok ? *reinterpret_cast<const half8_t*>(a_hi + off) : zero8;
+            ra_l[i] = ok ? *reinterpret_cast<const half8_t*>(a_lo + off) : zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int n = n0 + w_row[i];
+            const bool ok = n < N;
+            const int64_t off = (int64_t)(ok ? n : 0) * K + k0 + w_pc[i] * 8;
+            rw_h[i] = ok ? *reinterpret_cast<const half8_t*>(w_hi + off) : zero8;
+            rw_l[i] = ok ? *reinterpret_cast<const half8_t*>(w_lo + off) : zero8;
+        }
+    };
+    auto sstore = [&](int stage) __attribute__((always_inline)) {
+        char* s = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            *reinterpret_cast<half8_t*>(s + a_row[i] * ROW + a_pc[i] * 16) = ra_h[i];
+            *reinterpret_cast<half8_t*>(s + A_BYTES + a_row[i] * ROW + a_pc[i] * 16) = ra_l[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            *reinterpret_cast<half8_t*>(s + 2 * A_BYTES + w_row[i] * ROW + w_pc[i] * 16) = rw_h[i];
+            *reinterpret_cast<half8_t*>(s + 2 * A_BYTES + W_BYTES + w_row[i] * ROW + w_pc[i] * 16) = rw_l[i];
+        }
+    };
+
+    floatx16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int st = kc & 1;
+        if (kc + 1 < nk) gload(kc + 1);  // in flight under the MFMAs of this chunk
+        const char* s = smem + st * STAGE;
+        const char* sa = s + (wm * 64 + l31) * ROW + hi * 16;
+        const char* sw = s + 2 * A_BYTES + (wn * WN + l31) * ROW + hi * 16;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            half8_t ah[2], al[2], bh[NB], bl[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const half8_t*>(sa + i * 32 * ROW + ks * 32);
+                al[i] = *reinterpret_cast<const half8_t*>(sa + A_BYTES + i * 32 * ROW + ks * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                bh[j] = *reinterpret_cast<const half8_t*>(sw + j * 32 * ROW + ks * 32);
+                bl[j] = *reinterpret_cast<const half8_t*>(sw + W_BYTES + j * 32 * ROW + ks * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < nk) {
+            sstore(st ^ 1);  // (the other stage was last read before the barrier that ended chunk kc - 1)
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: lane (l31, hi) holds column n = .. + l31 and rows (r & 3) + 8 (r >> 2) + 4 hi of each 32 x 32 block
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n >= N) continue;
+        const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m >= M) continue;
+                float v = acc[i][j][r] * acc_scale + b;
+                if (act == 1) v = fmaxf(v, 0.f);
+                if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU() (exact, erf form)
+                if (out) out[(int64_t)m * ldc + n] = v;
+                if (o_hi) {
+                    half_t h, l;
+                    fn_split(v, split_scale, h, l);
+                    o_hi[(int64_t)m * ldo + n] = h;
+                    o_lo[(int64_t)m * ldo + n] = l;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// InstanceNorm2d statistics of x (n_img * rows, C) fp32: pass 1 = fp64 partial sums over row slabs, pass 2 = fixed-order
+// combine.  grid (slabs, n_img), 256 threads: thread t owns channel t % CP and every (256 / CP)-th row of the slab.
+__global__ __launch_bounds__(256) void fn_colstats_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                                  int rows, int C, int slab_rows) {
+    __shared__ double s1[256], s2[256];
+    const int img = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+    const int groups = 256 / C > 0 ? 256 / C : 1;
+    const int r0 = slab * slab_rows, r1 = min(rows, r0 + slab_rows);
+    for (int cb = 0; cb < C; cb += 256) {  // (C <= 256 in this network: one trip)
+        const int c = cb + tid % (C < 256 ? C : 256), g = tid / (C < 256 ? C : 256);
+        double a = 0.0, b = 0.0;
+        if (g < groups && c < C) {
+            const float* p = x + ((int64_t)img * rows) * C + c;
+            for (int r = r0 + g; r < r1; r += groups) {
+                const double v = (double)p[(int64_t)r * C];
+                a += v;
+                b += v * v;
+            }
+        }
+        s1[tid] = a;
+        s2[tid] = b;
+        __syncthreads();
+        if (g == 0 && c < C) {
+            for (int gg = 1; gg < groups; ++gg) {
+                a += s1[tid + gg * C];
+                b += s2[tid + gg * C];
+            }
+            double* o = part + (((int64_t)img * gridDim.x + slab) * C + c) * 2;
+            o[0] = a;
+            o[1] = b;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void fn_colstats_final_kernel(const double* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
+                                         int slabs, int C, int rows, float eps, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (img, c)
+    if (i >= total) return;
+    const int img = i / C, c = i - img * C;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < slabs; ++s) {
+        const double* p = part + (((int64_t)img * slabs + s) * C + c) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    const double m = a / rows;
+    double var = b / rows - m * m;  // biased variance (InstanceNorm2d)
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = relu_b?( relu_a?((x - mean) * rstd) + residual ), 4 channels per thread; writes fp32 y (ld C) and / or the (hi, lo)
+// planes with row stride ldo >= C (channels C .. ldo-1 are zeroed: K padding of the next product)
+__global__ __launch_bounds__(256) void fn_prep_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ res,
+                                                      float* __restrict__ y, half_t* __restrict__ o_hi,
+                                                      half_t* __restrict__ o_lo, int64_t M, int C, int ldo,
+                                                      int rows_per_img, int relu_a, int relu_b, float split_scale) {
+    const int q = ldo / 4;  // quads per output row (C % 4 == 0, ldo % 4 == 0)
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * q) return;
+    const int64_t m = idx / q;
+    const int c = (int)(idx - m * q) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const floatx4 t = *reinterpret_cast<const floatx4*>(x + m * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = t[e];
+        if (mean) {
+            const int64_t s = (m / rows_per_img) * C + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean[s + e]) * rstd[s + e];
+        }
+        if (relu_a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (res) {
+            const floatx4 t2 = *reinterpret_cast<const floatx4*>(res + m * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += t2[e];
+        }
+        if (relu_b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (y) {
+            floatx4 t3 = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<floatx4*>(y + m * C + c) = t3;
+        }
+    }
+    if (o_hi) {
+        half4_t h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            half_t hh, ll;
+            fn_split(v[e], split_scale, hh, ll);
+            h[e] = hh;
+            l[e] = ll;
+        }
+        *reinterpret_cast<half4_t*>(o_hi + m * ldo + c) = h;
+        *reinterpret_cast<half4_t*>(o_lo + m * ldo + c) = l;
+    }
+}
+
+// LayerNorm over C = 128 channels (eps inside the sqrt, affine), one wave per row, two channels per lane:
+// y = [res +] ((x - mean) / sqrt(var + eps)) * gamma + beta
+__global__ __launch_bounds__(256) void fn_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res,
+                                                           float* __restrict__ y, half_t* __restrict__ o_hi,
+                                                           half_t* __restrict__ o_lo, int64_t ldy, int64_t ldo, int64_t M,
+                                                           float eps, float split_scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float a = x[m * 128 + lane * 2], b = x[m * 128 + lane * 2 + 1];
+    const float mean = wave_sum(a + b) * (1.f / 128.f);
+    const float da = a - mean, db = b - mean;
+    const float var = wave_sum(da * da + db * db) * (1.f / 128.f);
+    const float r = 1.f / sqrtf(var + eps);
+    float ya = da * r * gamma[lane * 2] + beta[lane * 2];
+    float yb = db * r * gamma[lane * 2 + 1] + beta[lane * 2 + 1];
+    if (res) {
+        ya += res[m * 128 + lane * 2];
+        yb += res[m * 128 + lane * 2 + 1];
+    }
+    if (y) {
+        y[m * ldy + lane * 2] = ya;
+        y[m * ldy + lane * 2 + 1] = yb;
+    }
+    if (o_hi) {
+        half_t h0, l0, h1, l1;
+        fn_split(ya, split_scale, h0, l0);
+        fn_split(yb, split_scale, h1, l1);
+        o_hi[m * ldo + lane * 2] = h0;
+        o_hi[m * ldo + lane * 2 + 1] = h1;
+        o_lo[m * ldo + lane * 2] = l0;
+        o_lo[m * ldo + lane * 2 + 1] = l1;
+    }
+}
+
+// The stem: Conv2d(3, 64, 7, stride 2, padding 3, bias=False) on NHWC fp32, direct fp32 FMAs.  A block = 64 consecutive
+// output pixels of one output row x 64 output channels: thread (pixel = tid & 63, 16 channels = tid >> 6).  The 7 input rows
+// x (2 * 64 + 5) columns x 3 channels and the 147 x 64 weights live in LDS; a wave reads each weight as a broadcast.
+__global__ __launch_bounds__(256) void fn_conv7_rgb_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ out, int H, int W, int OH, int OW) {
+    constexpr int PW = 2 * 64 + 5;  // input columns of a block
+    __shared__ __attribute__((aligned(16))) float ws[147 * 64];  // [k = (ky, kx, ci)][cout]
+    __shared__ float xs[7 * PW * 3];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.z, oy = blockIdx.y, ox0 = blockIdx.x * 64;
+    for (int i = tid; i < 147 * 64; i += 256) ws[i] = w[i];
+    const int iy0 = oy * 2 - 3, ix0 = ox0 * 2 - 3;
+    for (int i = tid; i < 7 * PW * 3; i += 256) {
+        const int ky = i / (PW * 3), r = i - ky * (PW * 3);
+        const int cx = r / 3, ci = r - cx * 3;
+        const int iy = iy0 + ky, ix = ix0 + cx;
+        xs[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)img * H + iy) * W + ix) * 3 + ci] : 0.f;
+    }
+    __syncthreads();
+    const int p = tid & 63, cg = tid >> 6;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int ky = 0; ky < 7; ++ky)
+        for (int t = 0; t < 21; ++t) {  // t = kx * 3 + ci
+            const float a = xs[ky * (PW * 3) + p * 6 + t];
+            const float* wp = ws + (ky * 21 + t) * 64 + cg * 16;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const floatx4 wv = *reinterpret_cast<const floatx4*>(wp + j4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j4 * 4 + e] = fmaf(a, wv[e], acc[j4 * 4 + e]);
+            }
+        }
+    const int ox = ox0 + p;
+    if (ox < OW) {
+        float* o = out + (((int64_t)img * OH + oy) * OW + ox) * 64 + cg * 16;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+            floatx4 v = {acc[j4 * 4], acc[j4 * 4 + 1], acc[j4 * 4 + 2], acc[j4 * 4 + 3]};
+            *reinterpret_cast<floatx4*>(o + j4 * 4) = v;
+        }
+    }
+}
+
+}  // namespace fresco
+
+using namespace fresco;
+
+extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, const void* w_hi, const void* w_lo,
+                              const float* bias, float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M,
+                              int N, int K, int act, float acc_scale, float split_scale, int n_img, int H, int W, int kh,
+                              int kw, int stride, int pad, void* stream) {
+    if (!a_hi || !a_lo || !w_hi || !w_lo || (!out && !out_hi) || (out_hi && !out_lo) || M <= 0 || N <= 0 || K <= 0)
+        return FRESCO_EINVAL;
+    if (K % 32 != 0 || lda % 8 != 0 || act < 0 || act > 2) return FRESCO_EUNSUPPORTED;
+    if ((out && ldc < N) || (out_hi && ldo < N)) return FRESCO_EINVAL;
+    FnConv cv = {0, 0, 1, 0, 0, 0, 0, 0, 0};
+    if (kh > 0) {
+        if (kw <= 0 || stride <= 0 || pad < 0 || n_img <= 0 || H <= 0 || W <= 0) return FRESCO_EINVAL;
+        const int cin = K / (kh * kw);
+        if (cin * kh * kw != K || cin % 32 != 0 || lda < cin) return FRESCO_EUNSUPPORTED;
+        const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
+        if ((int64_t)n_img * OH * OW != M) return FRESCO_EINVAL;
+        cv = FnConv{kh, kw, stride, pad, H, W, OH, OW, cin};
+    } else if (lda < K) {
+        return FRESCO_EINVAL;
+    }
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(FRESCO_PROF_FN_GEMM, M, N, K, kh, st);
+    const half_t* ah = static_cast<const half_t*>(a_hi);
+    const half_t* al = static_cast<const half_t*>(a_lo);
+    const half_t* wh = static_cast<const half_t*>(w_hi);
+    const half_t* wl = static_cast<const half_t*>(w_lo);
+    half_t* oh = static_cast<half_t*>(out_hi);
+    half_t* ol = static_cast<half_t*>(out_lo);
+    if (N <= 64) {
+        constexpr int BN = 64;
+        const int lds = 2 * (2 * 128 * 80 + 2 * BN * 80);
+        hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3((M + 127) / 128, (N + BN - 1) / BN), dim3(256), lds, st, ah, al, lda, cv,
+                           wh, wl, bias, out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale);
+    } else {
+        constexpr int BN = 128;
+        const int lds = 2 * (2 * 128 * 80 + 2 * BN * 80);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3((M + 127) / 128, (N + BN - 1) / BN), dim3(256), lds, st, ah, al, lda, cv,
+                           wh, wl, bias, out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale);
+    }
+    return check_launch();
+}
+
+extern "C" size_t fresco_fn_colstats_workspace_bytes(int n_img, int rows, int C) {
+    if (n_img <= 0 || rows <= 0 || C <= 0) return 0;
+    const int slabs = (rows + 511) / 512;
+    return (size_t)n_img * slabs * C * 2 * sizeof(double);
+}
+
+extern "C" int fresco_fn_colstats(const float* x, float* mean, float* rstd, void* workspace, size_t workspace_bytes,
+                                  int n_img, int rows, int C, float eps, void* stream) {
+    if (!x || !mean || !rstd || !workspace || n_img <= 0 || rows <= 0 || C <= 0) return FRESCO_EINVAL;
+    if (C > 256 || n_img > 65535) return FRESCO_EUNSUPPORTED;
+    if (workspace_bytes < fresco_fn_colstats_workspace_bytes(n_img, rows, C)) return FRESCO_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const int slabs = (rows + 511) / 512;
+    double* part = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(fn_colstats_partial_kernel, dim3(slabs, n_img), dim3(256), 0, st, x, part, rows, C, 512);
+    const int total = n_img * C;
+    hipLaunchKernelGGL(fn_colstats_final_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, mean, rstd, slabs, C, rows,
+                       eps, total);
+    return check_launch();
+}
+
+extern "C" int fresco_fn_prep(const float* x, const float* mean, const float* rstd, const float* residual, float* y,
+                              void* out_hi, void* out_lo, int64_t M, int C, int ldo, int rows_per_img, int relu_a,
+                              int relu_b, float split_scale, void* stream) {
+    if (!x || M <= 0 || C <= 0 || (!y && !out_hi) || (out_hi && !out_lo) || ((mean != nullptr) != (rstd != nullptr)))
+        return FRESCO_EINVAL;
+    if (C % 4 != 0) return FRESCO_EUNSUPPORTED;
+    if (!out_hi) ldo = C;
+    if (ldo < C || ldo % 4 != 0 || (mean && rows_per_img <= 0)) return FRESCO_EINVAL;
+    const int64_t n = M * (ldo / 4);
+    hipLaunchKernelGGL(fn_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, mean, rstd,
+                       residual, y, static_cast<half_t*>(out_hi), static_cast<half_t*>(out_lo), M, C, ldo,
+                       rows_per_img > 0 ? rows_per_img : 1, relu_a, relu_b, split_scale);
+    return check_launch();
+}
+
+extern "C" int fresco_fn_layernorm(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                                   void* out_hi, void* out_lo, int64_t ldy, int64_t ldo, int64_t M, int C, float eps,
+                                   float split_scale, void* stream) {
+    if (!x || !gamma || !beta || M <= 0 || (!y && !out_hi) || (out_hi && !out_lo)) return FRESCO_EINVAL;
+    if (C != 128) return FRESCO_EUNSUPPORTED;
+    if ((y && ldy < C) || (out_hi && ldo < C)) return FRESCO_EINVAL;
+    hipLaunchKernelGGL(fn_layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream), x, gamma, beta,
+                       residual, y, static_cast<half_t*>(out_hi), static_cast<half_t*>(out_lo), ldy, ldo, M, eps, split_scale);
+    return check_launch();
+}
+
+extern "C" int fresco_fn_conv7_rgb(const float* x, const float* w, float* out, int n_img, int H, int W, void* stream) {
+    if (!x || !w || !out || n_img <= 0 || H <= 0 || W <= 0) return FRESCO_EINVAL;
+    const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+    if (OH > 65535 || n_img > 65535) return FRESCO_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(FRESCO_PROF_FN_GEMM, n_img * OH * OW, 64, 147, 7, st);
+    hipLaunchKernelGGL(fn_conv7_rgb_kernel, dim3((OW + 63) / 64, OH, n_img), dim3(256), 0, st, x, w, out, H, W, OH, OW);
+    return check_launch();
+}

@@ -13,12 +13,18 @@ tree carries the reference's parameter names, so `load_state_dict` takes the pub
     four) regions a rolled window is stitched from, so tokens are grouped by (window, region) once per
     resolution and every group is an ordinary attention problem; equally sized groups share a launch;
   * no roll / split / merge copies, no L x L score or mask tensors;
-  * convolutions, instance / layer norms and the linear layers are PyTorch's (MIOpen / rocBLAS), fp32.
+  * round 5: on the GPU the dense layers run on this package's kernels too (csrc/flownet.hip: implicit-GEMM convolutions,
+    linear layers, InstanceNorm / LayerNorm, all fp32-accurate products on the fp16 matrix pipe from (hi, lo) operand
+    planes), in NHWC -- which is the transformer's token layout, so nothing is transposed between the encoder and the
+    attention layers.  The nn.Module tree stays (it carries the checkpoint's parameter names); its own forward methods --
+    PyTorch's convolutions / norms / linears -- are what runs for tensors that are not on the GPU (the CPU architecture
+    test with a stubbed attention) and with FRESCO_GMFLOW_LIBRARY_OPS=1 (A/B measurements).
 
 `GMFlow.forward(img0, img1, attn_splits_list=[2], corr_radius_list=[-1], prop_radius_list=[-1],
 pred_bidir_flow=True)` returns {'flow_preds': [flow]} like the reference, flow (2B, 2, H, W) in pixels.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -193,6 +199,123 @@ class FeatureFlowAttention(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
+# the dense layers on csrc/flownet.hip (GPU tensors): NHWC rows, (hi, lo) operand planes
+# ------------------------------------------------------------------------------------------------
+class _Weights:
+    """(hi, lo) fp16 planes of a layer's weight as the (N, K) matrix fresco_fn_gemm reads, made once per parameter version"""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, p, kind, pad_cin=None):
+        key = (id(p), kind)
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == (p._version, p.data_ptr()):
+            return hit[1]
+        w = p.detach().float()
+        if kind == "conv":  # (cout, cin, kh, kw) -> (cout, kh, kw, cin [padded]) -> (cout, K)
+            w = w.permute(0, 2, 3, 1)
+            if pad_cin is not None and pad_cin > w.shape[-1]:
+                w = F.pad(w, (0, pad_cin - w.shape[-1]))
+            w = w.reshape(w.shape[0], -1)
+        elif kind == "stem":  # (64, 3, 7, 7) -> (7, 7, 3, 64) fp32
+            val = w.permute(2, 3, 1, 0).contiguous()
+            self.cache[key] = ((p._version, p.data_ptr()), val)
+            return val
+        _, val = ops.fn_prep(w.contiguous(), scale=ops.FN_W_SCALE)
+        self.cache[key] = ((p._version, p.data_ptr()), val)
+        return val
+
+
+def _conv(wts, x_split, conv, n, H, W, stride, act=0, want_f32=True, want_split=False, pad_cin=None):
+    """Conv2d on the NHWC tensor behind the planes x_split -> rows (n * OH * OW, cout)"""
+    kh = conv.kernel_size[0]
+    w = wts.get(conv.weight, "conv", pad_cin)
+    K = w[0].shape[1]
+    return ops.fn_gemm(x_split, w, conv.out_channels, K, bias=conv.bias, act=act,
+                       conv=(n, H, W, kh, kh, stride, conv.padding[0]), want_f32=want_f32, want_split=want_split)
+
+
+def _res_block(wts, blk, x, xs, n, H, W):
+    """ResidualBlock.forward on NHWC rows: x fp32 (n H W, cin), xs its planes -> (out fp32, planes, OH, OW)"""
+    s = blk.conv1.stride[0]
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    c1, _ = _conv(wts, xs, blk.conv1, n, H, W, s)
+    m1, r1 = ops.fn_colstats(c1, n)
+    _, a1 = ops.fn_prep(c1, m1, r1, rows_per_img=OH * OW, relu_a=True)
+    c2, _ = _conv(wts, a1, blk.conv2, n, OH, OW, 1)
+    m2, r2 = ops.fn_colstats(c2, n)
+    if blk.downsample is not None:
+        c3, _ = _conv(wts, xs, blk.downsample[0], n, H, W, s)
+        m3, r3 = ops.fn_colstats(c3, n)
+        x, _ = ops.fn_prep(c3, m3, r3, rows_per_img=OH * OW, want_f32=True, want_split=False)
+    out, outs = ops.fn_prep(c2, m2, r2, residual=x, rows_per_img=OH * OW, relu_a=True, relu_b=True, want_f32=True)
+    return out, outs, OH, OW
+
+
+def _backbone_native(bb, wts, x_nchw):
+    """CNNEncoder.forward -> tokens (n, h * w, C) fp32 (= NHWC), h, w"""
+    n, _, H, W = x_nchw.shape
+    c = ops.fn_conv7_rgb(x_nchw.permute(0, 2, 3, 1).contiguous(), wts.get(bb.conv1.weight, "stem"))
+    H, W = c.shape[1], c.shape[2]
+    c = c.view(n * H * W, 64)
+    m, r = ops.fn_colstats(c, n)
+    x, xs = ops.fn_prep(c, m, r, rows_per_img=H * W, relu_a=True, want_f32=True)
+    for layer in (bb.layer1, bb.layer2, bb.layer3):
+        for blk in layer:
+            x, xs, H, W = _res_block(wts, blk, x, xs, n, H, W)
+    w = wts.get(bb.conv2.weight, "conv")
+    feats, _ = ops.fn_gemm(xs, w, bb.conv2.out_channels, w[0].shape[1], bias=bb.conv2.bias)
+    return feats.view(n, H * W, -1), H, W
+
+
+def _layer_native(layer, wts, src, src_s, tgt_s, groups):
+    """TransformerLayer.forward on token rows: src (B, L, C) fp32, src_s / tgt_s planes (B L, C) -> (out fp32, planes)"""
+    B, L, C = src.shape
+    lin = lambda p: wts.get(p.weight, "lin")
+    q, _ = ops.fn_gemm(src_s, lin(layer.q_proj), C, C)
+    k, _ = ops.fn_gemm(tgt_s, lin(layer.k_proj), C, C)
+    v, _ = ops.fn_gemm(tgt_s, lin(layer.v_proj), C, C)
+    msg = grouped_attention(q.view(B, L, C), k.view(B, L, C), v.view(B, L, C), groups, 1.0 / math.sqrt(C))
+    _, ms = ops.fn_prep(msg.view(B * L, C))
+    mg, _ = ops.fn_gemm(ms, lin(layer.merge), C, C)
+    src2 = src.view(B * L, C)
+    if layer.no_ffn:
+        out, outs = ops.fn_layernorm(mg, layer.norm1.weight, layer.norm1.bias, residual=src2, eps=layer.norm1.eps,
+                                     want_split=True)
+        return out.view(B, L, C), outs
+    # mlp(cat(source, norm1(merge))): the LayerNorm writes its planes into the right half of the concatenated operand
+    dev = src.device
+    ch = torch.empty(B * L, 2 * C, dtype=torch.float16, device=dev)
+    cl = torch.empty(B * L, 2 * C, dtype=torch.float16, device=dev)
+    ch[:, :C].copy_(src_s[0])
+    cl[:, :C].copy_(src_s[1])
+    ops.fn_layernorm(mg, layer.norm1.weight, layer.norm1.bias, eps=layer.norm1.eps, want_f32=False,
+                     out_split=(ch[:, C:], cl[:, C:], 2 * C))
+    w1, w2 = lin(layer.mlp[0]), lin(layer.mlp[2])
+    hid = layer.mlp[0].out_features
+    _, hs = ops.fn_gemm((ch, cl), w1, hid, 2 * C, act=2, want_f32=False, want_split=True)
+    o2, _ = ops.fn_gemm(hs, w2, C, hid)
+    out, outs = ops.fn_layernorm(o2, layer.norm2.weight, layer.norm2.bias, residual=src2, eps=layer.norm2.eps, want_split=True)
+    return out.view(B, L, C), outs
+
+
+def _transformer_native(tr, wts, tok, b, h, w, splits):
+    """FeatureTransformer.forward on tokens (2b, L, C) (both directions in one batch) -> tokens"""
+    x = tok
+    _, xs = ops.fn_prep(x.reshape(-1, x.shape[-1]))
+    L, C = x.shape[1], x.shape[2]
+    swap = lambda t: torch.cat((t.view(2, b * L, C)[1], t.view(2, b * L, C)[0]), 0)
+    for i, blk in enumerate(tr.layers):
+        shifted = splits > 1 and i % 2 == 1
+        groups = tr._get_groups(h, w, splits, shifted, x.device)
+        ys = (swap(xs[0]), swap(xs[1]))  # the other image's tokens BEFORE this block (transformer.py:279-288)
+        x, xs = _layer_native(blk.self_attn, wts, x, xs, xs, groups)
+        x, xs = _layer_native(blk.cross_attn_ffn, wts, x, xs, ys, groups)
+    return x, xs
+
+
+# ------------------------------------------------------------------------------------------------
 # helpers
 # ------------------------------------------------------------------------------------------------
 def sine_position(c, h, w, device, temperature=10000.0):
@@ -230,6 +353,48 @@ class GMFlow(nn.Module):
         self.feature_flow_attn = FeatureFlowAttention(feature_channels)
         self.upsampler = nn.Sequential(nn.Conv2d(2 + feature_channels, 256, 3, 1, 1), nn.ReLU(inplace=True),
                                        nn.Conv2d(256, upsample_factor ** 2 * 9, 1, 1, 0))
+        self._wts = _Weights()
+
+    def _forward_native(self, x, splits, pred_bidir_flow):
+        """the forward on csrc/flownet.hip + attn32.hip: NHWC / token layout end to end (x: normalised (2b, 3, H, W))"""
+        wts, K = self._wts, self.upsample_factor
+        b = x.shape[0] // 2
+        tok, h, w = _backbone_native(self.backbone, wts, x)
+        c = tok.shape[-1]
+        if h % splits or w % splits:
+            raise ValueError("feature map %dx%d is not divisible into %d x %d windows" % (h, w, splits, splits))
+        pos = sine_position(c, h // splits, w // splits, x.device).repeat(1, 1, splits, splits)
+        tok = tok + pos.flatten(2).transpose(1, 2)
+        tok, toks = _transformer_native(self.transformer, wts, tok.contiguous(), b, h, w, splits)
+        L = h * w
+        t0, t1 = tok[:b], tok[b:]
+        grid = pixel_grid(h, w, x.device)
+        gtok = grid.flatten(1).t().unsqueeze(0)
+        if pred_bidir_flow:
+            qs, ks, B2, fs = tok, torch.cat((t1, t0), 0), 2 * b, toks
+        else:
+            qs, ks, B2, fs = t0, t1, b, (toks[0][:b * L], toks[1][:b * L])
+        corr = ops.attention_f32(qs, ks, gtok.expand(B2, -1, -1).contiguous(), 1.0 / math.sqrt(c))   # (B2, L, 2)
+        flow_tok = corr - gtok                                                                          # matching.py:30-34
+        # flow propagation (transformer.py:353-372; k = k_proj(q_proj(x)) kept)
+        fa = self.feature_flow_attn
+        query, qsp = ops.fn_gemm(fs, wts.get(fa.q_proj.weight, "lin"), c, c, bias=fa.q_proj.bias, want_split=True)
+        key, _ = ops.fn_gemm(qsp, wts.get(fa.k_proj.weight, "lin"), c, c, bias=fa.k_proj.bias)
+        flow_tok = ops.attention_f32(query.view(B2, L, c), key.view(B2, L, c), flow_tok.contiguous(), 1.0 / math.sqrt(c))
+        # convex upsampling (gmflow.py:75-90): mask head on NHWC rows [flow | feature | zero padding to 160 channels]
+        cat = torch.zeros(B2 * L, c + 4, dtype=torch.float32, device=x.device)
+        cat[:, :2] = flow_tok.reshape(B2 * L, 2)
+        cat[:, 2:2 + c] = qs.reshape(B2 * L, c)
+        _, cs = ops.fn_prep(cat, ld=160)
+        up0, up2 = self.upsampler[0], self.upsampler[2]
+        _, hs = _conv(wts, cs, up0, B2, h, w, 1, act=1, want_f32=False, want_split=True, pad_cin=160)
+        w2 = wts.get(up2.weight, "conv")
+        mk, _ = ops.fn_gemm(hs, w2, up2.out_channels, w2[0].shape[1], bias=up2.bias)
+        mask = mk.view(B2, h, w, 9, K, K).softmax(3)
+        flow = flow_tok.transpose(1, 2).reshape(B2, 2, h, w)
+        nb = F.unfold(K * flow, (3, 3), padding=1).view(B2, 2, 9, h, w)
+        up = torch.einsum("bhwnyx,bcnhw->bchywx", mask, nb)
+        return up.reshape(B2, 2, K * h, K * w)
 
     def upsample_flow(self, flow, feature):
         """convex upsampling (gmflow.py:75-90): every fine pixel is a softmax-weighted mix of its coarse 3x3"""
@@ -250,6 +415,8 @@ class GMFlow(nn.Module):
         mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
         std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
         x = torch.cat((img0, img1), 0).float()
+        if x.is_cuda and os.environ.get("FRESCO_GMFLOW_LIBRARY_OPS", "0") != "1":
+            return {"flow_preds": [self._forward_native((x / 255.0 - mean) / std, splits, pred_bidir_flow)]}
         feats = self.backbone((x / 255.0 - mean) / std)
         f0, f1 = feats.chunk(2, 0)
         b, c, h, w = f0.shape

@@ -253,6 +253,114 @@ def attention_f32(q, k, v, scale):
     return out
 
 
+# ---- the flow network's dense layers (csrc/flownet.hip): fp32 tensors in NHWC / token layout, products on the fp16 matrix
+# pipe from (hi, lo) fp16 planes.  A "split" below is a pair of fp16 tensors (M, ld) with x * scale = hi + lo (scale: FN_A_SCALE
+# for activations, FN_W_SCALE for weights -- powers of two that keep the lo pieces normal fp16 numbers, csrc/flownet.hip).
+FN_A_SCALE, FN_W_SCALE = 64.0, 1024.0
+
+
+def fn_prep(x, mean=None, rstd=None, residual=None, rows_per_img=0, relu_a=False, relu_b=False, want_f32=False,
+            want_split=True, ld=None, out_split=None, scale=FN_A_SCALE):
+    """y = relu_b?(relu_a?((x - mean) * rstd) + residual) on (M, C) fp32 rows (fresco_fn_prep).  Returns (y or None,
+    (hi, lo) or None); the planes have row stride ld >= C with channels C .. ld-1 zeroed.  out_split: planes to write into
+    (views with a row stride are fine: (hi, lo, ld))."""
+    _need_gpu(x)
+    x = _f32c(x)
+    M, C = x.shape
+    y = torch.empty_like(x) if want_f32 else None
+    hi = lo = None
+    ldo = C
+    if out_split is not None:
+        hi, lo, ldo = out_split
+    elif want_split:
+        ldo = ld or C
+        hi = torch.empty(M, ldo, dtype=torch.float16, device=x.device)
+        lo = torch.empty(M, ldo, dtype=torch.float16, device=x.device)
+    rc = _lib.load().fresco_fn_prep(x.data_ptr(), _ptr(mean), _ptr(rstd), _ptr(residual), _ptr(y), _ptr(hi), _ptr(lo), M, C,
+                                    int(ldo), int(rows_per_img), int(relu_a), int(relu_b), float(scale), _stream())
+    _lib.check(rc, "fresco_fn_prep(M=%d,C=%d,ld=%d)" % (M, C, ldo))
+    return y, ((hi, lo) if hi is not None else None)
+
+
+def fn_colstats(x, n_img, eps=1e-5):
+    """InstanceNorm2d statistics of x (n_img * rows, C) fp32 -> (mean, rstd), (n_img, C) each (fresco_fn_colstats)"""
+    _need_gpu(x)
+    M, C = x.shape
+    rows = M // n_img
+    lib = _lib.load()
+    nbytes = lib.fresco_fn_colstats_workspace_bytes(n_img, rows, C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    mean = torch.empty(n_img, C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n_img, C, dtype=torch.float32, device=x.device)
+    rc = lib.fresco_fn_colstats(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), nbytes, n_img, rows, C,
+                                float(eps), _stream())
+    _lib.check(rc, "fresco_fn_colstats(n=%d,rows=%d,C=%d)" % (n_img, rows, C))
+    return mean, rstd
+
+
+def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want_split=False, out_split=None):
+    """act(A W^T + bias) (fresco_fn_gemm).  a = (hi, lo) planes, (rows, lda); w = (hi, lo) planes (N, K).
+    conv = (n_img, H, W, kh, kw, stride, pad): implicit im2col of the NHWC tensor behind `a` (K = kh kw cin).
+    Returns (out fp32 (M, N) or None, (hi, lo) (M, N) or None)."""
+    ah, al = a
+    wh, wl = w
+    _need_gpu(ah, wh)
+    lda = ah.stride(0)
+    if conv is None:
+        M = ah.shape[0] if M is None else M
+        cargs = (0, 0, 0, 0, 0, 1, 0)
+    else:
+        n_img, H, W, kh, kw, stride, pad = conv
+        OH, OW = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        M = n_img * OH * OW
+        cargs = (n_img, H, W, kh, kw, stride, pad)
+    dev = ah.device
+    out = torch.empty(M, N, dtype=torch.float32, device=dev) if want_f32 else None
+    oh = ol = None
+    ldo = N
+    if out_split is not None:
+        oh, ol, ldo = out_split
+    elif want_split:
+        oh = torch.empty(M, N, dtype=torch.float16, device=dev)
+        ol = torch.empty(M, N, dtype=torch.float16, device=dev)
+    rc = _lib.load().fresco_fn_gemm(ah.data_ptr(), al.data_ptr(), lda, wh.data_ptr(), wl.data_ptr(), _ptr(bias), _ptr(out),
+                                    _ptr(oh), _ptr(ol), N, int(ldo), M, N, K, int(act), 1.0 / (FN_A_SCALE * FN_W_SCALE),
+                                    FN_A_SCALE, *cargs, _stream())
+    _lib.check(rc, "fresco_fn_gemm(M=%d,N=%d,K=%d,conv=%s)" % (M, N, K, conv))
+    return out, ((oh, ol) if oh is not None else None)
+
+
+def fn_layernorm(x, gamma, beta, residual=None, eps=1e-5, want_f32=True, want_split=False, out_split=None):
+    """residual + LayerNorm(x) over the 128 channels of (M, 128) fp32 rows (fresco_fn_layernorm) -> (y or None, split or None)"""
+    _need_gpu(x)
+    x = _f32c(x)
+    M, C = x.shape
+    y = torch.empty_like(x) if want_f32 else None
+    oh = ol = None
+    ldo = C
+    if out_split is not None:
+        oh, ol, ldo = out_split
+    elif want_split:
+        oh = torch.empty(M, C, dtype=torch.float16, device=x.device)
+        ol = torch.empty(M, C, dtype=torch.float16, device=x.device)
+    rc = _lib.load().fresco_fn_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(residual), _ptr(y), _ptr(oh),
+                                         _ptr(ol), C, int(ldo), M, C, float(eps), FN_A_SCALE, _stream())
+    _lib.check(rc, "fresco_fn_layernorm(M=%d,C=%d)" % (M, C))
+    return y, ((oh, ol) if oh is not None else None)
+
+
+def fn_conv7_rgb(x_nhwc, w_khwc):
+    """Conv2d(3, 64, 7, stride 2, padding 3, bias=False) on (n, H, W, 3) fp32 NHWC with w (7, 7, 3, 64) -> (n, OH, OW, 64)"""
+    _need_gpu(x_nhwc, w_khwc)
+    x_nhwc, w_khwc = _f32c(x_nhwc), _f32c(w_khwc)
+    n, H, W, _ = x_nhwc.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty(n, OH, OW, 64, dtype=torch.float32, device=x_nhwc.device)
+    rc = _lib.load().fresco_fn_conv7_rgb(x_nhwc.data_ptr(), w_khwc.data_ptr(), out.data_ptr(), n, H, W, _stream())
+    _lib.check(rc, "fresco_fn_conv7_rgb(n=%d,H=%d,W=%d)" % (n, H, W))
+    return out
+
+
 _checked_tables = {}
 
 

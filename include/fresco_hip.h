@@ -63,6 +63,7 @@ const char* fresco_last_error(void);
 #define FRESCO_PROF_OPT_ADAM 9
 #define FRESCO_PROF_LINEAR 10 /* dims = {M, N, K, nw} */
 #define FRESCO_PROF_ATTN_F32 11 /* dims = {B, Lq, Lk, D} */
+#define FRESCO_PROF_FN_GEMM 12  /* dims = {M, N, K, kernel height (0: linear layer)} */
 int fresco_prof_enable(int capacity);
 int fresco_prof_disable(void);
 int fresco_prof_read(int max_records, int* tags, int* dims, float* ms);
@@ -220,6 +221,48 @@ int fresco_attn_f32_ws(const float* q, const float* k, const float* v, float* ou
 int fresco_attn_f32_guarded(const float* q, const float* k, const float* v, float* out, void* workspace,
                             size_t workspace_bytes, int* flag, int B, int Lq, int Lk, int D, int Dv, float scale,
                             void* stream);
+
+/* ---- the flow network's dense layers (f3): GMFlow's CNN encoder, transformer projections / FFN / LayerNorms, upsampler head
+ * (gmflow/backbone.py:7-117, transformer.py:111-237, gmflow.py:44-90).  fp32 in, fp32 out, fp32-class accuracy on the fp16
+ * matrix pipe: a tensor that feeds a product exists as a pair of fp16 planes (hi, lo), x = hi + lo to 2^-22, written by its
+ * producer (fresco_fn_prep / fresco_fn_layernorm / fresco_fn_gemm's epilogue); products are hi hi + hi lo + lo hi.
+ * The planes hold x * split_scale (a power of two: the matrix pipe flushes fp16 subnormals, so lo pieces must stay normal
+ * numbers; fresco_amd uses 2^6 for activations, |x| < 1000, and 2^10 for weights, |w| < 60; beyond that the scaled value
+ * saturates); fresco_fn_gemm multiplies its fp32 accumulators by acc_scale = 1 / (scale_A * scale_W) before the bias.
+ * Activations are NHWC: rows m = (image, y, x), channels contiguous -- the transformer's (B, L, C) token layout. */
+
+/* out[m][n] = act( sum_k A(m, k) W[n][k] + bias[n] ),  m < M, n < N, K % 32 == 0.
+ *   kh == 0: A = a_hi + a_lo, (M, K) row-major with row stride lda (halfs)               -- nn.Linear / 1 x 1 conv
+ *   kh  > 0: implicit im2col of an NHWC tensor (n_img, H, W, cin = K / (kh kw)), pixel stride lda >= cin, cin % 32 == 0,
+ *            k = (ky, kx, ci), zero padding `pad`, stride `stride`; M must be n_img * OH * OW    -- nn.Conv2d
+ *   w_hi / w_lo: (N, K) row-major fp16 planes; bias (N) fp32 or NULL; act 0 none, 1 ReLU, 2 GELU (erf form).
+ *   out (M, ldc) fp32 and / or out_hi / out_lo (M, ldo) fp16 planes of the result (either may be NULL, not both). */
+int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, const void* w_hi, const void* w_lo, const float* bias,
+                   float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M, int N, int K, int act,
+                   float acc_scale, float split_scale, int n_img, int H, int W, int kh, int kw, int stride, int pad,
+                   void* stream);
+
+/* nn.InstanceNorm2d statistics (affine=False, biased variance): x (n_img * rows, C) fp32 NHWC -> mean, rstd = 1 / sqrt(var +
+ * eps), (n_img, C) each.  fp64 partial sums in a fixed order.  C <= 256. */
+size_t fresco_fn_colstats_workspace_bytes(int n_img, int rows, int C);
+int fresco_fn_colstats(const float* x, float* mean, float* rstd, void* workspace, size_t workspace_bytes, int n_img, int rows,
+                       int C, float eps, void* stream);
+
+/* y = relu_b?( relu_a?( (x - mean[img]) * rstd[img] ) + residual ) on (M, C) fp32 rows (mean / rstd / residual may be NULL;
+ * img = m / rows_per_img).  Writes y (M, C) fp32 and / or the fp16 planes out_hi / out_lo with row stride ldo >= C, channels
+ * C .. ldo-1 zeroed (K padding of the product that reads them).  C % 4 == 0, ldo % 4 == 0. */
+int fresco_fn_prep(const float* x, const float* mean, const float* rstd, const float* residual, float* y, void* out_hi,
+                   void* out_lo, int64_t M, int C, int ldo, int rows_per_img, int relu_a, int relu_b, float split_scale,
+                   void* stream);
+
+/* nn.LayerNorm(128) (+ residual): y = residual + ((x - mean) / sqrt(var + eps)) gamma + beta on (M, 128) fp32 rows; fp32 y
+ * (row stride ldy) and / or fp16 planes (row stride ldo). */
+int fresco_fn_layernorm(const float* x, const float* gamma, const float* beta, const float* residual, float* y, void* out_hi,
+                        void* out_lo, int64_t ldy, int64_t ldo, int64_t M, int C, float eps, float split_scale, void* stream);
+
+/* The encoder's stem: Conv2d(3, 64, 7, stride 2, padding 3, bias=False), direct fp32 FMAs.  x (n_img, H, W, 3) NHWC,
+ * w (7, 7, 3, 64) = weight.permute(2, 3, 1, 0), out (n_img, OH, OW, 64) NHWC. */
+int fresco_fn_conv7_rgb(const float* x, const float* w, float* out, int n_img, int H, int W, void* stream);
 
 /* forward_backward_consistency_check (gmflow/geometry.py:75-96) fused with the colour-difference
  * occlusion refinement of get_flow_and_interframe_paras (DH:919-926).  Pair n couples frame n with frame

@@ -1,0 +1,114 @@
+"""GPU parity of the flow network's dense-layer kernels (csrc/flownet.hip; SURVEY 8 row f3: GMFlow's CNN encoder, transformer
+projections / FFN / LayerNorms, upsampler head -- gmflow/backbone.py:7-117, transformer.py:111-237, gmflow.py:44-90) against
+torch in fp64 on the same fp32 inputs.  The products run on the fp16 matrix pipe from (hi, lo) operand planes: the bar is
+fp32-class accuracy, a few 1e-6 of sum |a| |w| (an fp32 GEMM's own error grows like sqrt(K) 6e-8 of the same sum)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bar(a_abs_w_abs):
+    return 4e-6 * float(a_abs_w_abs.max()) + 1e-6
+
+
+@pytest.mark.parametrize("M,K,N,act,bias", [(1000, 128, 128, 0, False), (777, 256, 1024, 2, False), (515, 1024, 128, 0, False),
+                                             (300, 256, 576, 0, True), (129, 128, 64, 1, True), (4096, 128, 96, 0, True)])
+def test_fn_gemm_linear(M, K, N, act, bias):
+    import fresco_amd.ops as ops
+    g = synth.gen(M + K + N)
+    x = torch.randn(M, K, generator=g) * 1.7
+    x[::7] *= 1e-3                                   # small activations: their lo pieces would flush without the pre-scale
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g) if bias else None
+    _, xs = ops.fn_prep(x.to(DEV))
+    _, ws = ops.fn_prep(w.to(DEV), scale=ops.FN_W_SCALE)
+    out, outs = ops.fn_gemm(xs, ws, N, K, bias=None if b is None else b.to(DEV), act=act, want_split=True)
+    ref = x.double() @ w.double().t() + (0 if b is None else b.double())
+    if act == 1:
+        ref = ref.clamp_min(0)
+    if act == 2:
+        ref = F.gelu(ref)
+    bar = _bar(x.abs().double() @ w.abs().double().t())
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err < bar, (err, bar)
+    # the epilogue's own (hi, lo) planes reproduce the fp32 result to 2^-22
+    rec = (outs[0].float() + outs[1].float()) / ops.FN_A_SCALE
+    assert float((rec - out).abs().max()) <= 2 ** -21 * float(out.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,bias", [(64, 64, 3, 1, 1, 20, 28, False), (64, 96, 3, 2, 1, 20, 28, False),
+                                                            (96, 128, 3, 2, 1, 16, 24, False), (64, 96, 1, 2, 0, 20, 28, True),
+                                                            (128, 128, 3, 1, 1, 9, 13, False), (130, 256, 3, 1, 1, 8, 12, True)])
+def test_fn_gemm_implicit_conv(cin, cout, k, stride, pad, H, W, bias):
+    """nn.Conv2d as the implicit GEMM over NHWC rows: every encoder / upsampler shape class (3 x 3 stride 1 / 2, the 1 x 1
+    stride-2 shortcut with bias, a map whose width is no multiple of anything, and the 130-channel input padded to 160)"""
+    import fresco_amd.ops as ops
+    g = synth.gen(cin + cout + k + H)
+    n = 3
+    x = torch.randn(n, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (1.0 / math.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g) if bias else None
+    cp = (cin + 31) // 32 * 32
+    xr = x.permute(0, 2, 3, 1).reshape(n * H * W, cin)
+    if cin % 4:
+        xr = F.pad(xr, (0, 4 - cin % 4))
+    _, xs = ops.fn_prep(xr.contiguous().to(DEV), ld=cp)
+    wr = F.pad(w.permute(0, 2, 3, 1), (0, cp - cin)).reshape(cout, -1).contiguous()
+    _, ws = ops.fn_prep(wr.to(DEV), scale=ops.FN_W_SCALE)
+    out, _ = ops.fn_gemm(xs, ws, cout, k * k * cp, bias=None if b is None else b.to(DEV), conv=(n, H, W, k, k, stride, pad))
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride=stride, padding=pad)
+    OH, OW = ref.shape[2], ref.shape[3]
+    got = out.view(n, OH, OW, cout).permute(0, 3, 1, 2).cpu().double()
+    bar = _bar(F.conv2d(x.abs().double(), w.abs().double(), None, stride=stride, padding=pad))
+    err = float((got - ref).abs().max())
+    assert err < bar, (err, bar)
+
+
+def test_fn_instance_norm_prep_and_layernorm():
+    import fresco_amd.ops as ops
+    g = synth.gen(5)
+    n, rows, C = 3, 700, 96
+    x = torch.randn(n * rows, C, generator=g) * 3.0 + 1.5
+    res = torch.randn(n * rows, C, generator=g)
+    mean, rstd = ops.fn_colstats(x.to(DEV), n)
+    xd = x.double().view(n, rows, C)
+    m_ref, v_ref = xd.mean(1), xd.var(1, unbiased=False)
+    assert float((mean.cpu().double() - m_ref).abs().max()) < 1e-6
+    assert float((rstd.cpu().double() - 1 / (v_ref + 1e-5).sqrt()).abs().max()) < 1e-6
+    y, ys = ops.fn_prep(x.to(DEV), mean, rstd, residual=res.to(DEV), rows_per_img=rows, relu_a=True, relu_b=True, want_f32=True,
+                        ld=128)
+    ref = (((xd - m_ref[:, None]) / (v_ref[:, None] + 1e-5).sqrt()).clamp_min(0).view(-1, C) + res.double()).clamp_min(0)
+    assert float((y.cpu().double() - ref).abs().max()) < 5e-6
+    rec = (ys[0].float() + ys[1].float()) / ops.FN_A_SCALE
+    assert tuple(rec.shape) == (n * rows, 128) and float(rec[:, C:].abs().max()) == 0.0
+    assert float((rec[:, :C].cpu().double() - ref).abs().max()) < 5e-6
+    # LayerNorm(128) + residual
+    t = torch.randn(1000, 128, generator=g) * 2.0
+    r2 = torch.randn(1000, 128, generator=g)
+    ln = torch.nn.LayerNorm(128)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(128, generator=g))
+        ln.bias.copy_(torch.randn(128, generator=g))
+    y2, _ = ops.fn_layernorm(t.to(DEV), ln.weight.to(DEV), ln.bias.to(DEV), residual=r2.to(DEV))
+    ref2 = F.layer_norm(t.double(), (128,), ln.weight.double(), ln.bias.double(), 1e-5) + r2.double()
+    assert float((y2.cpu().double() - ref2).abs().max()) < 5e-6
+
+
+def test_fn_conv7_rgb_stem():
+    import fresco_amd.ops as ops
+    g = synth.gen(7)
+    n, H, W = 2, 40, 72
+    x = torch.randn(n, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.08
+    out = ops.fn_conv7_rgb(x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(2, 3, 1, 0).contiguous().to(DEV))
+    ref = F.conv2d(x.double(), w.double(), None, stride=2, padding=3)
+    got = out.permute(0, 3, 1, 2).cpu().double()
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert float((got - ref).abs().max()) < 2e-5
