@@ -44,6 +44,16 @@ def measure(N=8, R=512, dev="cuda", reps=3, verbose=False):
     for i in range(n):
         if tags[i] == 11:
             agg.setdefault(tuple(dims[4 * i: 4 * i + 4]), []).append(ms[i])
+    # the dense layers (csrc/flownet.hip, tag 12: dims = {M, N, K, kernel height}): per-shape means and the total
+    fn = {}
+    for i in range(n):
+        if tags[i] == 12:
+            fn.setdefault(tuple(dims[4 * i: 4 * i + 4]), []).append(ms[i])
+    fn_tot = sum(sum(v) for v in fn.values())
+    fn_flop = sum(2.0 * k[0] * k[1] * k[2] * len(v) for k, v in fn.items())
+    fn_launches = {"M%d_N%d_K%d_kh%d" % k: dict(launches=len(v), avg_us=round(1e3 * sum(v) / len(v), 1),
+                                                algorithmic_tflops=round(2.0 * k[0] * k[1] * k[2] / (sum(v) / len(v) * 1e-3) / 1e12, 1))
+                   for k, v in sorted(fn.items())}
     tot, launches, best = 0.0, {}, None
     for k, v in sorted(agg.items()):
         B, Lq, Lk, D = k
@@ -65,7 +75,24 @@ def measure(N=8, R=512, dev="cuda", reps=3, verbose=False):
     res = dict(workload="f3: GMFlow forward (stand-in weights) for %d frame pairs x 2 directions at %dx%d + occlusions, masks, "
                         "mappings (get_flow_and_interframe_paras), once per batch of frames" % (N, R, R),
                gmflow_forward_ms=round(1e3 * t_net, 2), get_flow_and_interframe_paras_ms=round(1e3 * t_all, 2),
-               attention_ms_of_forward=round(tot, 2), timing="fastest of %d" % reps, attn_f32_launches=launches)
+               attention_ms_of_forward=round(tot, 2), timing="fastest of %d" % reps, attn_f32_launches=launches,
+               dense_layers=dict(kernel="fn_gemm_kernel / fn_conv7_rgb_kernel (csrc/flownet.hip): convolutions as implicit GEMM + "
+                                        "linear layers, fp32-accurate split-fp16 products (3 MFMAs per product)",
+                                 ms_of_forward=round(fn_tot, 2), launches=sum(len(v) for v in fn.values()),
+                                 algorithmic_tflops=round(fn_flop / max(fn_tot, 1e-9) / 1e9, 1),
+                                 executed_fp16_tflops=round(3 * fn_flop / max(fn_tot, 1e-9) / 1e9, 1),
+                                 frac_executed_of_fp16_peak=round(3 * fn_flop / max(fn_tot, 1e-9) / 1e9 / (PEAK_F16_DENSE / 1e12), 3),
+                                 per_shape=fn_launches))
+    # the same forward with PyTorch's own convolutions / norms / linears around the same attention kernel (rounds 1-4)
+    os.environ["FRESCO_GMFLOW_LIBRARY_OPS"] = "1"
+    t_lib = 1e9
+    with torch.no_grad():
+        for rep in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            m(imgs, imgs[nxt], **kw)
+            torch.cuda.synchronize(); t_lib = min(t_lib, time.perf_counter() - t0)
+    del os.environ["FRESCO_GMFLOW_LIBRARY_OPS"]
+    res["gmflow_forward_library_ops_ms"] = round(1e3 * t_lib, 2)
     if best:
         res["roofline"] = dict(bound="mfma", kernel="kv_split_kernel + attn_f32p_kernel<128,128> (swin window attention, B 64, L 1024, D 128)",
                                achieved=best["executed_fp16_tflops"], peak=PEAK_F16_DENSE / 1e12, unit="TFLOP/s",
