@@ -36,7 +36,20 @@ __device__ __forceinline__ void fn_split(float x, float scale, half_t& h, half_t
 // ------------------------------------------------------------------------------------------------------------------------
 struct FnConv {  // implicit-GEMM view of an NHWC tensor; kh == 0: A is a plain row-major matrix
     int kh, kw, stride, pad, H, W, OH, OW, cin;  // cin = channels per pixel of the (padded) input rows
+    int tiled;                                   // 1: a workgroup's 128 rows are an 8 x 16 patch of output pixels
 };
+
+// Row r (0 .. 127) of row block `blk` -> output row m.  Linear layers and odd-sized maps: m = blk * 128 + r.  Convolutions on
+// maps of whole 8 x 16 patches: the block is a PATCH of one image, so that the 3 x 3 taps of its 128 pixels touch a
+// 10 x 18 window of the input (23 KB per operand plane: the (ky, kx) chunks re-read it from L1 / L2) instead of three
+// 130-pixel row segments (50 KB: thrashes the 32 KB L1).  The output keeps its NHWC row order either way.
+__device__ __forceinline__ int fn_row_of(const FnConv& cv, int blk, int r) {
+    if (!cv.tiled) return blk * 128 + r;
+    const int tw = cv.OW >> 4, per_img = (cv.OH >> 3) * tw;
+    const int img = blk / per_img, t = blk - img * per_img;
+    const int ty = t / tw, tx = t - ty * tw;
+    return (img * cv.OH + ty * 8 + (r >> 4)) * cv.OW + tx * 16 + (r & 15);
+}
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restrict__ a_hi, const half_t* __restrict__ a_lo,
@@ -44,7 +57,8 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
                                                          const half_t* __restrict__ w_lo, const float* __restrict__ bias,
                                                          float* __restrict__ out, half_t* __restrict__ o_hi,
                                                          half_t* __restrict__ o_lo, int64_t ldc, int64_t ldo, int M, int N,
-                                                         int K, int act, float acc_scale, float split_scale) {
+                                                         int K, int act, float acc_scale, float split_scale,
+                                                         double* __restrict__ stats) {
     constexpr int BM = 128, BK = 32;
     constexpr int ROW = BK * 2 + 16;            // LDS bytes per operand row (5 x 16 B: conflict-free b128 reads)
     constexpr int A_BYTES = BM * ROW, W_BYTES = BN * ROW;
@@ -55,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * BN;
 
     // ---- loaders: 16-byte pieces.  A tile: 128 rows x 4 pieces (x hi, lo); W tile: BN rows x 4 pieces
     constexpr int APT = BM * 4 / 256;           // A pieces per thread and plane (2)
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
         const int id = tid + i * 256;
         a_row[i] = id >> 2;
         a_pc[i] = id & 3;
-        const int m = m0 + a_row[i];
+        const int m = fn_row_of(cv, blockIdx.x, a_row[i]);
         a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
         if (cv.kh == 0) {
@@ -185,29 +199,67 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
             __syncthreads();
         }
     }
-    // ---- epilogue: lane (l31, hi) holds column n = .. + l31 and rows (r & 3) + 8 (r >> 2) + 4 hi of each 32 x 32 block
+    // ---- epilogue: lane (l31, hi) holds column n = .. + l31 and rows (r & 3) + 8 (r >> 2) + 4 hi of each 32 x 32 block.
+    // fp32 results go out as they sit (a store instruction writes 32 consecutive floats of one row = one 128-byte line).
+    // The (hi, lo) planes would be 2-byte stores, 64 bytes per row and instruction: they are transposed through the wave's
+    // share of the (now free) operand ring instead -- [64 rows][WN columns] halfs per plane -- and leave as 16-byte pieces.
+    // stats != NULL: per-column sum and sum of squares of the (pre-activation-free) results over this wave's 64 rows, fp64,
+    // into slab (row block * 2 + wm) of the InstanceNorm partial-sum buffer (fn_colstats_final_kernel adds the slabs in order).
+    __syncthreads();  // every wave is done with the ring
+    constexpr int TROW = WN * 2 + 16;  // bytes per transposed row (odd number of 16-byte units)
+    char* th = smem + wave * (2 * 64 * TROW);
+    char* tl = th + 64 * TROW;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
-        if (n >= N) continue;
-        const float b = bias ? bias[n] : 0.f;
+        const bool nok = n < N;
+        const float b = (bias && nok) ? bias[n] : 0.f;
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m >= M) continue;
+                const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int m = fn_row_of(cv, blockIdx.x, rl);
                 float v = acc[i][j][r] * acc_scale + b;
                 if (act == 1) v = fmaxf(v, 0.f);
                 if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU() (exact, erf form)
-                if (out) out[(int64_t)m * ldc + n] = v;
+                const bool ok = nok && m < M;
+                if (out && ok) out[(int64_t)m * ldc + n] = v;
+                if (stats && ok) {
+                    s1 += (double)v;
+                    s2 += (double)v * (double)v;
+                }
                 if (o_hi) {
                     half_t h, l;
                     fn_split(v, split_scale, h, l);
-                    o_hi[(int64_t)m * ldo + n] = h;
-                    o_lo[(int64_t)m * ldo + n] = l;
+                    const int off = (rl - wm * 64) * TROW + (j * 32 + l31) * 2;
+                    *reinterpret_cast<half_t*>(th + off) = h;
+                    *reinterpret_cast<half_t*>(tl + off) = l;
                 }
             }
+        if (stats) {  // the two half-waves hold the two row halves of the same column: add them in a fixed order
+            const double t1 = __shfl_xor(s1, 32, 64), t2 = __shfl_xor(s2, 32, 64);
+            if (hi == 0 && nok) {
+                double* o = stats + (((int64_t)blockIdx.x * 2 + wm) * N + n) * 2;
+                o[0] = s1 + t1;
+                o[1] = s2 + t2;
+            }
+        }
+    }
+    if (o_hi) {
+        // (same wave wrote what it reads: no barrier, only the LDS counter)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int PPR = WN / 8;  // 16-byte pieces per row
+#pragma unroll
+        for (int it = 0; it < 64 * PPR / 64; ++it) {
+            const int id = it * 64 + lane, rr = id / PPR, pc = id % PPR;
+            const int m = fn_row_of(cv, blockIdx.x, wm * 64 + rr), n = n0 + wn * WN + pc * 8;
+            if (m < M && n < N) {  // (N % 8 == 0 for split outputs: checked by the launcher)
+                *reinterpret_cast<half8_t*>(o_hi + (int64_t)m * ldo + n) = *reinterpret_cast<const half8_t*>(th + rr * TROW + pc * 16);
+                *reinterpret_cast<half8_t*>(o_lo + (int64_t)m * ldo + n) = *reinterpret_cast<const half8_t*>(tl + rr * TROW + pc * 16);
+            }
+        }
     }
 }
 
@@ -405,19 +457,24 @@ using namespace fresco;
 extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, const void* w_hi, const void* w_lo,
                               const float* bias, float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M,
                               int N, int K, int act, float acc_scale, float split_scale, int n_img, int H, int W, int kh,
-                              int kw, int stride, int pad, void* stream) {
+                              int kw, int stride, int pad, void* stats, void* stream) {
     if (!a_hi || !a_lo || !w_hi || !w_lo || (!out && !out_hi) || (out_hi && !out_lo) || M <= 0 || N <= 0 || K <= 0)
         return FRESCO_EINVAL;
     if (K % 32 != 0 || lda % 8 != 0 || act < 0 || act > 2) return FRESCO_EUNSUPPORTED;
     if ((out && ldc < N) || (out_hi && ldo < N)) return FRESCO_EINVAL;
-    FnConv cv = {0, 0, 1, 0, 0, 0, 0, 0, 0};
+    if (out_hi && (N % 8 != 0 || ldo % 8 != 0)) return FRESCO_EUNSUPPORTED;
+    FnConv cv = {0, 0, 1, 0, 0, 0, 0, 0, 0, 0};
     if (kh > 0) {
         if (kw <= 0 || stride <= 0 || pad < 0 || n_img <= 0 || H <= 0 || W <= 0) return FRESCO_EINVAL;
         const int cin = K / (kh * kw);
         if (cin * kh * kw != K || cin % 32 != 0 || lda < cin) return FRESCO_EUNSUPPORTED;
         const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
         if ((int64_t)n_img * OH * OW != M) return FRESCO_EINVAL;
-        cv = FnConv{kh, kw, stride, pad, H, W, OH, OW, cin};
+        cv = FnConv{kh, kw, stride, pad, H, W, OH, OW, cin, (OH % 8 == 0 && OW % 16 == 0) ? 1 : 0};
+        // fused InstanceNorm partial sums: a row block must not straddle two images
+        if (stats && ((int64_t)OH * OW) % 128 != 0) return FRESCO_EUNSUPPORTED;
+    } else if (stats) {
+        return FRESCO_EUNSUPPORTED;
     } else if (lda < K) {
         return FRESCO_EINVAL;
     }
@@ -433,14 +490,14 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
         constexpr int BN = 64;
         const int lds = 2 * (2 * 128 * 80 + 2 * BN * 80);
         hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3((M + 127) / 128, (N + BN - 1) / BN), dim3(256), lds, st, ah, al, lda, cv,
-                           wh, wl, bias, out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale);
+                           wh, wl, bias, out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, static_cast<double*>(stats));
     } else {
         constexpr int BN = 128;
         const int lds = 2 * (2 * 128 * 80 + 2 * BN * 80);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3((M + 127) / 128, (N + BN - 1) / BN), dim3(256), lds, st, ah, al, lda, cv,
-                           wh, wl, bias, out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale);
+                           wh, wl, bias, out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, static_cast<double*>(stats));
     }
     return check_launch();
 }
@@ -463,6 +520,17 @@ extern "C" int fresco_fn_colstats(const float* x, float* mean, float* rstd, void
     const int total = n_img * C;
     hipLaunchKernelGGL(fn_colstats_final_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, mean, rstd, slabs, C, rows,
                        eps, total);
+    return check_launch();
+}
+
+/* Finish InstanceNorm statistics from the partial sums fresco_fn_gemm left in `stats` (its `stats` argument): slabs =
+ * 2 * (rows / 128) per image. */
+extern "C" int fresco_fn_colstats_finish(const void* stats, float* mean, float* rstd, int n_img, int rows, int C, float eps,
+                                         void* stream) {
+    if (!stats || !mean || !rstd || n_img <= 0 || rows <= 0 || C <= 0 || rows % 128 != 0) return FRESCO_EINVAL;
+    const int total = n_img * C;
+    hipLaunchKernelGGL(fn_colstats_final_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
+                       static_cast<const double*>(stats), mean, rstd, 2 * (rows / 128), C, rows, eps, total);
     return check_launch();
 }
 

@@ -1017,6 +1017,9 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
 // conflict-free (the padded S rows had 2-way conflicts: 25 % of the LDS cycles, profiles/r04_pmc_removed_gram16x_kernel.csv), and
 // three slots (72 KB) fit twice per CU: chunks arrive two steps ahead.
 // ------------------------------------------------------------------------------------------------
+#ifndef FRESCO_SV_SPLIT_READS
+#define FRESCO_SV_SPLIT_READS 1
+#endif
 constexpr int SB_TC = 128, SB_K = 32;
 constexpr int SB_VROW = SB_K * 2, SB_SROW = SB_K;
 constexpr int SB_NSLOT = 3;
@@ -1119,7 +1122,13 @@ __global__ __launch_bounds__(512, 4) void sv16b_kernel(const half_t* __restrict_
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const u32x2 raw = *reinterpret_cast<const u32x2*>(base + rs + j * 32 * SB_SROW + us);
+                // (round 5: hipcc fused the NJ reads of a k-step into ONE ds_read2st64_b64 -- which the LDS services in
+                // 16-lane groups against 32 banks: 8 cycles + 2-way conflicts on these 32-byte rows, SQ_LDS_BANK_CONFLICT = 24 %
+                // of the LDS cycles in profiles/r05_pmc_opt_C640_h64.csv -- where two ds_read_b64 take 2 conflict-free cycles
+                // each (32-lane groups, 64 banks: the layout the swizzle was designed for).  The laundered offset keeps them apart.)
+                int sj = j * 32 * SB_SROW;
+                if (FRESCO_SV_SPLIT_READS && j > 0) asm volatile("" : "+v"(sj));
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(base + rs + sj + us);
                 u32x4 w;
                 w[0] = __builtin_amdgcn_perm(0u, raw[0], 0x010c000cu);
                 w[1] = __builtin_amdgcn_perm(0u, raw[0], 0x030c020cu);

@@ -227,27 +227,26 @@ class _Weights:
         return val
 
 
-def _conv(wts, x_split, conv, n, H, W, stride, act=0, want_f32=True, want_split=False, pad_cin=None):
-    """Conv2d on the NHWC tensor behind the planes x_split -> rows (n * OH * OW, cout)"""
+def _conv(wts, x_split, conv, n, H, W, stride, act=0, want_f32=True, want_split=False, pad_cin=None, norm=None):
+    """Conv2d on the NHWC tensor behind the planes x_split -> rows (n * OH * OW, cout); norm: the InstanceNorm2d module that
+    follows (its statistics come out of the convolution's epilogue)"""
     kh = conv.kernel_size[0]
     w = wts.get(conv.weight, "conv", pad_cin)
     K = w[0].shape[1]
     return ops.fn_gemm(x_split, w, conv.out_channels, K, bias=conv.bias, act=act,
-                       conv=(n, H, W, kh, kh, stride, conv.padding[0]), want_f32=want_f32, want_split=want_split)
+                       conv=(n, H, W, kh, kh, stride, conv.padding[0]), want_f32=want_f32, want_split=want_split,
+                       instance_norm_eps=None if norm is None else norm.eps)
 
 
 def _res_block(wts, blk, x, xs, n, H, W):
     """ResidualBlock.forward on NHWC rows: x fp32 (n H W, cin), xs its planes -> (out fp32, planes, OH, OW)"""
     s = blk.conv1.stride[0]
     OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
-    c1, _ = _conv(wts, xs, blk.conv1, n, H, W, s)
-    m1, r1 = ops.fn_colstats(c1, n)
+    c1, _, (m1, r1) = _conv(wts, xs, blk.conv1, n, H, W, s, norm=blk.norm1)
     _, a1 = ops.fn_prep(c1, m1, r1, rows_per_img=OH * OW, relu_a=True)
-    c2, _ = _conv(wts, a1, blk.conv2, n, OH, OW, 1)
-    m2, r2 = ops.fn_colstats(c2, n)
+    c2, _, (m2, r2) = _conv(wts, a1, blk.conv2, n, OH, OW, 1, norm=blk.norm2)
     if blk.downsample is not None:
-        c3, _ = _conv(wts, xs, blk.downsample[0], n, H, W, s)
-        m3, r3 = ops.fn_colstats(c3, n)
+        c3, _, (m3, r3) = _conv(wts, xs, blk.downsample[0], n, H, W, s, norm=blk.downsample[1])
         x, _ = ops.fn_prep(c3, m3, r3, rows_per_img=OH * OW, want_f32=True, want_split=False)
     out, outs = ops.fn_prep(c2, m2, r2, residual=x, rows_per_img=OH * OW, relu_a=True, relu_b=True, want_f32=True)
     return out, outs, OH, OW
@@ -259,7 +258,7 @@ def _backbone_native(bb, wts, x_nchw):
     c = ops.fn_conv7_rgb(x_nchw.permute(0, 2, 3, 1).contiguous(), wts.get(bb.conv1.weight, "stem"))
     H, W = c.shape[1], c.shape[2]
     c = c.view(n * H * W, 64)
-    m, r = ops.fn_colstats(c, n)
+    m, r = ops.fn_colstats(c, n, bb.norm1.eps)
     x, xs = ops.fn_prep(c, m, r, rows_per_img=H * W, relu_a=True, want_f32=True)
     for layer in (bb.layer1, bb.layer2, bb.layer3):
         for blk in layer:

@@ -298,10 +298,13 @@ def fn_colstats(x, n_img, eps=1e-5):
     return mean, rstd
 
 
-def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want_split=False, out_split=None):
+def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want_split=False, out_split=None,
+            instance_norm_eps=None):
     """act(A W^T + bias) (fresco_fn_gemm).  a = (hi, lo) planes, (rows, lda); w = (hi, lo) planes (N, K).
     conv = (n_img, H, W, kh, kw, stride, pad): implicit im2col of the NHWC tensor behind `a` (K = kh kw cin).
-    Returns (out fp32 (M, N) or None, (hi, lo) (M, N) or None)."""
+    instance_norm_eps (convolutions): also return InstanceNorm2d statistics (mean, rstd) of the result, from partial sums
+    the kernel's epilogue leaves behind (no second pass over the output).
+    Returns (out fp32 (M, N) or None, (hi, lo) (M, N) or None[, (mean, rstd)])."""
     ah, al = a
     wh, wl = w
     _need_gpu(ah, wh)
@@ -323,11 +326,26 @@ def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want
     elif want_split:
         oh = torch.empty(M, N, dtype=torch.float16, device=dev)
         ol = torch.empty(M, N, dtype=torch.float16, device=dev)
-    rc = _lib.load().fresco_fn_gemm(ah.data_ptr(), al.data_ptr(), lda, wh.data_ptr(), wl.data_ptr(), _ptr(bias), _ptr(out),
-                                    _ptr(oh), _ptr(ol), N, int(ldo), M, N, K, int(act), 1.0 / (FN_A_SCALE * FN_W_SCALE),
-                                    FN_A_SCALE, *cargs, _stream())
+    stats = None
+    fused = instance_norm_eps is not None and conv is not None and (M // conv[0]) % 128 == 0
+    if fused:
+        stats = torch.empty(2 * (M // 128) * N * 2, dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    rc = lib.fresco_fn_gemm(ah.data_ptr(), al.data_ptr(), lda, wh.data_ptr(), wl.data_ptr(), _ptr(bias), _ptr(out),
+                            _ptr(oh), _ptr(ol), N, int(ldo), M, N, K, int(act), 1.0 / (FN_A_SCALE * FN_W_SCALE),
+                            FN_A_SCALE, *cargs, _ptr(stats), _stream())
     _lib.check(rc, "fresco_fn_gemm(M=%d,N=%d,K=%d,conv=%s)" % (M, N, K, conv))
-    return out, ((oh, ol) if oh is not None else None)
+    res = (out, ((oh, ol) if oh is not None else None))
+    if instance_norm_eps is None:
+        return res
+    if not fused:
+        return res + (fn_colstats(out, conv[0], instance_norm_eps),)
+    mean = torch.empty(conv[0], N, dtype=torch.float32, device=dev)
+    rstd = torch.empty(conv[0], N, dtype=torch.float32, device=dev)
+    rc = lib.fresco_fn_colstats_finish(stats.data_ptr(), mean.data_ptr(), rstd.data_ptr(), conv[0], M // conv[0], N,
+                                       float(instance_norm_eps), _stream())
+    _lib.check(rc, "fresco_fn_colstats_finish")
+    return res + ((mean, rstd),)
 
 
 def fn_layernorm(x, gamma, beta, residual=None, eps=1e-5, want_f32=True, want_split=False, out_split=None):

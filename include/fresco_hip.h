@@ -236,17 +236,21 @@ int fresco_attn_f32_guarded(const float* q, const float* k, const float* v, floa
  *   kh  > 0: implicit im2col of an NHWC tensor (n_img, H, W, cin = K / (kh kw)), pixel stride lda >= cin, cin % 32 == 0,
  *            k = (ky, kx, ci), zero padding `pad`, stride `stride`; M must be n_img * OH * OW    -- nn.Conv2d
  *   w_hi / w_lo: (N, K) row-major fp16 planes; bias (N) fp32 or NULL; act 0 none, 1 ReLU, 2 GELU (erf form).
- *   out (M, ldc) fp32 and / or out_hi / out_lo (M, ldo) fp16 planes of the result (either may be NULL, not both). */
+ *   out (M, ldc) fp32 and / or out_hi / out_lo (M, ldo) fp16 planes of the result (either may be NULL, not both; planes need
+ *   N % 8 == 0).  stats (convolutions whose OH * OW is a multiple of 128; else NULL): 2 * (M / 128) * N * 2 doubles that
+ *   receive per-column partial sums / sums of squares of the results for fresco_fn_colstats_finish (InstanceNorm2d without a
+ *   second pass over the convolution's output). */
 int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, const void* w_hi, const void* w_lo, const float* bias,
                    float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M, int N, int K, int act,
                    float acc_scale, float split_scale, int n_img, int H, int W, int kh, int kw, int stride, int pad,
-                   void* stream);
+                   void* stats, void* stream);
 
 /* nn.InstanceNorm2d statistics (affine=False, biased variance): x (n_img * rows, C) fp32 NHWC -> mean, rstd = 1 / sqrt(var +
  * eps), (n_img, C) each.  fp64 partial sums in a fixed order.  C <= 256. */
 size_t fresco_fn_colstats_workspace_bytes(int n_img, int rows, int C);
 int fresco_fn_colstats(const float* x, float* mean, float* rstd, void* workspace, size_t workspace_bytes, int n_img, int rows,
                        int C, float eps, void* stream);
+int fresco_fn_colstats_finish(const void* stats, float* mean, float* rstd, int n_img, int rows, int C, float eps, void* stream);
 
 /* y = relu_b?( relu_a?( (x - mean[img]) * rstd[img] ) + residual ) on (M, C) fp32 rows (mean / rstd / residual may be NULL;
  * img = m / rows_per_img).  Writes y (M, C) fp32 and / or the fp16 planes out_hi / out_lo with row stride ldo >= C, channels

@@ -45,7 +45,9 @@ def test_fn_gemm_linear(M, K, N, act, bias):
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,bias", [(64, 64, 3, 1, 1, 20, 28, False), (64, 96, 3, 2, 1, 20, 28, False),
                                                             (96, 128, 3, 2, 1, 16, 24, False), (64, 96, 1, 2, 0, 20, 28, True),
-                                                            (128, 128, 3, 1, 1, 9, 13, False), (130, 256, 3, 1, 1, 8, 12, True)])
+                                                            (128, 128, 3, 1, 1, 9, 13, False), (130, 256, 3, 1, 1, 8, 12, True),
+                                                            (64, 64, 3, 1, 1, 32, 32, False), (64, 96, 3, 2, 1, 32, 64, False),
+                                                            (96, 128, 1, 2, 0, 32, 64, True)])
 def test_fn_gemm_implicit_conv(cin, cout, k, stride, pad, H, W, bias):
     """nn.Conv2d as the implicit GEMM over NHWC rows: every encoder / upsampler shape class (3 x 3 stride 1 / 2, the 1 x 1
     stride-2 shortcut with bias, a map whose width is no multiple of anything, and the 130-channel input padded to 160)"""
@@ -62,9 +64,15 @@ def test_fn_gemm_implicit_conv(cin, cout, k, stride, pad, H, W, bias):
     _, xs = ops.fn_prep(xr.contiguous().to(DEV), ld=cp)
     wr = F.pad(w.permute(0, 2, 3, 1), (0, cp - cin)).reshape(cout, -1).contiguous()
     _, ws = ops.fn_prep(wr.to(DEV), scale=ops.FN_W_SCALE)
-    out, _ = ops.fn_gemm(xs, ws, cout, k * k * cp, bias=None if b is None else b.to(DEV), conv=(n, H, W, k, k, stride, pad))
+    out, _, (mean, rstd) = ops.fn_gemm(xs, ws, cout, k * k * cp, bias=None if b is None else b.to(DEV),
+                                       conv=(n, H, W, k, k, stride, pad), instance_norm_eps=1e-5)
     ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride=stride, padding=pad)
     OH, OW = ref.shape[2], ref.shape[3]
+    # InstanceNorm2d statistics of the result: out of the epilogue's partial sums when OH * OW % 128 == 0 (the last three
+    # cases, which also take the 8 x 16 patch order of the row blocks), else from a second pass (fresco_fn_colstats)
+    rf = ref.reshape(n, cout, -1)
+    assert float((mean.cpu().double() - rf.mean(2)).abs().max()) < 2e-6
+    assert float((rstd.cpu().double() * (rf.var(2, unbiased=False) + 1e-5).sqrt() - 1).abs().max()) < 1e-5
     got = out.view(n, OH, OW, cout).permute(0, 3, 1, 2).cpu().double()
     bar = _bar(F.conv2d(x.abs().double(), w.abs().double(), None, stride=stride, padding=pad))
     err = float((got - ref).abs().max())
