@@ -11,9 +11,10 @@
 // GEMM's loaders move 16-byte pieces of ready operands and no conversion sits between the loads and the MFMAs.
 //
 //   fn_gemm_kernel<BN>   out[m][n] = sum_k A(m, k) W[n][k] (+ bias, GELU / ReLU), A either row-major (linear layers) or the
-//                        implicit im2col view of an NHWC tensor (k = (ky, kx, ci), zero padding): 128 x BN x 32 tiles,
-//                        4 waves, operands double-buffered in LDS (80-byte rows: conflict-free ds_read_b128), fp32 result
-//                        and / or its (hi, lo) split written by the epilogue
+//                        implicit im2col view of an NHWC tensor (k = (ky, kx, ci), zero padding): 256 x BN x 32 tiles,
+//                        8 waves, operands by LDS-DMA into a 3-slot ring (source-side swizzle, counted vmcnt, one barrier
+//                        per chunk), fp32 result and / or its (hi, lo) split and / or InstanceNorm partial sums written
+//                        by the epilogue
 //   fn_colstats_kernel   InstanceNorm2d statistics: mean and 1 / sqrt(biased var + eps) per (image, channel), fp64 partial
 //                        sums in a fixed order (deterministic)
 //   fn_prep_kernel       y = [relu]( [relu]((x - mean) rstd) + residual ) -> fp32 and / or (hi, lo), channel-padded rows
@@ -36,54 +37,72 @@ __device__ __forceinline__ void fn_split(float x, float scale, half_t& h, half_t
 // ------------------------------------------------------------------------------------------------------------------------
 struct FnConv {  // implicit-GEMM view of an NHWC tensor; kh == 0: A is a plain row-major matrix
     int kh, kw, stride, pad, H, W, OH, OW, cin;  // cin = channels per pixel of the (padded) input rows
-    int tiled;                                   // 1: a workgroup's 128 rows are an 8 x 16 patch of output pixels
+    int tiled;                                   // 1: a workgroup's 256 rows are a 16 x 16 patch of output pixels
 };
 
-// Row r (0 .. 127) of row block `blk` -> output row m.  Linear layers and odd-sized maps: m = blk * 128 + r.  Convolutions on
-// maps of whole 8 x 16 patches: the block is a PATCH of one image, so that the 3 x 3 taps of its 128 pixels touch a
-// 10 x 18 window of the input (23 KB per operand plane: the (ky, kx) chunks re-read it from L1 / L2) instead of three
-// 130-pixel row segments (50 KB: thrashes the 32 KB L1).  The output keeps its NHWC row order either way.
+constexpr int FN_BM = 256, FN_BK = 32, FN_NS = 3;
+
+// Row r (0 .. 255) of row block `blk` -> output row m.  Linear layers and odd-sized maps: m = blk * 256 + r.  Convolutions on
+// maps of whole 16 x 16 patches: the block is a PATCH of one image, so that the 3 x 3 taps of its 256 pixels touch an
+// 18 x 18 window of the input (the nine (ky, kx) chunks re-read it from L1 / L2) instead of a 256-pixel row segment times
+// three rows.  The output keeps its NHWC row order either way.
 __device__ __forceinline__ int fn_row_of(const FnConv& cv, int blk, int r) {
-    if (!cv.tiled) return blk * 128 + r;
-    const int tw = cv.OW >> 4, per_img = (cv.OH >> 3) * tw;
+    if (!cv.tiled) return blk * FN_BM + r;
+    const int tw = cv.OW >> 4, per_img = (cv.OH >> 4) * tw;
     const int img = blk / per_img, t = blk - img * per_img;
     const int ty = t / tw, tx = t - ty * tw;
-    return (img * cv.OH + ty * 8 + (r >> 4)) * cv.OW + tx * 16 + (r & 15);
+    return (img * cv.OH + ty * 16 + (r >> 4)) * cv.OW + tx * 16 + (r & 15);
 }
 
+// one LDS-DMA piece: 64 lanes x 16 bytes, lane l's bytes land at lds_dst + 16 l (M0 is written in the statement that uses it)
+__device__ __forceinline__ void fn_dma16(const void* gsrc, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N_>
+__device__ __forceinline__ void fn_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_) : "memory");
+}
+
+// 256 x BN x 32 tiles, 8 waves as 4 x 2 (wave tiles 64 x BN/2), one workgroup per CU.  Operands arrive by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write) into a ring of three slots, chunks two steps ahead, behind
+// counted vmcnt waits and ONE barrier per chunk (the protocol of opt_fast.hip's Gram / S V kernels).  A slot holds the four
+// planes [A hi | A lo | W hi | W lo] as unpadded 64-byte rows (32 halfs): the DMA writes lane-linear, so the bank swizzle is on
+// the SOURCE side -- the lane that owns LDS position q of row R fetches 16-byte piece q ^ ((R >> 2) & 3) of that row -- and
+// on the read side (fragment piece p of row R sits at position p ^ ((R >> 2) & 3)): conflict-free ds_read_b128 in the b128
+// lane groups.  Rows outside the problem (m >= M, n >= N, the zero padding of a convolution) are fetched from a 16-byte
+// page of zeros.
 template <int BN>
-__global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restrict__ a_hi, const half_t* __restrict__ a_lo,
+__global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restrict__ a_hi, const half_t* __restrict__ a_lo,
                                                          int64_t lda, FnConv cv, const half_t* __restrict__ w_hi,
                                                          const half_t* __restrict__ w_lo, const float* __restrict__ bias,
                                                          float* __restrict__ out, half_t* __restrict__ o_hi,
                                                          half_t* __restrict__ o_lo, int64_t ldc, int64_t ldo, int M, int N,
                                                          int K, int act, float acc_scale, float split_scale,
-                                                         double* __restrict__ stats) {
-    constexpr int BM = 128, BK = 32;
-    constexpr int ROW = BK * 2 + 16;            // LDS bytes per operand row (5 x 16 B: conflict-free b128 reads)
-    constexpr int A_BYTES = BM * ROW, W_BYTES = BN * ROW;
-    constexpr int STAGE = 2 * A_BYTES + 2 * W_BYTES;
-    constexpr int WN = BN / 2;                  // wave tile: 64 rows x WN columns (waves 2 x 2)
-    constexpr int NB = WN / 32;
+                                                         double* __restrict__ stats, const void* __restrict__ zeros) {
+    constexpr int BM = FN_BM, BK = FN_BK, NS = FN_NS;
+    constexpr int A_PL = BM * 64, W_PL = BN * 64;          // bytes per plane and slot
+    constexpr int SLOT = 2 * A_PL + 2 * W_PL;
+    constexpr int WN = BN / 2, NB = WN / 32;
+    constexpr int NPW = 4 + (BN == 128 ? 2 : 1);           // DMA pieces per wave and chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.y * BN;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
 
-    // ---- loaders: 16-byte pieces.  A tile: 128 rows x 4 pieces (x hi, lo); W tile: BN rows x 4 pieces
-    constexpr int APT = BM * 4 / 256;           // A pieces per thread and plane (2)
-    constexpr int WPT = BN * 4 / 256;           // W pieces per thread and plane (2 or 1)
-    int a_row[APT], a_pc[APT];
-    int64_t a_base[APT];                        // row-major: element offset of the row; conv: pixel (img, oy*s - p, ox*s - p)
-    int a_iy[APT], a_ix[APT];
-    bool a_ok[APT];
+    // ---- DMA sources.  A: this wave copies pieces 2 wave, 2 wave + 1 of both A planes (16 rows each); a lane owns LDS
+    // position q = lane & 3 of row R = 16 piece + (lane >> 2) and fetches source piece q ^ ((R >> 2) & 3) of that row
+    const int q = lane & 3;
+    int a_pc[2], a_iy[2], a_ix[2];
+    int64_t a_base[2];
+    bool a_ok[2];
 #pragma unroll
-    for (int i = 0; i < APT; ++i) {
-        const int id = tid + i * 256;
-        a_row[i] = id >> 2;
-        a_pc[i] = id & 3;
-        const int m = fn_row_of(cv, blockIdx.x, a_row[i]);
+    for (int i = 0; i < 2; ++i) {
+        const int R = (2 * wave + i) * 16 + (lane >> 2);
+        a_pc[i] = q ^ ((R >> 2) & 3);
+        const int m = fn_row_of(cv, blockIdx.x, R);
         a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
         if (cv.kh == 0) {
@@ -98,18 +117,15 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
             a_base[i] = (int64_t)img * cv.H * cv.W;
         }
     }
-    int w_row[WPT], w_pc[WPT];
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        const int id = tid + i * 256;
-        w_row[i] = id >> 2;
-        w_pc[i] = id & 3;
-    }
+    // W: BN = 128: piece `wave` of both W planes; BN = 64: waves 0-3 piece `wave` of W hi, waves 4-7 piece wave - 4 of W lo
+    const int w_piece = BN == 128 ? wave : (wave & 3);
+    const int w_R = w_piece * 16 + (lane >> 2);
+    const int w_pc = q ^ ((w_R >> 2) & 3);
+    const bool w_ok = n0 + w_R < N;
+    const int64_t w_off = (int64_t)(w_ok ? n0 + w_R : 0) * K + w_pc * 8;
     const int nk = K / BK;
-    half8_t ra_h[APT], ra_l[APT], rw_h[WPT], rw_l[WPT];
-    const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    auto gload = [&](int kc) __attribute__((always_inline)) {
+    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
         const int k0 = kc * BK;
         int ky = 0, kx = 0, c0 = k0;
         if (cv.kh != 0) {  // a 32-channel chunk lies inside one (ky, kx): cin % 32 == 0
@@ -118,8 +134,9 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
             ky = t / cv.kw;
             kx = t - ky * cv.kw;
         }
+        const uint32_t sb = lds0 + (uint32_t)(slot * SLOT);
 #pragma unroll
-        for (int i = 0; i < APT; ++i) {
+        for (int i = 0; i < 2; ++i) {
             bool ok = a_ok[i];
             int64_t off;
             if (cv.kh == 0) {
@@ -129,29 +146,18 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
                 ok = ok && iy >= 0 && iy < cv.H && ix >= 0 && ix < cv.W;
                 off = (a_base[i] + (int64_t)iy * cv.W + ix) * lda + c0 + a_pc[i] * 8;
             }
-            ra_h[i] = ok ? *reinterpret_cast<const half8_t*>(a_hi + off) : zero8;
-            ra_l[i] = ok ? *reinterpret_cast<const half8_t*>(a_lo + off) : zero8;
+            const void* ph = ok ? static_cast<const void*>(a_hi + off) : zeros;
+            const void* pl = ok ? static_cast<const void*>(a_lo + off) : zeros;
+            fn_dma16(ph, sb + (uint32_t)((2 * wave + i) * 1024));
+            fn_dma16(pl, sb + (uint32_t)(A_PL + (2 * wave + i) * 1024));
         }
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int n = n0 + w_row[i];
-            const bool ok = n < N;
-            const int64_t off = (int64_t)(ok ? n : 0) * K + k0 + w_pc[i] * 8;
-            rw_h[i] = ok ? *reinterpret_cast<const half8_t*>(w_hi + off) : zero8;
-            rw_l[i] = ok ? *reinterpret_cast<const half8_t*>(w_lo + off) : zero8;
-        }
-    };
-    auto sstore = [&](int stage) __attribute__((always_inline)) {
-        char* s = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            *reinterpret_cast<half8_t*>(s + a_row[i] * ROW + a_pc[i] * 16) = ra_h[i];
-            *reinterpret_cast<half8_t*>(s + A_BYTES + a_row[i] * ROW + a_pc[i] * 16) = ra_l[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            *reinterpret_cast<half8_t*>(s + 2 * A_BYTES + w_row[i] * ROW + w_pc[i] * 16) = rw_h[i];
-            *reinterpret_cast<half8_t*>(s + 2 * A_BYTES + W_BYTES + w_row[i] * ROW + w_pc[i] * 16) = rw_l[i];
+        if (BN == 128) {
+            fn_dma16(w_ok ? static_cast<const void*>(w_hi + w_off + k0) : zeros, sb + (uint32_t)(2 * A_PL + wave * 1024));
+            fn_dma16(w_ok ? static_cast<const void*>(w_lo + w_off + k0) : zeros, sb + (uint32_t)(2 * A_PL + W_PL + wave * 1024));
+        } else {
+            const half_t* wp = wave < 4 ? w_hi : w_lo;
+            fn_dma16(w_ok ? static_cast<const void*>(wp + w_off + k0) : zeros,
+                     sb + (uint32_t)(2 * A_PL + (wave < 4 ? 0 : W_PL) + (wave & 3) * 1024));
         }
     };
 
@@ -163,27 +169,34 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    sstore(0);
-    __syncthreads();
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    const int sw = (l31 >> 2) & 3;
+    int slot = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        const int st = kc & 1;
-        if (kc + 1 < nk) gload(kc + 1);  // in flight under the MFMAs of this chunk
-        const char* s = smem + st * STAGE;
-        const char* sa = s + (wm * 64 + l31) * ROW + hi * 16;
-        const char* sw = s + 2 * A_BYTES + (wn * WN + l31) * ROW + hi * 16;
+        // own pieces of chunk kc have landed (what may still fly: chunk kc + 1's), then everyone's, and every wave is done
+        // with chunk kc - 1: its slot takes chunk kc + 2
+        if (kc + 1 < nk)
+            fn_wait_barrier<NPW>();
+        else
+            fn_wait_barrier<0>();
+        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : NS - 1);
+        const char* s = smem + slot * SLOT;
+        const char* sa = s + (wm * 64 + l31) * 64;
+        const char* sw_ = s + 2 * A_PL + (wn * WN + l31) * 64;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            const int pos = ((ks * 2 + hi) ^ sw) * 16;
             half8_t ah[2], al[2], bh[NB], bl[NB];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const half8_t*>(sa + i * 32 * ROW + ks * 32);
-                al[i] = *reinterpret_cast<const half8_t*>(sa + A_BYTES + i * 32 * ROW + ks * 32);
+                ah[i] = *reinterpret_cast<const half8_t*>(sa + i * 32 * 64 + pos);
+                al[i] = *reinterpret_cast<const half8_t*>(sa + A_PL + i * 32 * 64 + pos);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                bh[j] = *reinterpret_cast<const half8_t*>(sw + j * 32 * ROW + ks * 32);
-                bl[j] = *reinterpret_cast<const half8_t*>(sw + W_BYTES + j * 32 * ROW + ks * 32);
+                bh[j] = *reinterpret_cast<const half8_t*>(sw_ + j * 32 * 64 + pos);
+                bl[j] = *reinterpret_cast<const half8_t*>(sw_ + W_PL + j * 32 * 64 + pos);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -194,26 +207,27 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (kc + 1 < nk) {
-            sstore(st ^ 1);  // (the other stage was last read before the barrier that ended chunk kc - 1)
-            __syncthreads();
-        }
+        slot = slot == NS - 1 ? 0 : slot + 1;
     }
     // ---- epilogue: lane (l31, hi) holds column n = .. + l31 and rows (r & 3) + 8 (r >> 2) + 4 hi of each 32 x 32 block.
     // fp32 results go out as they sit (a store instruction writes 32 consecutive floats of one row = one 128-byte line).
-    // The (hi, lo) planes would be 2-byte stores, 64 bytes per row and instruction: they are transposed through the wave's
-    // share of the (now free) operand ring instead -- [64 rows][WN columns] halfs per plane -- and leave as 16-byte pieces.
-    // stats != NULL: per-column sum and sum of squares of the (pre-activation-free) results over this wave's 64 rows, fp64,
-    // into slab (row block * 2 + wm) of the InstanceNorm partial-sum buffer (fn_colstats_final_kernel adds the slabs in order).
-    __syncthreads();  // every wave is done with the ring
+    // The (hi, lo) planes would be 2-byte stores, 64 bytes per row and instruction: each plane is transposed through the
+    // wave's share of the (now free) ring instead -- [64 rows][WN columns] halfs -- and leaves as 16-byte pieces.
+    // stats != NULL: per-column sum and sum of squares of the results over this wave's 64 rows, fp64, into slab
+    // (row block * 4 + wm) of the InstanceNorm partial-sum buffer (fn_colstats_final_kernel adds the slabs in order).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the ring
     constexpr int TROW = WN * 2 + 16;  // bytes per transposed row (odd number of 16-byte units)
-    char* th = smem + wave * (2 * 64 * TROW);
-    char* tl = th + 64 * TROW;
+    char* tp = smem + wave * (64 * TROW);
+    float bcol[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        bcol[j] = (bias && n < N) ? bias[n] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
         const bool nok = n < N;
-        const float b = (bias && nok) ? bias[n] : 0.f;
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -221,43 +235,49 @@ __global__ __launch_bounds__(256, 2) void fn_gemm_kernel(const half_t* __restric
             for (int r = 0; r < 16; ++r) {
                 const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int m = fn_row_of(cv, blockIdx.x, rl);
-                float v = acc[i][j][r] * acc_scale + b;
+                float v = acc[i][j][r] * acc_scale + bcol[j];
                 if (act == 1) v = fmaxf(v, 0.f);
                 if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU() (exact, erf form)
+                acc[i][j][r] = v;
                 const bool ok = nok && m < M;
                 if (out && ok) out[(int64_t)m * ldc + n] = v;
                 if (stats && ok) {
                     s1 += (double)v;
                     s2 += (double)v * (double)v;
                 }
-                if (o_hi) {
-                    half_t h, l;
-                    fn_split(v, split_scale, h, l);
-                    const int off = (rl - wm * 64) * TROW + (j * 32 + l31) * 2;
-                    *reinterpret_cast<half_t*>(th + off) = h;
-                    *reinterpret_cast<half_t*>(tl + off) = l;
-                }
             }
         if (stats) {  // the two half-waves hold the two row halves of the same column: add them in a fixed order
             const double t1 = __shfl_xor(s1, 32, 64), t2 = __shfl_xor(s2, 32, 64);
             if (hi == 0 && nok) {
-                double* o = stats + (((int64_t)blockIdx.x * 2 + wm) * N + n) * 2;
+                double* o = stats + (((int64_t)blockIdx.x * 4 + wm) * N + n) * 2;
                 o[0] = s1 + t1;
                 o[1] = s2 + t2;
             }
         }
     }
     if (o_hi) {
-        // (same wave wrote what it reads: no barrier, only the LDS counter)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         constexpr int PPR = WN / 8;  // 16-byte pieces per row
 #pragma unroll
-        for (int it = 0; it < 64 * PPR / 64; ++it) {
-            const int id = it * 64 + lane, rr = id / PPR, pc = id % PPR;
-            const int m = fn_row_of(cv, blockIdx.x, wm * 64 + rr), n = n0 + wn * WN + pc * 8;
-            if (m < M && n < N) {  // (N % 8 == 0 for split outputs: checked by the launcher)
-                *reinterpret_cast<half8_t*>(o_hi + (int64_t)m * ldo + n) = *reinterpret_cast<const half8_t*>(th + rr * TROW + pc * 16);
-                *reinterpret_cast<half8_t*>(o_lo + (int64_t)m * ldo + n) = *reinterpret_cast<const half8_t*>(tl + rr * TROW + pc * 16);
+        for (int plane = 0; plane < 2; ++plane) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        half_t h, l;
+                        fn_split(acc[i][j][r], split_scale, h, l);
+                        const int off = (i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * TROW + (j * 32 + l31) * 2;
+                        *reinterpret_cast<half_t*>(tp + off) = plane == 0 ? h : l;
+                    }
+            // (the wave that wrote is the wave that reads: the LDS executes a wave's operations in order)
+            half_t* op = plane == 0 ? o_hi : o_lo;
+#pragma unroll
+            for (int it = 0; it < PPR; ++it) {
+                const int id = it * 64 + lane, rr = id / PPR, pc = id % PPR;
+                const int m = fn_row_of(cv, blockIdx.x, wm * 64 + rr), n = n0 + wn * WN + pc * 8;
+                const half8_t v8 = *reinterpret_cast<const half8_t*>(tp + rr * TROW + pc * 16);
+                if (m < M && n < N) *reinterpret_cast<half8_t*>(op + (int64_t)m * ldo + n) = v8;  // (N % 8 == 0: launcher)
             }
         }
     }
@@ -457,7 +477,8 @@ using namespace fresco;
 extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, const void* w_hi, const void* w_lo,
                               const float* bias, float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M,
                               int N, int K, int act, float acc_scale, float split_scale, int n_img, int H, int W, int kh,
-                              int kw, int stride, int pad, void* stats, void* stream) {
+                              int kw, int stride, int pad, void* stats, const void* zeros, void* stream) {
+    if (!zeros) return FRESCO_EINVAL;
     if (!a_hi || !a_lo || !w_hi || !w_lo || (!out && !out_hi) || (out_hi && !out_lo) || M <= 0 || N <= 0 || K <= 0)
         return FRESCO_EINVAL;
     if (K % 32 != 0 || lda % 8 != 0 || act < 0 || act > 2) return FRESCO_EUNSUPPORTED;
@@ -470,9 +491,9 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
         if (cin * kh * kw != K || cin % 32 != 0 || lda < cin) return FRESCO_EUNSUPPORTED;
         const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
         if ((int64_t)n_img * OH * OW != M) return FRESCO_EINVAL;
-        cv = FnConv{kh, kw, stride, pad, H, W, OH, OW, cin, (OH % 8 == 0 && OW % 16 == 0) ? 1 : 0};
+        cv = FnConv{kh, kw, stride, pad, H, W, OH, OW, cin, (OH % 16 == 0 && OW % 16 == 0) ? 1 : 0};
         // fused InstanceNorm partial sums: a row block must not straddle two images
-        if (stats && ((int64_t)OH * OW) % 128 != 0) return FRESCO_EUNSUPPORTED;
+        if (stats && ((int64_t)OH * OW) % FN_BM != 0) return FRESCO_EUNSUPPORTED;
     } else if (stats) {
         return FRESCO_EUNSUPPORTED;
     } else if (lda < K) {
@@ -486,18 +507,22 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
     const half_t* wl = static_cast<const half_t*>(w_lo);
     half_t* oh = static_cast<half_t*>(out_hi);
     half_t* ol = static_cast<half_t*>(out_lo);
+    double* sp = static_cast<double*>(stats);
+    const int rb = (M + FN_BM - 1) / FN_BM;
     if (N <= 64) {
         constexpr int BN = 64;
-        const int lds = 2 * (2 * 128 * 80 + 2 * BN * 80);
-        hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3((M + 127) / 128, (N + BN - 1) / BN), dim3(256), lds, st, ah, al, lda, cv,
-                           wh, wl, bias, out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, static_cast<double*>(stats));
-    } else {
-        constexpr int BN = 128;
-        const int lds = 2 * (2 * 128 * 80 + 2 * BN * 80);
+        const int lds = FN_NS * (2 * FN_BM * 64 + 2 * BN * 64);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3((M + 127) / 128, (N + BN - 1) / BN), dim3(256), lds, st, ah, al, lda, cv,
-                           wh, wl, bias, out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, static_cast<double*>(stats));
+        hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
+                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros);
+    } else {
+        constexpr int BN = 128;
+        const int lds = FN_NS * (2 * FN_BM * 64 + 2 * BN * 64);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
+                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros);
     }
     return check_launch();
 }
@@ -524,13 +549,13 @@ extern "C" int fresco_fn_colstats(const float* x, float* mean, float* rstd, void
 }
 
 /* Finish InstanceNorm statistics from the partial sums fresco_fn_gemm left in `stats` (its `stats` argument): slabs =
- * 2 * (rows / 128) per image. */
+ * rows / 64 per image (one per wave row of a 256-row block). */
 extern "C" int fresco_fn_colstats_finish(const void* stats, float* mean, float* rstd, int n_img, int rows, int C, float eps,
                                          void* stream) {
-    if (!stats || !mean || !rstd || n_img <= 0 || rows <= 0 || C <= 0 || rows % 128 != 0) return FRESCO_EINVAL;
+    if (!stats || !mean || !rstd || n_img <= 0 || rows <= 0 || C <= 0 || rows % 256 != 0) return FRESCO_EINVAL;
     const int total = n_img * C;
     hipLaunchKernelGGL(fn_colstats_final_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
-                       static_cast<const double*>(stats), mean, rstd, 2 * (rows / 128), C, rows, eps, total);
+                       static_cast<const double*>(stats), mean, rstd, rows / 64, C, rows, eps, total);
     return check_launch();
 }
 

@@ -257,6 +257,7 @@ def attention_f32(q, k, v, scale):
 # pipe from (hi, lo) fp16 planes.  A "split" below is a pair of fp16 tensors (M, ld) with x * scale = hi + lo (scale: FN_A_SCALE
 # for activations, FN_W_SCALE for weights -- powers of two that keep the lo pieces normal fp16 numbers, csrc/flownet.hip).
 FN_A_SCALE, FN_W_SCALE = 64.0, 1024.0
+_fn_zero_page = {}  # per device: 128 bytes of zeros, the LDS-DMA source of rows outside a GEMM (padding, tails)
 
 
 def fn_prep(x, mean=None, rstd=None, residual=None, rows_per_img=0, relu_a=False, relu_b=False, want_f32=False,
@@ -327,13 +328,16 @@ def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want
         oh = torch.empty(M, N, dtype=torch.float16, device=dev)
         ol = torch.empty(M, N, dtype=torch.float16, device=dev)
     stats = None
-    fused = instance_norm_eps is not None and conv is not None and (M // conv[0]) % 128 == 0
+    fused = instance_norm_eps is not None and conv is not None and (M // conv[0]) % 256 == 0
     if fused:
-        stats = torch.empty(2 * (M // 128) * N * 2, dtype=torch.float64, device=dev)
+        stats = torch.empty((M // 64) * N * 2, dtype=torch.float64, device=dev)
+    zeros = _fn_zero_page.get(dev)
+    if zeros is None:
+        zeros = _fn_zero_page[dev] = torch.zeros(64, dtype=torch.float16, device=dev)
     lib = _lib.load()
     rc = lib.fresco_fn_gemm(ah.data_ptr(), al.data_ptr(), lda, wh.data_ptr(), wl.data_ptr(), _ptr(bias), _ptr(out),
                             _ptr(oh), _ptr(ol), N, int(ldo), M, N, K, int(act), 1.0 / (FN_A_SCALE * FN_W_SCALE),
-                            FN_A_SCALE, *cargs, _ptr(stats), _stream())
+                            FN_A_SCALE, *cargs, _ptr(stats), zeros.data_ptr(), _stream())
     _lib.check(rc, "fresco_fn_gemm(M=%d,N=%d,K=%d,conv=%s)" % (M, N, K, conv))
     res = (out, ((oh, ol) if oh is not None else None))
     if instance_norm_eps is None:

@@ -75,3 +75,19 @@ def test_temporal_kernels_do_not_spill(tmp_path):
                 r"temporal_mfma_kernelILi80ELi2E"):
         r = _one(k, pat)
         assert r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+
+
+def test_flow_network_gemm_fits_two_waves_per_simd_and_sv_reads_stay_split(tmp_path):
+    """csrc/flownet.hip's GEMM: 8-wave workgroups, one per CU -> two waves per SIMD: <= 256 VGPRs, nothing in scratch.
+    opt_fast.hip's S V kernel: the two sign-row reads of a k-step must stay two ds_read_b64 (32-lane groups, 64 banks: the
+    layout its swizzle is conflict-free for); hipcc once fused them into a ds_read2st64_b64 (16-lane groups, 32 banks:
+    2-way conflicts, 24 % of the kernel's LDS cycles in profiles/r05_pmc_opt_C640_h64.csv)."""
+    k = _listing("flownet.hip", tmp_path)
+    for pat in (r"fn_gemm_kernelILi64E", r"fn_gemm_kernelILi128E"):
+        r = _one(k, pat)
+        assert r["vgpr"] + r["agpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+    _listing("opt_fast.hip", tmp_path)
+    txt = open(str(tmp_path / "opt_fast.hip.s")).read()
+    i = txt.index("\n_ZN6fresco12sv16b_kernelILi128E")
+    body = txt[i:txt.index("s_endpgm", i)]
+    assert "ds_read2st64_b64" not in body and body.count("ds_read_b64") >= 4, re.findall(r"ds_read\w+", body)[:20]
