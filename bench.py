@@ -567,12 +567,6 @@ def main():
             run_step(proc, ctrl, layers, mode, refs, paras, masks)
     torch.cuda.synchronize()
 
-    census = parity = xch = None
-    if world > 1:
-        census = rank_census(rank, world, device, backend)
-        parity = sharded_vs_single(layers, params, N, device, shard, proc, ctrl, refs, paras, masks, rank)
-        xch = exchange_timing(layers, params, N, device, shard)
-
     run_eager(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -668,12 +662,6 @@ def main():
                           for n_ in ("L2", "L3"))
             res["collectives_per_step"] = dict(cross_frame=cf_coll, temporal_all_to_all=12,
                                                schedule_mean=round(cf_coll + 12 * 8.0 / 15.0, 1))
-            res["rank_census"] = census
-            res["sharded_vs_single_gpu_max_abs_delta"] = dict(
-                per_mode=parity, bar=1e-3,
-                note="one step per attention mode, sharded over the ranks, vs the same step on ONE GPU (rank 0, unsharded "
-                     "processor): max |delta| over rank 0's frames of all six layer calls, before any timing")
-            res["exchange_timing"] = xch
         if world == 1 and not args.no_aux:
             res["cfg2b"] = cfg2b_large_mask(layers, N, R, device, lib)
             rows3 = params[8][3].reshape(-1).nonzero().squeeze(1).to(torch.int32).to(device)
@@ -732,12 +720,19 @@ def main():
     # the frame-parallel claim of BASELINE.json rests on (per-frame work 16x config 2's).  It runs at N = 1 too, so that a
     # SCALE record of the default command carries this workload's own curve next to config 2's strong-scaling `value`.
     if (N, R) == (8, 512) and 32 % world == 0 and not args.no_aux:
-        c5 = timed_workload(32, 768, device, (rank, world) if world > 1 else None, max(args.steps // 2, 2), 1, barrier,
-                            max_over_ranks)
+        try:
+            c5 = timed_workload(32, 768, device, (rank, world) if world > 1 else None, max(args.steps // 2, 2), 1, barrier,
+                                max_over_ranks)
+        except Exception as e:  # noqa: BLE001 -- an auxiliary leg must not take the measurement with it
+            c5 = dict(error="%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else ""))
         if rank == 0:
             res["cfg5"] = c5
     # ---- optional legs, all AFTER the result above is complete and all fenced by one watchdog (a hang prints the eager
     # line and exits; the watchdog's line and the normal one are mutually exclusive):
+    #  (o)  N > 1: the run proves itself -- every rank reports who it is (`rank_census`), one step per attention mode is
+    #       evaluated sharded AND on one GPU and compared (`sharded_vs_single_gpu_max_abs_delta`), and the exchanges are
+    #       timed alone per layer kind (`exchange_timing`).  Each in its own try / except: a failure is recorded in the
+    #       line, it does not take the measurement with it.
     #  (i)  N > 1 on RCCL: the cross-frame exchange as ONE grouped launch of point-to-point transfers
     #       (FrameShard.p2p_exchange = True, FRESCO_BENCH_P2P=0 skips): its outputs must equal the broadcast + all-gather
     #       form's bit for bit (same rows, same kernels) and its K steps are timed beside `value`.  The grouped form has
@@ -750,7 +745,7 @@ def main():
     # `value` / `ms_per_step` are ALWAYS the eager figures of the default exchange form.
     want_graph = os.environ.get("FRESCO_BENCH_GRAPH", "0") == "1"
     want_p2p = world > 1 and backend == "nccl" and os.environ.get("FRESCO_BENCH_P2P", "1") == "1"
-    if want_graph or want_p2p:
+    if want_graph or want_p2p or world > 1:
         import threading
 
         out_lock = threading.Lock()  # the watchdog's line and the normal one are mutually exclusive
@@ -780,6 +775,25 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return float(t.item())
 
+        if world > 1:
+            def leg(name, fn):
+                stage[0] = name
+                try:
+                    return fn()
+                except Exception as e:  # noqa: BLE001 -- recorded, not fatal
+                    return dict(error="%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else ""))
+
+            census = leg("rank census", lambda: rank_census(rank, world, device, backend))
+            parity = leg("sharded vs single GPU", lambda: sharded_vs_single(layers, params, N, device, shard, proc, ctrl,
+                                                                            refs, paras, masks, rank))
+            xch = leg("exchange timing", lambda: exchange_timing(layers, params, N, device, shard))
+            if rank == 0:
+                res["rank_census"] = census
+                res["sharded_vs_single_gpu_max_abs_delta"] = dict(
+                    per_mode=parity, bar=1e-3,
+                    note="one step per attention mode, sharded over the ranks, vs the same step on ONE GPU (rank 0, unsharded "
+                         "processor): max |delta| over rank 0's frames of all six layer calls")
+                res["exchange_timing"] = xch
         if want_p2p:
             stage[0] = "p2p exchange: parity"
             err = None
