@@ -319,22 +319,39 @@ __global__ __launch_bounds__(256) void fn_colstats_partial_kernel(const float* _
     }
 }
 
-__global__ void fn_colstats_final_kernel(const double* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
-                                         int slabs, int C, int rows, float eps, int total) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (img, c)
-    if (i >= total) return;
-    const int img = i / C, c = i - img * C;
+// Combine the slabs of partial sums: grid (ceil(C / 16), n_img), 256 threads = 16 channels x 16 slab lanes.  Lane g adds
+// slabs g, g + 16, ... in order, thread g = 0 of a channel adds the 16 lane sums in order: a fixed summation order whatever
+// the launch looks like.  (Round 5, first form: ONE thread per (image, channel) walking all slabs -- 1024 dependent loads at
+// 256 x 256: 160 us average, 464 us worst, 12 % of the flow network's forward in profiles/r05_gmflow_kernel_stats.csv.)
+__global__ __launch_bounds__(256) void fn_colstats_final_kernel(const double* __restrict__ part, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, int slabs, int C, int rows,
+                                                                float eps) {
+    __shared__ double s1[16][17], s2[16][17];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl, img = blockIdx.y;
     double a = 0.0, b = 0.0;
-    for (int s = 0; s < slabs; ++s) {
-        const double* p = part + (((int64_t)img * slabs + s) * C + c) * 2;
-        a += p[0];
-        b += p[1];
+    if (c < C)
+        for (int s = g; s < slabs; s += 16) {
+            const double* p = part + (((int64_t)img * slabs + s) * C + c) * 2;
+            a += p[0];
+            b += p[1];
+        }
+    s1[g][cl] = a;
+    s2[g][cl] = b;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        a = 0.0;
+        b = 0.0;
+        for (int k = 0; k < 16; ++k) {
+            a += s1[k][cl];
+            b += s2[k][cl];
+        }
+        const double m = a / rows;
+        double var = b / rows - m * m;  // biased variance (InstanceNorm2d)
+        if (var < 0.0) var = 0.0;
+        mean[(int64_t)img * C + c] = (float)m;
+        rstd[(int64_t)img * C + c] = (float)(1.0 / sqrt(var + (double)eps));
     }
-    const double m = a / rows;
-    double var = b / rows - m * m;  // biased variance (InstanceNorm2d)
-    if (var < 0.0) var = 0.0;
-    mean[i] = (float)m;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // y = relu_b?( relu_a?((x - mean) * rstd) + residual ), 4 channels per thread; writes fp32 y (ld C) and / or the (hi, lo)
@@ -470,6 +487,47 @@ __global__ __launch_bounds__(256) void fn_conv7_rgb_kernel(const float* __restri
     }
 }
 
+// Convex upsampling (gmflow.py:75-90): every fine pixel (8 y + ky, 8 x + kx) is a softmax-weighted mix of the 3 x 3 coarse
+// neighbourhood of 8 * flow (zero padding, F.unfold order n = 3 dy + dx).  logits (B, h, w, 9 * 64) NHWC rows of the mask head
+// (channel = n * 64 + ky * 8 + kx), flow (B, h w, 2) tokens, out (B, 2, 8 h, 8 w).  One thread per fine pixel.
+__global__ __launch_bounds__(256) void fn_convex_upsample_kernel(const float* __restrict__ logits, const float* __restrict__ flow,
+                                                                 float* __restrict__ out, int B, int h, int w) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)B * h * w * 64;
+    if (idx >= total) return;
+    const int sub = (int)(idx & 63), kx = sub & 7, ky = sub >> 3;
+    const int64_t pix = idx >> 6;
+    const int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((int64_t)w * h));
+    const float* lg = logits + pix * 576 + sub;
+    float e[9], mx = -3.0e38f;
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        e[n] = lg[n * 64];
+        mx = fmaxf(mx, e[n]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        e[n] = expf(e[n] - mx);
+        den += e[n];
+    }
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        const int yy = y + n / 3 - 1, xx = x + n % 3 - 1;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            const float* f = flow + (((int64_t)b * h + yy) * w + xx) * 2;
+            const float wgt = e[n] / den;
+            ax = fmaf(wgt, 8.f * f[0], ax);
+            ay = fmaf(wgt, 8.f * f[1], ay);
+        }
+    }
+    const int64_t H8 = 8 * (int64_t)h, W8 = 8 * (int64_t)w;
+    const int64_t o = ((int64_t)b * 2 * H8 + (8 * y + ky)) * W8 + 8 * x + kx;
+    out[o] = ax;
+    out[o + H8 * W8] = ay;
+}
+
 }  // namespace fresco
 
 using namespace fresco;
@@ -542,9 +600,8 @@ extern "C" int fresco_fn_colstats(const float* x, float* mean, float* rstd, void
     const int slabs = (rows + 511) / 512;
     double* part = static_cast<double*>(workspace);
     hipLaunchKernelGGL(fn_colstats_partial_kernel, dim3(slabs, n_img), dim3(256), 0, st, x, part, rows, C, 512);
-    const int total = n_img * C;
-    hipLaunchKernelGGL(fn_colstats_final_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, mean, rstd, slabs, C, rows,
-                       eps, total);
+    hipLaunchKernelGGL(fn_colstats_final_kernel, dim3((C + 15) / 16, n_img), dim3(256), 0, st, part, mean, rstd, slabs, C, rows,
+                       eps);
     return check_launch();
 }
 
@@ -553,9 +610,9 @@ extern "C" int fresco_fn_colstats(const float* x, float* mean, float* rstd, void
 extern "C" int fresco_fn_colstats_finish(const void* stats, float* mean, float* rstd, int n_img, int rows, int C, float eps,
                                          void* stream) {
     if (!stats || !mean || !rstd || n_img <= 0 || rows <= 0 || C <= 0 || rows % 256 != 0) return FRESCO_EINVAL;
-    const int total = n_img * C;
-    hipLaunchKernelGGL(fn_colstats_final_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
-                       static_cast<const double*>(stats), mean, rstd, rows / 64, C, rows, eps, total);
+    if (n_img > 65535) return FRESCO_EUNSUPPORTED;
+    hipLaunchKernelGGL(fn_colstats_final_kernel, dim3((C + 15) / 16, n_img), dim3(256), 0, as_stream(stream),
+                       static_cast<const double*>(stats), mean, rstd, rows / 64, C, rows, eps);
     return check_launch();
 }
 
@@ -592,5 +649,14 @@ extern "C" int fresco_fn_conv7_rgb(const float* x, const float* w, float* out, i
     hipStream_t st = as_stream(stream);
     ProfScope ps(FRESCO_PROF_FN_GEMM, n_img * OH * OW, 64, 147, 7, st);
     hipLaunchKernelGGL(fn_conv7_rgb_kernel, dim3((OW + 63) / 64, OH, n_img), dim3(256), 0, st, x, w, out, H, W, OH, OW);
+    return check_launch();
+}
+
+extern "C" int fresco_fn_convex_upsample(const float* logits, const float* flow, float* out, int B, int h, int w, void* stream) {
+    if (!logits || !flow || !out || B <= 0 || h <= 0 || w <= 0) return FRESCO_EINVAL;
+    const int64_t total = (int64_t)B * h * w * 64;
+    if ((total + 255) / 256 > 0x7fffffff) return FRESCO_EUNSUPPORTED;
+    hipLaunchKernelGGL(fn_convex_upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), logits,
+                       flow, out, B, h, w);
     return check_launch();
 }

@@ -389,11 +389,9 @@ class GMFlow(nn.Module):
         _, hs = _conv(wts, cs, up0, B2, h, w, 1, act=1, want_f32=False, want_split=True, pad_cin=160)
         w2 = wts.get(up2.weight, "conv")
         mk, _ = ops.fn_gemm(hs, w2, up2.out_channels, w2[0].shape[1], bias=up2.bias)
-        mask = mk.view(B2, h, w, 9, K, K).softmax(3)
-        flow = flow_tok.transpose(1, 2).reshape(B2, 2, h, w)
-        nb = F.unfold(K * flow, (3, 3), padding=1).view(B2, 2, 9, h, w)
-        up = torch.einsum("bhwnyx,bcnhw->bchywx", mask, nb)
-        return up.reshape(B2, 2, K * h, K * w)
+        if K != 8:
+            raise NotImplementedError("fresco_amd.gmflow: upsample_factor 8 only (FRESCO's configuration)")
+        return ops.fn_convex_upsample(mk, flow_tok, B2, h, w)
 
     def upsample_flow(self, flow, feature):
         """convex upsampling (gmflow.py:75-90): every fine pixel is a softmax-weighted mix of its coarse 3x3"""

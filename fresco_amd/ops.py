@@ -383,6 +383,17 @@ def fn_conv7_rgb(x_nhwc, w_khwc):
     return out
 
 
+def fn_convex_upsample(logits, flow_tok, B, h, w):
+    """convex upsampling by 8 (gmflow.py:75-90): logits (B h w, 576) fp32 rows of the mask head, flow_tok (B, h w, 2) ->
+    (B, 2, 8 h, 8 w) (fresco_fn_convex_upsample)"""
+    _need_gpu(logits, flow_tok)
+    logits, flow_tok = _f32c(logits), _f32c(flow_tok)
+    out = torch.empty(B, 2, 8 * h, 8 * w, dtype=torch.float32, device=logits.device)
+    rc = _lib.load().fresco_fn_convex_upsample(logits.data_ptr(), flow_tok.data_ptr(), out.data_ptr(), B, h, w, _stream())
+    _lib.check(rc, "fresco_fn_convex_upsample(B=%d,h=%d,w=%d)" % (B, h, w))
+    return out
+
+
 _checked_tables = {}
 
 

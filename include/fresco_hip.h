@@ -270,6 +270,10 @@ int fresco_fn_layernorm(const float* x, const float* gamma, const float* beta, c
  * w (7, 7, 3, 64) = weight.permute(2, 3, 1, 0), out (n_img, OH, OW, 64) NHWC. */
 int fresco_fn_conv7_rgb(const float* x, const float* w, float* out, int n_img, int H, int W, void* stream);
 
+/* Convex upsampling by 8 (gmflow.py:75-90): out (B, 2, 8h, 8w) = softmax-over-9-weighted mix of the 3 x 3 coarse neighbourhood
+ * of 8 * flow.  logits (B, h, w, 576) = the mask head's NHWC rows (channel = n * 64 + ky * 8 + kx), flow (B, h * w, 2). */
+int fresco_fn_convex_upsample(const float* logits, const float* flow, float* out, int B, int h, int w, void* stream);
+
 /* forward_backward_consistency_check (gmflow/geometry.py:75-96) fused with the colour-difference
  * occlusion refinement of get_flow_and_interframe_paras (DH:919-926).  Pair n couples frame n with frame
  * (n+1) mod N: fwd_flow[n] maps frame n onto n+1, bwd_flow[n] the reverse; all fp32.

@@ -120,3 +120,18 @@ def test_fn_conv7_rgb_stem():
     got = out.permute(0, 3, 1, 2).cpu().double()
     assert tuple(got.shape) == tuple(ref.shape)
     assert float((got - ref).abs().max()) < 2e-5
+
+
+def test_fn_convex_upsample():
+    """gmflow.py:75-90 restated with torch ops (softmax over the 9 taps, F.unfold of 8 * flow) vs the fused kernel"""
+    import fresco_amd.ops as ops
+    g = synth.gen(21)
+    B, h, w = 3, 6, 10
+    logits_nchw = torch.randn(B, 576, h, w, generator=g) * 2.0
+    flow = torch.randn(B, 2, h, w, generator=g) * 3.0
+    mask = logits_nchw.view(B, 1, 9, 8, 8, h, w).softmax(2)
+    nb = F.unfold(8 * flow, (3, 3), padding=1).view(B, 2, 9, 1, 1, h, w)
+    ref = (mask * nb).sum(2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 8 * h, 8 * w)
+    out = ops.fn_convex_upsample(logits_nchw.permute(0, 2, 3, 1).reshape(B * h * w, 576).contiguous().to(DEV),
+                                 flow.flatten(2).transpose(1, 2).contiguous().to(DEV), B, h, w)
+    assert float((out.cpu() - ref).abs().max()) < 2e-5
