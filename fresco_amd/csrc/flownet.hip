@@ -78,7 +78,11 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                                                          float* __restrict__ out, half_t* __restrict__ o_hi,
                                                          half_t* __restrict__ o_lo, int64_t ldc, int64_t ldo, int M, int N,
                                                          int K, int act, float acc_scale, float split_scale,
-                                                         double* __restrict__ stats, const void* __restrict__ zeros) {
+                                                         double* __restrict__ stats, const void* __restrict__ zeros,
+                                                         const int32_t* __restrict__ a_rows,
+                                                         const int32_t* __restrict__ out_rows) {
+    // a_rows / out_rows (linear layers; NULL = identity): problem row m reads input row a_rows[m] and its results go to output
+    // row out_rows[m] -- the token gather / scatter of the (shifted-)window attention folded into the projections around it
     constexpr int BM = FN_BM, BK = FN_BK, NS = FN_NS;
     constexpr int A_PL = BM * 64, W_PL = BN * 64;          // bytes per plane and slot
     constexpr int SLOT = 2 * A_PL + 2 * W_PL;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
         a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
         if (cv.kh == 0) {
-            a_base[i] = (int64_t)mm * lda;
+            a_base[i] = (int64_t)(a_rows ? a_rows[mm] : mm) * lda;
             a_iy[i] = a_ix[i] = 0;
         } else {
             const int ohw = cv.OH * cv.OW;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                 if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU() (exact, erf form)
                 acc[i][j][r] = v;
                 const bool ok = nok && m < M;
-                if (out && ok) out[(int64_t)m * ldc + n] = v;
+                if (out && ok) out[(int64_t)((out_rows && m < M) ? out_rows[m] : m) * ldc + n] = v;
                 if (stats && ok) {
                     s1 += (double)v;
                     s2 += (double)v * (double)v;
@@ -277,7 +281,8 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                 const int id = it * 64 + lane, rr = id / PPR, pc = id % PPR;
                 const int m = fn_row_of(cv, blockIdx.x, wm * 64 + rr), n = n0 + wn * WN + pc * 8;
                 const half8_t v8 = *reinterpret_cast<const half8_t*>(tp + rr * TROW + pc * 16);
-                if (m < M && n < N) *reinterpret_cast<half8_t*>(op + (int64_t)m * ldo + n) = v8;  // (N % 8 == 0: launcher)
+                if (m < M && n < N)  // (N % 8 == 0: launcher)
+                    *reinterpret_cast<half8_t*>(op + (int64_t)(out_rows ? out_rows[m] : m) * ldo + n) = v8;
             }
         }
     }
@@ -535,8 +540,10 @@ using namespace fresco;
 extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, const void* w_hi, const void* w_lo,
                               const float* bias, float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M,
                               int N, int K, int act, float acc_scale, float split_scale, int n_img, int H, int W, int kh,
-                              int kw, int stride, int pad, void* stats, const void* zeros, void* stream) {
+                              int kw, int stride, int pad, void* stats, const void* zeros, const int32_t* a_rows,
+                              const int32_t* out_rows, void* stream) {
     if (!zeros) return FRESCO_EINVAL;
+    if ((a_rows || out_rows) && (kh > 0 || stats)) return FRESCO_EUNSUPPORTED;
     if (!a_hi || !a_lo || !w_hi || !w_lo || (!out && !out_hi) || (out_hi && !out_lo) || M <= 0 || N <= 0 || K <= 0)
         return FRESCO_EINVAL;
     if (K % 32 != 0 || lda % 8 != 0 || act < 0 || act > 2) return FRESCO_EUNSUPPORTED;
@@ -573,14 +580,14 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
-                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros);
+                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows);
     } else {
         constexpr int BN = 128;
         const int lds = FN_NS * (2 * FN_BM * 64 + 2 * BN * 64);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
-                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros);
+                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows);
     }
     return check_launch();
 }

@@ -268,16 +268,40 @@ def _backbone_native(bb, wts, x_nchw):
     return feats.view(n, H * W, -1), H, W
 
 
-def _layer_native(layer, wts, src, src_s, tgt_s, groups):
-    """TransformerLayer.forward on token rows: src (B, L, C) fp32, src_s / tgt_s planes (B L, C) -> (out fp32, planes)"""
+def _group_rows(groups, B, L, device):
+    """Row table of the grouped attention for (B, L, C) tokens: position g of the GROUP-MAJOR order -> token row b L + l.
+    Size class k (G groups of n tokens) occupies the contiguous positions [off, off + B G n) as (b, group, token): exactly
+    the (B G, n, C) problem list fresco_attn_f32 takes.  Returns (table int32 (B L), [(off, G, n), ...])."""
+    parts, spans, off = [], [], 0
+    for idx in groups:
+        G, n = idx.shape
+        parts.append((torch.arange(B, device=device).view(B, 1) * L + idx.reshape(1, -1).to(device)).reshape(-1))
+        spans.append((off, G, n))
+        off += B * G * n
+    return torch.cat(parts).to(torch.int32).contiguous(), spans
+
+
+def _layer_native(layer, wts, src, src_s, tgt_s, grows):
+    """TransformerLayer.forward on token rows: src (B, L, C) fp32, src_s / tgt_s planes (B L, C) -> (out fp32, planes).
+    The window grouping costs nothing: the q / k / v projections READ their rows through the group-major table (their
+    outputs are the attention problems, contiguous per size class) and the merge projection WRITES its rows back through
+    it -- no gather / scatter passes over the tokens (PyTorch index kernels: 1.5 ms of the forward before)."""
     B, L, C = src.shape
+    table, spans = grows
     lin = lambda p: wts.get(p.weight, "lin")
-    q, _ = ops.fn_gemm(src_s, lin(layer.q_proj), C, C)
-    k, _ = ops.fn_gemm(tgt_s, lin(layer.k_proj), C, C)
-    v, _ = ops.fn_gemm(tgt_s, lin(layer.v_proj), C, C)
-    msg = grouped_attention(q.view(B, L, C), k.view(B, L, C), v.view(B, L, C), groups, 1.0 / math.sqrt(C))
-    _, ms = ops.fn_prep(msg.view(B * L, C))
-    mg, _ = ops.fn_gemm(ms, lin(layer.merge), C, C)
+    q, _ = ops.fn_gemm(src_s, lin(layer.q_proj), C, C, a_rows=table)
+    k, _ = ops.fn_gemm(tgt_s, lin(layer.k_proj), C, C, a_rows=table)
+    v, _ = ops.fn_gemm(tgt_s, lin(layer.v_proj), C, C, a_rows=table)
+    scale = 1.0 / math.sqrt(C)
+    outs_ = []
+    for off, G, n in spans:
+        rows = slice(off, off + B * G * n)
+        outs_.append(ops.attention_f32(q[rows].view(B * G, n, C), k[rows].view(B * G, n, C), v[rows].view(B * G, n, C),
+                                       scale).view(-1, C))
+    msg = outs_[0] if len(outs_) == 1 else torch.cat(outs_, 0)
+    _, ms = ops.fn_prep(msg)
+    mg = torch.empty(B * L, C, dtype=torch.float32, device=src.device)
+    ops.fn_gemm(ms, lin(layer.merge), C, C, out_rows=table, out_f32=mg)
     src2 = src.view(B * L, C)
     if layer.no_ffn:
         out, outs = ops.fn_layernorm(mg, layer.norm1.weight, layer.norm1.bias, residual=src2, eps=layer.norm1.eps,
@@ -305,12 +329,16 @@ def _transformer_native(tr, wts, tok, b, h, w, splits):
     _, xs = ops.fn_prep(x.reshape(-1, x.shape[-1]))
     L, C = x.shape[1], x.shape[2]
     swap = lambda t: torch.cat((t.view(2, b * L, C)[1], t.view(2, b * L, C)[0]), 0)
+    B = x.shape[0]
     for i, blk in enumerate(tr.layers):
         shifted = splits > 1 and i % 2 == 1
-        groups = tr._get_groups(h, w, splits, shifted, x.device)
+        key = ("rows", h, w, splits, shifted, B, str(x.device))
+        if key not in tr._groups:
+            tr._groups[key] = _group_rows(tr._get_groups(h, w, splits, shifted, x.device), B, L, x.device)
+        grows = tr._groups[key]
         ys = (swap(xs[0]), swap(xs[1]))  # the other image's tokens BEFORE this block (transformer.py:279-288)
-        x, xs = _layer_native(blk.self_attn, wts, x, xs, xs, groups)
-        x, xs = _layer_native(blk.cross_attn_ffn, wts, x, xs, ys, groups)
+        x, xs = _layer_native(blk.self_attn, wts, x, xs, xs, grows)
+        x, xs = _layer_native(blk.cross_attn_ffn, wts, x, xs, ys, grows)
     return x, xs
 
 

@@ -300,9 +300,11 @@ def fn_colstats(x, n_img, eps=1e-5):
 
 
 def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want_split=False, out_split=None,
-            instance_norm_eps=None):
+            instance_norm_eps=None, a_rows=None, out_rows=None, out_f32=None):
     """act(A W^T + bias) (fresco_fn_gemm).  a = (hi, lo) planes, (rows, lda); w = (hi, lo) planes (N, K).
     conv = (n_img, H, W, kh, kw, stride, pad): implicit im2col of the NHWC tensor behind `a` (K = kh kw cin).
+    a_rows / out_rows (linear layers): int32 (M) tables -- problem row m reads input row a_rows[m], writes output row
+    out_rows[m] (the rows of `out` not named by the table keep whatever they held: pass a full permutation).
     instance_norm_eps (convolutions): also return InstanceNorm2d statistics (mean, rstd) of the result, from partial sums
     the kernel's epilogue leaves behind (no second pass over the output).
     Returns (out fp32 (M, N) or None, (hi, lo) (M, N) or None[, (mean, rstd)])."""
@@ -311,7 +313,7 @@ def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want
     _need_gpu(ah, wh)
     lda = ah.stride(0)
     if conv is None:
-        M = ah.shape[0] if M is None else M
+        M = (ah.shape[0] if a_rows is None else a_rows.numel()) if M is None else M
         cargs = (0, 0, 0, 0, 0, 1, 0)
     else:
         n_img, H, W, kh, kw, stride, pad = conv
@@ -319,7 +321,7 @@ def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want
         M = n_img * OH * OW
         cargs = (n_img, H, W, kh, kw, stride, pad)
     dev = ah.device
-    out = torch.empty(M, N, dtype=torch.float32, device=dev) if want_f32 else None
+    out = out_f32 if out_f32 is not None else (torch.empty(M, N, dtype=torch.float32, device=dev) if want_f32 else None)
     oh = ol = None
     ldo = N
     if out_split is not None:
@@ -337,7 +339,7 @@ def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want
     lib = _lib.load()
     rc = lib.fresco_fn_gemm(ah.data_ptr(), al.data_ptr(), lda, wh.data_ptr(), wl.data_ptr(), _ptr(bias), _ptr(out),
                             _ptr(oh), _ptr(ol), N, int(ldo), M, N, K, int(act), 1.0 / (FN_A_SCALE * FN_W_SCALE),
-                            FN_A_SCALE, *cargs, _ptr(stats), zeros.data_ptr(), _stream())
+                            FN_A_SCALE, *cargs, _ptr(stats), zeros.data_ptr(), _ptr(a_rows), _ptr(out_rows), _stream())
     _lib.check(rc, "fresco_fn_gemm(M=%d,N=%d,K=%d,conv=%s)" % (M, N, K, conv))
     res = (out, ((oh, ol) if oh is not None else None))
     if instance_norm_eps is None:

@@ -239,13 +239,14 @@ int fresco_attn_f32_guarded(const float* q, const float* k, const float* v, floa
  *   out (M, ldc) fp32 and / or out_hi / out_lo (M, ldo) fp16 planes of the result (either may be NULL, not both; planes need
  *   N % 8 == 0).  zeros: 16 bytes of zeros in device memory (the source of every row outside the problem and of a
  *   convolution's zero padding: the operands arrive by LDS-DMA).  stats (convolutions whose OH * OW is a multiple of 256;
- *   else NULL): (M / 64) * N * 2 doubles that
+ *   a_rows / out_rows (linear layers only, int32 (M) device tables or NULL): problem row m reads input row a_rows[m], its
+ *   results go to output row out_rows[m] (a token gather / scatter folded into the product).  stats: (M / 64) * N * 2 doubles that
  *   receive per-column partial sums / sums of squares of the results for fresco_fn_colstats_finish (InstanceNorm2d without a
  *   second pass over the convolution's output). */
 int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, const void* w_hi, const void* w_lo, const float* bias,
                    float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M, int N, int K, int act,
                    float acc_scale, float split_scale, int n_img, int H, int W, int kh, int kw, int stride, int pad,
-                   void* stats, const void* zeros, void* stream);
+                   void* stats, const void* zeros, const int32_t* a_rows, const int32_t* out_rows, void* stream);
 
 /* nn.InstanceNorm2d statistics (affine=False, biased variance): x (n_img * rows, C) fp32 NHWC -> mean, rstd = 1 / sqrt(var +
  * eps), (n_img, C) each.  fp64 partial sums in a fixed order.  C <= 256. */

@@ -135,3 +135,29 @@ def test_fn_convex_upsample():
     out = ops.fn_convex_upsample(logits_nchw.permute(0, 2, 3, 1).reshape(B * h * w, 576).contiguous().to(DEV),
                                  flow.flatten(2).transpose(1, 2).contiguous().to(DEV), B, h, w)
     assert float((out.cpu() - ref).abs().max()) < 2e-5
+
+
+def test_fn_gemm_row_tables():
+    """a_rows / out_rows: problem row m reads input row a_rows[m], its results land in output row out_rows[m] (the token
+    gather / scatter of the window attention folded into the projections)"""
+    import fresco_amd.ops as ops
+    g = synth.gen(33)
+    M, K, N = 777, 128, 128
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    perm = torch.randperm(M, generator=g)
+    _, xs = ops.fn_prep(x.to(DEV))
+    _, ws = ops.fn_prep(w.to(DEV), scale=ops.FN_W_SCALE)
+    ref = (x.double() @ w.double().t())
+    bar = _bar(x.abs().double() @ w.abs().double().t())
+    t = perm.to(torch.int32).to(DEV)
+    a, _ = ops.fn_gemm(xs, ws, N, K, a_rows=t)                      # a[m] = (x W^T)[perm[m]]
+    assert float((a.cpu().double() - ref[perm]).abs().max()) < bar
+    out = torch.zeros(M, N, device=DEV)
+    ops.fn_gemm(xs, ws, N, K, out_rows=t, out_f32=out)                # out[perm[m]] = (x W^T)[m]
+    back = torch.empty_like(ref)
+    back[perm] = ref
+    assert float((out.cpu().double() - back).abs().max()) < bar
+    _, sp = ops.fn_gemm(xs, ws, N, K, out_rows=t, want_f32=False, want_split=True)
+    rec = (sp[0].float() + sp[1].float()) / ops.FN_A_SCALE
+    assert float((rec.cpu().double() - back).abs().max()) < bar + 2 ** -20 * float(back.abs().max())
