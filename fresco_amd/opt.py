@@ -33,7 +33,7 @@ def optimize_feature(sample, flows, occs, correlation_matrix=[], intra_weight=1e
         # the reference reaches `loss = 0; loss.backward()` here and dies with AttributeError
         raise ValueError("optimize_feature: no loss term is active (no flows and no Gram target of "
                          "%d x %d tokens)" % (h * w, h * w))
-    cs = sample.to(torch.float32).contiguous().clone()
+    cs = sample.contiguous().to(torch.float32, copy=True)  # (one pass: the cast IS the private copy)
     if shard is not None:
         # frame-parallel form (fresco_amd/dist.py): `sample` and the Gram target hold this rank's frames,
         # flows / occs describe all N pairs; the pairs touching the local frames are selected here

@@ -85,7 +85,7 @@ def warp_tensor(sample, flows, occs, saliency, unet_chunk_size, shard=None):
 
     sal, warp_sal, warp_sal_last = _cached("saliency", (saliency, flows[0], flows[1], occs[0], occs[1]), (int(h), int(n)),
                                            sal_terms)
-    lat = sample.to(torch.float32).contiguous().clone()
+    lat = sample.contiguous().to(torch.float32, copy=True)  # (one pass: the cast IS the private copy)
     ops.warp_fuse_chain(lat, bwd_flow, fwd_flow, bwd_occ, fwd_occ, sal, warp_sal, warp_sal_last,
                         unet_chunk_size)
     return lat.to(sample.dtype)
