@@ -25,6 +25,24 @@ def _inputs(N, R, dev, g):
     return flows, occs, sal
 
 
+def _pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of a config-3 kernel from the newest committed counter passes over (640, 64 x 64)
+    (profiles/r*_pmc_opt_C640_h64.csv, written by tools/pmc_opt.sh: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950, + WRITE_SIZE, both KiB per launch, separate --pmc passes).  None without a profile."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_opt_C640_h64.csv")))
+    if not files:
+        return None
+    for line in open(files[-1]):
+        f = line.strip().split(",")
+        if len(f) == 5 and kernel_substr in f[0]:
+            try:
+                return dict(bytes=int((2.0 * float(f[2]) + float(f[3])) * 1024), source=os.path.basename(files[-1]))
+            except ValueError:
+                pass
+    return None
+
+
 def _dominant_roofline(kern):
     """roofline of cfg3's dominant kernel: the Gram product at the largest layer (C = 640, 64 x 64).  `achieved` counts
     the ALGORITHMIC flop of one G = V V^T (2 B hw^2 C, what the reference's bmm computes) against the dense fp16 MFMA
@@ -33,8 +51,12 @@ def _dominant_roofline(kern):
     k = kern.get("C640_h64", {}).get("gram_roofline")
     if not k:
         return None
+    pmc = _pmc_traffic("gram16y_kernel") or {}
     return dict(bound="mfma", kernel="gram16y_kernel at (C 640, 64 x 64)", achieved=k["algorithmic_tflops"],
                 peak=PEAK_F16_DENSE / 1e12, unit="TFLOP/s", frac=k["frac_algorithmic"], frac_executed=k["frac_executed"],
+                traffic=pmc.get("bytes"), traffic_source=pmc.get("source"),
+                # targets (fp32, upper triangle) + sign bytes (direct + mirror position) + the (hi, lo) pixel-major operands once
+                algorithmic_bytes_per_launch=int(16 * 4096 * 4096 * 4 // 2 + 16 * 4096 * 4096 + 16 * 640 * 4096 * 4),
                 note="the Gram and S V products are fp32-accurate products built from 3 / 2 fp16 MFMAs on hi / lo halves "
                      "(exact to ~2^-22); per-kernel fractions of every launch, MFMA- and HBM-bound alike, are in "
                      "kernel_avg_us.*_roofline")
