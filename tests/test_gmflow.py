@@ -176,3 +176,19 @@ def test_gmflow_native_dense_layers_vs_library_ops_and_reference(gm_golden, tag,
     assert tuple(flow.shape) == tuple(ref.shape) and bool(torch.isfinite(flow).all())
     assert float(e_nat.max()) < float(e_lib.max()) + 2e-2 and float(e_nat.mean()) < float(e_lib.mean()) + 1e-2
     assert float(e_nat.max()) < 0.15 and float(e_nat.mean()) < 0.05
+
+
+@pytest.mark.gpu
+def test_gmflow_unidirectional_equals_first_half_of_bidirectional():
+    """pred_bidir_flow=False (not used by FRESCO, supported by the signature): the forward flows are the first half of the
+    bidirectional prediction -- same layers, the matching / propagation / upsampling run on image 0's tokens only"""
+    m, _ = _model("cuda")
+    N, H, W = CASES["b"]
+    imgs = cf.gmflow_frames(N, H, W).cuda()
+    nxt = list(range(1, N)) + [0]
+    kw = dict(KW)
+    both = m(imgs, imgs[nxt], **kw)["flow_preds"][-1]
+    kw["pred_bidir_flow"] = False
+    one = m(imgs, imgs[nxt], **kw)["flow_preds"][-1]
+    assert tuple(one.shape) == (N, 2, H, W) and tuple(both.shape) == (2 * N, 2, H, W)
+    assert float(_epe(one, both[:N]).max()) < 1e-3
