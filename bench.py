@@ -733,8 +733,8 @@ def main():
     #       evaluated sharded AND on one GPU and compared (`sharded_vs_single_gpu_max_abs_delta`), and the exchanges are
     #       timed alone per layer kind (`exchange_timing`).  Each in its own try / except: a failure is recorded in the
     #       line, it does not take the measurement with it.
-    #  (i)  N > 1 on RCCL: the cross-frame exchange as ONE grouped launch of point-to-point transfers
-    #       (FrameShard.p2p_exchange = True, FRESCO_BENCH_P2P=0 skips): its outputs must equal the broadcast + all-gather
+    #  (i)  N > 1 on RCCL, OPT-IN (FRESCO_BENCH_P2P=1): the cross-frame exchange as ONE grouped launch of point-to-point
+    #       transfers (FrameShard.p2p_exchange = True): its outputs must equal the broadcast + all-gather
     #       form's bit for bit (same rows, same kernels) and its K steps are timed beside `value`.  The grouped form has
     #       never run on RCCL on the build boxes, hence opt-in in the library and fenced here.
     #  (ii) hipGraph replay, OPT-IN (FRESCO_BENCH_GRAPH=1) until it has run once on RCCL: one graph per attention mode,
@@ -744,7 +744,9 @@ def main():
     #       inside is unverified.  A failure on ANY rank (agreed through an all-reduce) keeps the eager result.
     # `value` / `ms_per_step` are ALWAYS the eager figures of the default exchange form.
     want_graph = os.environ.get("FRESCO_BENCH_GRAPH", "0") == "1"
-    want_p2p = world > 1 and backend == "nccl" and os.environ.get("FRESCO_BENCH_P2P", "1") == "1"
+    # (opt-in like the graph leg: a leg that has never run on RCCL must not be able to cost the driver's scale run its line --
+    # a hang would hold the JSON back until the watchdog fires)
+    want_p2p = world > 1 and backend == "nccl" and os.environ.get("FRESCO_BENCH_P2P", "0") == "1"
     if want_graph or want_p2p or world > 1:
         import threading
 
@@ -764,7 +766,7 @@ def main():
             emit()
             os._exit(0)  # (a hung collective cannot be torn down from here; the eager result above is complete)
 
-        dog = threading.Timer(float(os.environ.get("FRESCO_BENCH_GRAPH_TIMEOUT", "180")), bail)
+        dog = threading.Timer(float(os.environ.get("FRESCO_BENCH_GRAPH_TIMEOUT", "120")), bail)
         dog.daemon = True
         dog.start()
 
@@ -868,6 +870,8 @@ def main():
                 res["graph_replay"] = dict(status="capture failed on some rank%s" % (": " + err if err else ""))
         elif rank == 0 and world > 1:
             res["graph_replay"] = dict(status="not attempted (opt-in: FRESCO_BENCH_GRAPH=1)")
+        if rank == 0 and world > 1 and not want_p2p:
+            res["p2p_exchange"] = dict(status="not attempted (opt-in: FRESCO_BENCH_P2P=1)")
         dog.cancel()
         emit()
     elif rank == 0:

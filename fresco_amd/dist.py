@@ -97,7 +97,7 @@ class FrameShard:
         # cross-frame exchange form (exchange_cf).  False (default): one broadcast + one all-gather -- the two stock
         # collectives.  True: ONE grouped launch of point-to-point transfers (dist.batch_isend_irecv).  The grouped form
         # has only ever run on gloo / emulated ranks (the build boxes have one GPU), so it stays opt-in until an RCCL
-        # run has shown parity and timing: `bench.py --gpus N` checks and times BOTH forms and reports them side by side.
+        # run has shown parity and timing: `FRESCO_BENCH_P2P=1 bench.py --gpus N` checks and times BOTH forms side by side.
         self.p2p_exchange = False
 
     def local_batch_index(self):
