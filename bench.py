@@ -346,6 +346,19 @@ def collective_bytes_per_step(N, R, world, M_rest):
         out[name] = dict(cross_frame=int(cf), temporal_all_to_all=int(a2a))
         tot += 3 * (cf + a2a * 8.0 / 15.0)
     out["per_step_mean"] = int(tot)
+    # optimize_feature (configs[2]; not part of this bench's step): neighbour-only halo exchange of the temporal term, two
+    # (chunk, C, h, w) fp32 slabs per Adam iteration and rank whatever the world size (one on two ranks with one frame each;
+    # rounds 1-5 all-gathered 2 * world slabs) -- x 20 iterations x 4 decoder planes per denoising step
+    if world > 1:
+        halo = {}
+        per_step = 0
+        for name, C, down in (("up0", 1280, 64), ("up1", 1280, 32), ("up2", 1280, 16), ("up3", 640, 8)):
+            slab = 2 * C * (R // down) ** 2 * 4
+            n = 1 if (N // world == 1 and world == 2) else 2
+            halo[name] = dict(slabs_per_iteration=n, bytes_per_iteration=n * slab)
+            per_step += 20 * n * slab
+        halo["per_step_20_iterations"] = per_step
+        out["optimize_feature_halo"] = halo
     return out
 
 
@@ -470,12 +483,53 @@ def exchange_timing(layers, params, N, device, shard, reps=10):
         t["cross_frame_bytes_received"] = int(((HW if shard.rank else 0) + (shard.world - 1) * plan["Rmax"]) * shard.chunk * 2 * C * 2)
         t["all_to_all_bytes_sent"] = int((send.numel() + back.numel()) * 2 * (shard.world - 1) / shard.world)
         res[l["name"]] = t
+    # optimize_feature's halo exchange (neighbour-only, two slabs each way) at the largest decoder plane: alone, and the
+    # same exchange started before / finished after a stand-in for the launches it is meant to hide under (a device copy of
+    # the features: ~ the HBM traffic of one prep launch) -- `halo_overlapped_extra_us` ~ 0 means the transfer is hidden
+    C0, hh = 640, layers[3]["HW"]
+    side = int(round(hh ** 0.5))
+    cs = torch.randn(shard.B_loc, C0, side, side, device=device, dtype=torch.float32)
+    scratch = torch.empty_like(cs)
+
+    def halo():
+        shard.halo_finish(shard.halo_start(cs))
+
+    def halo_under_copy():
+        hnd = shard.halo_start(cs)
+        for _ in range(4):
+            scratch.copy_(cs)
+        shard.halo_finish(hnd)
+
+    def copy_only():
+        for _ in range(4):
+            scratch.copy_(cs)
+
+    th = {}
+    for name, fn in (("halo_exchange_us", halo), ("halo_under_copies_us", halo_under_copy), ("copies_alone_us", copy_only)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        th[name] = round(1e3 * e0.elapsed_time(e1) / reps, 1)
+    th["halo_bytes_received"] = int((1 if (shard.n_loc == 1 and shard.world == 2) else 2) * shard.chunk * C0 * hh * 4)
+    res["optimize_feature_halo_640x%dx%d" % (side, side)] = th
     # slowest rank per entry
     for name in res:
-        for k in ("cross_frame_exchange_us", "temporal_all_to_all_pair_us"):
+        for k in ("cross_frame_exchange_us", "temporal_all_to_all_pair_us", "halo_exchange_us", "halo_under_copies_us",
+                  "copies_alone_us"):
+            if k not in res[name]:
+                continue
             tt = torch.tensor([res[name][k]], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             res[name][k] = round(float(tt.item()), 1)
+    hk = "optimize_feature_halo_640x%dx%d" % (side, side)
+    res[hk]["halo_overlapped_extra_us"] = round(res[hk]["halo_under_copies_us"] - res[hk]["copies_alone_us"], 1)
     res["form"] = "grouped point-to-point" if shard.p2p_exchange else "broadcast + all-gather"
     res["note"] = "max over ranks of the mean of %d back-to-back exchanges, nothing overlapping them" % reps
     return res
@@ -486,6 +540,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=15)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="repetitions of the timed block of --steps steps (each bracketed by barrier + synchronize, max over "
+                         "ranks); `value` is steps / the MEDIAN block time, min / max / every block in the line")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -568,12 +625,28 @@ def main():
     torch.cuda.synchronize()
 
     run_eager(0, args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_eager(0, args.steps)
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    # The timed block: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks -- repeated --reps
+    # times back to back.  The boxes of the pool differ by +- 5-8 % and a single 20-step sample cannot carry the headline
+    # (VERDICT r05): `value` = steps / the MEDIAN block; every block, min and max are in the line.  host_s: the time this
+    # rank's host needed to ISSUE the block (before the closing synchronize): N > 1 runs are host-bound when it nears dt.
+    block_s, host_s = [], []
+    for _ in range(max(args.reps, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        run_eager(0, args.steps)
+        t_issue = time.perf_counter() - t0
+        barrier()
+        block_s.append(max_over_ranks(time.perf_counter() - t0))
+        host_s.append(t_issue)
+    dt = sorted(block_s)[len(block_s) // 2] if len(block_s) % 2 else 0.5 * sum(sorted(block_s)[len(block_s) // 2 - 1:len(block_s) // 2 + 1])
+    host_ms_per_step = 1e3 * sorted(host_s)[len(host_s) // 2] / args.steps
     launch_mode = "eager"
+    host_all = [host_ms_per_step]
+    if world > 1:
+        th = torch.zeros(world, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        th[rank] = host_ms_per_step
+        dist.all_reduce(th, op=dist.ReduceOp.SUM)
+        host_all = [float(v) for v in th.tolist()]
 
     # instrumented replay of the same K steps: per-launch HIP-event durations of the dominant kernel
     cap = args.steps * 64 + 64
@@ -625,6 +698,12 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "timing": dict(repetitions=len(block_s), statistic="median of the timed blocks (each = --steps steps, barrier + "
+                           "synchronize on both sides, max over ranks)",
+                           ms_per_step_all=[round(1e3 * b / args.steps, 4) for b in block_s],
+                           ms_per_step_min=round(1e3 * min(block_s) / args.steps, 4),
+                           ms_per_step_max=round(1e3 * max(block_s) / args.steps, 4),
+                           value_min=round(args.steps / max(block_s), 3), value_max=round(args.steps / min(block_s), 3)),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -647,6 +726,9 @@ def main():
             "kernel_avg_us": kernels_us,
             "launch_mode": launch_mode,
             "ms_per_step_by_mode": {"eager": round(1e3 * dt / args.steps, 4)},
+            # what every rank's HOST needed to issue one step (median block, before the closing synchronize): when it nears
+            # ms_per_step the run is host-bound, not kernel- or fabric-bound
+            "host_issue_ms_per_step": dict(per_rank=[round(v, 4) for v in host_all], max=round(max(host_all), 4)),
         }
         if world > 1:
             M_rest = {}
@@ -714,17 +796,91 @@ def main():
                                     attention_ms=res["ms_per_step"], feature_opt_ms=res["cfg3"]["ms_per_step"],
                                     vs_torch_gpu=round((1e3 / res["torch_gpu_baseline"]["value"] +
                                                         res["cfg3"]["torch_gpu_baseline"]["ms_per_step"]) / tot_ms, 2))
+            # the keyframe pipeline's own mix of the two step kinds (run_fresco.py:232 optimises features on
+            # timesteps[:end_opt_step]; the SDEdit loop of src/pipe_FRESCO.py:166 runs timesteps[num_warmup_steps:]):
+            # config_carturn.yaml:21-23 = 20 steps, 5 skipped, end_opt_step 15 -> 10 optimised + 5 plain steps executed;
+            # without the warm-up skip (num_warmup_steps = 0) 15 + 5
+            att, opt = res["ms_per_step"], res["cfg3"]["ms_per_step"]
+            t_att = 1e3 / res["torch_gpu_baseline"]["value"]
+            t_att_lean = 1e3 / res["torch_gpu_baseline"]["lean_port"]["value"]
+            t_opt = res["cfg3"]["torch_gpu_baseline"]["ms_per_step"]
+
+            def mix(n_opt, n_plain):
+                ours = (n_opt * (att + opt) + n_plain * att) / (n_opt + n_plain)
+                ref = (n_opt * (t_att + t_opt) + n_plain * t_att) / (n_opt + n_plain)
+                lean = (n_opt * (t_att_lean + t_opt) + n_plain * t_att_lean) / (n_opt + n_plain)
+                return dict(optimised_steps=n_opt, plain_steps=n_plain, ms_per_step=round(ours, 3),
+                            value=round(1e3 / ours, 3), torch_gpu_ms_per_step=round(ref, 3),
+                            vs_torch_gpu=round(ref / ours, 2), vs_torch_gpu_lean_port=round(lean / ours, 2))
+
+            res["pipeline_weighted"] = dict(
+                metric="denoising-steps/sec of the FRESCO hot path over the keyframe pipeline's own step mix",
+                config_carturn=mix(10, 5), no_warmup_skip=mix(15, 5),
+                where_the_north_star_is_met="steps with feature optimisation (configs[2]): %.1fx the reference's op sequence; "
+                                            "attention-only steps (configs[1], the headline `value`): %.2fx (%.2fx vs the lean "
+                                            "port) -- the >= 10x target is met on the former and NOT on the latter"
+                                            % (res["cfg3_step"]["vs_torch_gpu"], res["speedup_vs_torch_gpu"],
+                                               res["speedup_vs_torch_gpu_lean_port"]))
+            res["vs_baseline_range"] = dict(vs_reference_op_sequence=res["speedup_vs_torch_gpu"],
+                                            vs_lean_port=res["speedup_vs_torch_gpu_lean_port"],
+                                            note="the reference's op sequence includes its two torch.cuda.empty_cache() calls "
+                                                 "per layer call; the lean port drops them and the redundant clones")
         elif world == 1:
             res["cpu_baseline"] = None
+    # ---- watchdog for everything below (started BEFORE the cfg5 leg: a rank that throws inside it would otherwise leave its
+    # peers in a collective with nobody watching).  A hang prints the line as far as it got and exits; the watchdog's line
+    # and the normal one are mutually exclusive.
+    want_graph = os.environ.get("FRESCO_BENCH_GRAPH", "0") == "1"
+    # (opt-in like the graph leg: a leg that has never run on RCCL must not be able to cost the driver's scale run its line --
+    # a hang would hold the JSON back until the watchdog fires)
+    want_p2p = world > 1 and backend == "nccl" and os.environ.get("FRESCO_BENCH_P2P", "0") == "1"
+    fenced = want_graph or want_p2p or world > 1
+    import threading
+
+    out_lock = threading.Lock()
+    printed = [False]
+    stage = ["cfg5 leg"]
+
+    def emit():
+        with out_lock:
+            if rank == 0 and not printed[0]:
+                print(json.dumps(res), flush=True)
+            printed[0] = True
+
+    def bail():
+        if rank == 0:
+            res["optional_legs"] = dict(status="did not finish within the watchdog time", stage=stage[0])
+        emit()
+        os._exit(0)  # (a hung collective cannot be torn down from here; the eager result above is complete)
+
+    dog = None
+    if fenced:
+        dog = threading.Timer(float(os.environ.get("FRESCO_BENCH_GRAPH_TIMEOUT", "120")) + (60.0 if world > 1 else 0.0), bail)
+        dog.daemon = True
+        dog.start()
+
+    def all_min(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
     # ---- cfg5 leg (every world size, every rank takes part): 32 frames x 768^2 sharded over the same ranks -- the workload
     # the frame-parallel claim of BASELINE.json rests on (per-frame work 16x config 2's).  It runs at N = 1 too, so that a
     # SCALE record of the default command carries this workload's own curve next to config 2's strong-scaling `value`.
     if (N, R) == (8, 512) and 32 % world == 0 and not args.no_aux:
+        ok5 = 1.0
         try:
             c5 = timed_workload(32, 768, device, (rank, world) if world > 1 else None, max(args.steps // 2, 2), 1, barrier,
                                 max_over_ranks)
         except Exception as e:  # noqa: BLE001 -- an auxiliary leg must not take the measurement with it
             c5 = dict(error="%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else ""))
+            ok5 = 0.0
+        # every rank agrees on the outcome before any rank moves on to the next collective (a rank that threw while its
+        # peers sit in an all-to-all never gets past this line: the watchdog then prints the eager result and exits)
+        if all_min(ok5) != 1.0 and "error" not in c5:
+            c5 = dict(error="failed on another rank")
         if rank == 0:
             res["cfg5"] = c5
     # ---- optional legs, all AFTER the result above is complete and all fenced by one watchdog (a hang prints the eager
@@ -743,40 +899,8 @@ def main():
     #       rank's share of the kernels, so replay is what a production loop would use -- but capture with collectives
     #       inside is unverified.  A failure on ANY rank (agreed through an all-reduce) keeps the eager result.
     # `value` / `ms_per_step` are ALWAYS the eager figures of the default exchange form.
-    want_graph = os.environ.get("FRESCO_BENCH_GRAPH", "0") == "1"
-    # (opt-in like the graph leg: a leg that has never run on RCCL must not be able to cost the driver's scale run its line --
-    # a hang would hold the JSON back until the watchdog fires)
-    want_p2p = world > 1 and backend == "nccl" and os.environ.get("FRESCO_BENCH_P2P", "0") == "1"
-    if want_graph or want_p2p or world > 1:
-        import threading
-
-        out_lock = threading.Lock()  # the watchdog's line and the normal one are mutually exclusive
-        printed = [False]
-        stage = ["starting"]
-
-        def emit():
-            with out_lock:
-                if rank == 0 and not printed[0]:
-                    print(json.dumps(res), flush=True)
-                printed[0] = True
-
-        def bail():
-            if rank == 0:
-                res["optional_legs"] = dict(status="did not finish within the watchdog time", stage=stage[0])
-            emit()
-            os._exit(0)  # (a hung collective cannot be torn down from here; the eager result above is complete)
-
-        dog = threading.Timer(float(os.environ.get("FRESCO_BENCH_GRAPH_TIMEOUT", "120")), bail)
-        dog.daemon = True
-        dog.start()
-
-        def all_min(x):
-            if world == 1:
-                return x
-            t = torch.tensor([x], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return float(t.item())
-
+    if fenced:
+        stage[0] = "optional legs"
         if world > 1:
             def leg(name, fn):
                 stage[0] = name

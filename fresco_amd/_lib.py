@@ -55,12 +55,12 @@ SIGNATURES = {
     "fresco_attn_f32_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fresco_attn_f32_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _f, _vp]),
     "fresco_attn_f32_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "fresco_fn_gemm": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64] + [_i] * 4 + [_f, _f] + [_i] * 7 + [_vp, _vp, _vp, _vp, _vp]),
+    "fresco_fn_gemm": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64] + [_i] * 4 + [_f, _f] + [_i] * 7 + [_vp, _vp, _vp, _vp, _vp, _vp]),
     "fresco_fn_colstats_finish": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "fresco_fn_colstats_workspace_bytes": (_sz, [_i, _i, _i]),
     "fresco_fn_colstats": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _vp]),
-    "fresco_fn_prep": (_i, [_vp] * 7 + [_i64, _i, _i, _i, _i, _i, _f, _vp]),
-    "fresco_fn_layernorm": (_i, [_vp] * 7 + [_i64, _i64, _i64, _i, _f, _f, _vp]),
+    "fresco_fn_prep": (_i, [_vp] * 7 + [_i64, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "fresco_fn_layernorm": (_i, [_vp] * 7 + [_i64, _i64, _i64, _i, _f, _f, _vp, _vp]),
     "fresco_fn_conv7_rgb": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fresco_fn_convex_upsample": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fresco_flow_occlusion": (_i, [_vp] * 5 + [_i, _i, _i, _i, _f, _f, _f, _vp]),
@@ -73,6 +73,7 @@ SIGNATURES = {
     "fresco_opt_sharded_workspace_bytes": (_sz, [_i] * 7),
     "fresco_opt_sharded_begin": (_i, [_vp] * 5 + [_sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fresco_opt_sharded_step": (_i, [_vp] * 9 + [_sz, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _vp]),
+    "fresco_opt_sharded_step_part": (_i, [_vp] * 9 + [_sz, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _i, _vp]),
     "fresco_mapping_workspace_bytes": (_sz, [_i, _i, _i]),
     "fresco_mapping_ind": (_i, [_vp] * 7 + [_sz, _i, _i, _i, _f, _vp]),
     "fresco_ddpm_x0": (_i, [_vp] * 5 + [_i64, _f, _f, _f, _i, _vp]),

@@ -27,11 +27,19 @@ namespace fresco {
 // x * scale = h + l.  The matrix pipe FLUSHES fp16 subnormals (attn32.hip), so a lo piece below 6.1e-5 would be lost and the
 // operand would be no better than fp16: every plane is written pre-scaled by a power of two -- activations by 2^6 (lo pieces
 // stay normal down to |x| = 2e-3, values up to 1000 fit), weights by 2^10 (|w| from 1.2e-4 to 60) -- and the GEMM scales its
-// fp32 accumulators back exactly.  Beyond the range the scaled value saturates (finite, wrong) instead of becoming inf / NaN.
-__device__ __forceinline__ void fn_split(float x, float scale, half_t& h, half_t& l) {
-    x = fminf(fmaxf(x * scale, -65000.f), 65000.f);
+// fp32 accumulators back exactly.  Beyond the range the scaled value saturates (finite, wrong) instead of becoming inf / NaN
+// -- and the producer says so: fn_split returns true for a value it had to clamp (or a NaN), every producer kernel ORs
+// that into the caller's `range_flag` word (fresco_fn_prep / _layernorm / _gemm), and the host side of the flow network
+// re-runs the forward with library ops when the word is set (fresco_amd/gmflow.py) -- the flows feed integer decisions.
+__device__ __forceinline__ bool fn_split(float x, float scale, half_t& h, half_t& l) {
+    const float xs = x * scale;
+    x = fminf(fmaxf(xs, -65000.f), 65000.f);
     h = (half_t)x;
     l = (half_t)(x - (float)h);
+    return !(fabsf(xs) <= 65000.f);
+}
+__device__ __forceinline__ void fn_flag_range(int32_t* range_flag, bool sat) {
+    if (range_flag && sat) atomicOr(range_flag, 1);  // (rare path)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -56,7 +64,7 @@ __device__ __forceinline__ int fn_row_of(const FnConv& cv, int blk, int r) {
 
 // one LDS-DMA piece: 64 lanes x 16 bytes, lane l's bytes land at lds_dst + 16 l (M0 is written in the statement that uses it)
 __device__ __forceinline__ void fn_dma16(const void* gsrc, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");  // (m0 cannot be listed as a clobber: hipcc rejects it as a reserved register; it does not keep values in m0 across statements on gfx9+)
 }
 template <int N_>
 __device__ __forceinline__ void fn_wait_barrier() {
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                                                          int K, int act, float acc_scale, float split_scale,
                                                          double* __restrict__ stats, const void* __restrict__ zeros,
                                                          const int32_t* __restrict__ a_rows,
-                                                         const int32_t* __restrict__ out_rows) {
+                                                         const int32_t* __restrict__ out_rows, int32_t* range_flag) {
     // a_rows / out_rows (linear layers; NULL = identity): problem row m reads input row a_rows[m] and its results go to output
     // row out_rows[m] -- the token gather / scatter of the (shifted-)window attention folded into the projections around it
     constexpr int BM = FN_BM, BK = FN_BK, NS = FN_NS;
@@ -261,6 +269,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
     }
     if (o_hi) {
         constexpr int PPR = WN / 8;  // 16-byte pieces per row
+        bool sat = false;
 #pragma unroll
         for (int plane = 0; plane < 2; ++plane) {
 #pragma unroll
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         half_t h, l;
-                        fn_split(acc[i][j][r], split_scale, h, l);
+                        sat |= fn_split(acc[i][j][r], split_scale, h, l);
                         const int off = (i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * TROW + (j * 32 + l31) * 2;
                         *reinterpret_cast<half_t*>(tp + off) = plane == 0 ? h : l;
                     }
@@ -285,6 +294,8 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                     *reinterpret_cast<half8_t*>(op + (int64_t)(out_rows ? out_rows[m] : m) * ldo + n) = v8;
             }
         }
+        // (accumulators of rows / columns outside the problem are products with the zero page: never out of range)
+        fn_flag_range(range_flag, sat);
     }
 }
 
@@ -365,7 +376,8 @@ __global__ __launch_bounds__(256) void fn_prep_kernel(const float* __restrict__ 
                                                       const float* __restrict__ rstd, const float* __restrict__ res,
                                                       float* __restrict__ y, half_t* __restrict__ o_hi,
                                                       half_t* __restrict__ o_lo, int64_t M, int C, int ldo,
-                                                      int rows_per_img, int relu_a, int relu_b, float split_scale) {
+                                                      int rows_per_img, int relu_a, int relu_b, float split_scale,
+                                                      int32_t* range_flag) {
     const int q = ldo / 4;  // quads per output row (C % 4 == 0, ldo % 4 == 0)
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * q) return;
@@ -399,15 +411,17 @@ __global__ __launch_bounds__(256) void fn_prep_kernel(const float* __restrict__ 
     }
     if (o_hi) {
         half4_t h, l;
+        bool sat = false;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             half_t hh, ll;
-            fn_split(v[e], split_scale, hh, ll);
+            sat |= fn_split(v[e], split_scale, hh, ll);
             h[e] = hh;
             l[e] = ll;
         }
         *reinterpret_cast<half4_t*>(o_hi + m * ldo + c) = h;
         *reinterpret_cast<half4_t*>(o_lo + m * ldo + c) = l;
+        if (sat && range_flag) atomicOr(range_flag, 1);  // (rare; threads past M * q have returned: no wave-wide vote here)
     }
 }
 
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(256) void fn_layernorm_kernel(const float* __restri
                                                            const float* __restrict__ beta, const float* __restrict__ res,
                                                            float* __restrict__ y, half_t* __restrict__ o_hi,
                                                            half_t* __restrict__ o_lo, int64_t ldy, int64_t ldo, int64_t M,
-                                                           float eps, float split_scale) {
+                                                           float eps, float split_scale, int32_t* range_flag) {
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -438,8 +452,9 @@ __global__ __launch_bounds__(256) void fn_layernorm_kernel(const float* __restri
     }
     if (o_hi) {
         half_t h0, l0, h1, l1;
-        fn_split(ya, split_scale, h0, l0);
-        fn_split(yb, split_scale, h1, l1);
+        bool sat = fn_split(ya, split_scale, h0, l0);
+        sat |= fn_split(yb, split_scale, h1, l1);
+        if (sat && range_flag) atomicOr(range_flag, 1);
         o_hi[m * ldo + lane * 2] = h0;
         o_hi[m * ldo + lane * 2 + 1] = h1;
         o_lo[m * ldo + lane * 2] = l0;
@@ -541,7 +556,7 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
                               const float* bias, float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M,
                               int N, int K, int act, float acc_scale, float split_scale, int n_img, int H, int W, int kh,
                               int kw, int stride, int pad, void* stats, const void* zeros, const int32_t* a_rows,
-                              const int32_t* out_rows, void* stream) {
+                              const int32_t* out_rows, int32_t* range_flag, void* stream) {
     if (!zeros) return FRESCO_EINVAL;
     if ((a_rows || out_rows) && (kh > 0 || stats)) return FRESCO_EUNSUPPORTED;
     if (!a_hi || !a_lo || !w_hi || !w_lo || (!out && !out_hi) || (out_hi && !out_lo) || M <= 0 || N <= 0 || K <= 0)
@@ -580,14 +595,14 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
-                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows);
+                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows, range_flag);
     } else {
         constexpr int BN = 128;
         const int lds = FN_NS * (2 * FN_BM * 64 + 2 * BN * 64);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
-                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows);
+                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows, range_flag);
     }
     return check_launch();
 }
@@ -625,7 +640,7 @@ extern "C" int fresco_fn_colstats_finish(const void* stats, float* mean, float* 
 
 extern "C" int fresco_fn_prep(const float* x, const float* mean, const float* rstd, const float* residual, float* y,
                               void* out_hi, void* out_lo, int64_t M, int C, int ldo, int rows_per_img, int relu_a,
-                              int relu_b, float split_scale, void* stream) {
+                              int relu_b, float split_scale, int32_t* range_flag, void* stream) {
     if (!x || M <= 0 || C <= 0 || (!y && !out_hi) || (out_hi && !out_lo) || ((mean != nullptr) != (rstd != nullptr)))
         return FRESCO_EINVAL;
     if (C % 4 != 0) return FRESCO_EUNSUPPORTED;
@@ -634,18 +649,18 @@ extern "C" int fresco_fn_prep(const float* x, const float* mean, const float* rs
     const int64_t n = M * (ldo / 4);
     hipLaunchKernelGGL(fn_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, mean, rstd,
                        residual, y, static_cast<half_t*>(out_hi), static_cast<half_t*>(out_lo), M, C, ldo,
-                       rows_per_img > 0 ? rows_per_img : 1, relu_a, relu_b, split_scale);
+                       rows_per_img > 0 ? rows_per_img : 1, relu_a, relu_b, split_scale, range_flag);
     return check_launch();
 }
 
 extern "C" int fresco_fn_layernorm(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                                    void* out_hi, void* out_lo, int64_t ldy, int64_t ldo, int64_t M, int C, float eps,
-                                   float split_scale, void* stream) {
+                                   float split_scale, int32_t* range_flag, void* stream) {
     if (!x || !gamma || !beta || M <= 0 || (!y && !out_hi) || (out_hi && !out_lo)) return FRESCO_EINVAL;
     if (C != 128) return FRESCO_EUNSUPPORTED;
     if ((y && ldy < C) || (out_hi && ldo < C)) return FRESCO_EINVAL;
     hipLaunchKernelGGL(fn_layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream), x, gamma, beta,
-                       residual, y, static_cast<half_t*>(out_hi), static_cast<half_t*>(out_lo), ldy, ldo, M, eps, split_scale);
+                       residual, y, static_cast<half_t*>(out_hi), static_cast<half_t*>(out_lo), ldy, ldo, M, eps, split_scale, range_flag);
     return check_launch();
 }
 

@@ -825,7 +825,9 @@ static int opt_check_grid(int chunk, int N, int C) {
 static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const float* bwd_flow,
                         const float* fwd_occ, const float* bwd_occ, const float* target, int chunk, int N,
                         int C, int h, int wd, float intra_weight, int has_t, int has_s, int mode,
-                        float* gout, float* loss, AdamArgs a, hipStream_t st, const TLayout& L, int Bg) {
+                        float* gout, float* loss, AdamArgs a, hipStream_t st, const TLayout& L, int Bg, int parts = 3) {
+    // parts (frame-sharded form): 1 = the launches that read no halo frame (normalise, Gram, S V), 2 = residual signs of
+    // every pair + Adam; 3 = both.  The sign launch is independent of part 1's, so 1 then 2 equals 3 bit for bit.
     const int B = chunk * N, hw = h * wd;
     const float kscale = 2.f / ((float)Bg * (float)C * (float)hw);
     const int S = chan_slices(hw, B, C);
@@ -838,13 +840,13 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
         return (e && e[0] == 'f' && e[1] == '3') ? 1 : 0;
     }();
     const bool f16_sv = (hw % 16 == 0) && sv_mode == 0;
-    if (has_t) {
+    if (has_t && (parts & 2)) {
         dim3 sgrid((hw + 255) / 256, (C + OCPT - 1) / OCPT, chunk * L.n_pairs);
         ProfScope ps(FRESCO_PROF_OPT_TSIGN, B, C, hw, 0, st);
         hipLaunchKernelGGL(temporal_sign_kernel, sgrid, dim3(256), 0, st, cs, bwd_flow, fwd_flow, bwd_occ, fwd_occ,
                            w.sgn1, w.sgn2, loss, L, C, h, wd);
     }
-    if (has_s) {
+    if (has_s && (parts & 1)) {
         {
             ProfScope ps(FRESCO_PROF_OPT_COLNORM, B, C, hw, 0, st);
             hipLaunchKernelGGL((chan_partial_kernel<0>), dim3((hw + 63) / 64, S, B), dim3(256), 0, st, cs,
@@ -875,6 +877,7 @@ static void opt_closure(const OptWs& w, float* cs, const float* fwd_flow, const 
                                    w.dvt, C, hw, 2.f * coef);
         }
     }
+    if (!(parts & 2)) return;
     ProfScope ps(FRESCO_PROF_OPT_ADAM, B, C, hw, 0, st);
     const bool v_stored = !(has_s && (hw % 16 == 0) && sv_mode == 0 && C % 8 == 0);
     if (has_s) {
@@ -1222,18 +1225,19 @@ extern "C" int fresco_opt_sharded_begin(const float* fwd_flow, const float* bwd_
     return check_launch();
 }
 
-extern "C" int fresco_opt_sharded_step(float* cs, const float* halo_l, const float* halo_r,
-                                       const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
-                                       const float* bwd_occ, const float* target, void* workspace,
-                                       size_t workspace_bytes, int chunk, int n_loc, int N_total, int C, int h,
-                                       int w, float intra_weight, int it, float lr, float beta1, float beta2,
-                                       float eps, void* stream) {
+extern "C" int fresco_opt_sharded_step_part(float* cs, const float* halo_l, const float* halo_r,
+                                            const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                                            const float* bwd_occ, const float* target, void* workspace,
+                                            size_t workspace_bytes, int chunk, int n_loc, int N_total, int C, int h,
+                                            int w, float intra_weight, int it, float lr, float beta1, float beta2,
+                                            float eps, int part, void* stream) {
     if (!cs || !workspace || chunk <= 0 || n_loc <= 0 || N_total < n_loc || C <= 0 || h <= 1 || w <= 1 || it < 1)
         return FRESCO_EINVAL;
+    if (part < 1 || part > 3) return FRESCO_EINVAL;
     const bool all_t = fwd_flow && bwd_flow && fwd_occ && bwd_occ;
     const int has_t = all_t ? 1 : 0, has_s = (target && intra_weight > 0.f) ? 1 : 0;
     if (!has_t && !has_s) return FRESCO_EINVAL;
-    if (has_t && (!halo_l || !halo_r)) return FRESCO_EINVAL;
+    if (has_t && (part & 2) && (!halo_l || !halo_r)) return FRESCO_EINVAL;  // (part 1 reads no halo frame)
     if (workspace_bytes < opt_ws_layout(nullptr, nullptr, chunk, n_loc, C, h, w, has_t, has_s, n_loc + 1))
         return FRESCO_EWORKSPACE;
     hipStream_t st = as_stream(stream);
@@ -1241,13 +1245,27 @@ extern "C" int fresco_opt_sharded_step(float* cs, const float* halo_l, const flo
     opt_ws_layout(&ws, static_cast<char*>(workspace), chunk, n_loc, C, h, w, has_t, has_s, n_loc + 1);
     const TLayout L = {n_loc, n_loc + 1, 0, halo_l, halo_r};
     if (opt_fast_ok(C, h, w, has_s)) {
-        if (it == 1) opt_fast_begin(ws, cs, chunk * n_loc, C, h * w, chunk * N_total, st);
+        if (it == 1 && (part & 1)) opt_fast_begin(ws, cs, chunk * n_loc, C, h * w, chunk * N_total, st);
+        FastSync y;
+        y.parts = part;
+        y.halo_split = part == 3 ? 0 : 1;
         opt_fast_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, C, h, w, intra_weight, has_t, 0,
-                         nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N_total);
+                         nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N_total, &y);
     } else
         opt_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, n_loc, C, h, w, intra_weight, has_t,
-                    has_s, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N_total);
+                    has_s, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N_total, part);
     return check_launch();
+}
+
+extern "C" int fresco_opt_sharded_step(float* cs, const float* halo_l, const float* halo_r,
+                                       const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                                       const float* bwd_occ, const float* target, void* workspace,
+                                       size_t workspace_bytes, int chunk, int n_loc, int N_total, int C, int h,
+                                       int w, float intra_weight, int it, float lr, float beta1, float beta2,
+                                       float eps, void* stream) {
+    return fresco_opt_sharded_step_part(cs, halo_l, halo_r, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, workspace,
+                                        workspace_bytes, chunk, n_loc, N_total, C, h, w, intra_weight, it, lr, beta1, beta2,
+                                        eps, 3, stream);
 }
 
 extern "C" int fresco_gram_target(const float* x, float* target, void* workspace, size_t workspace_bytes,

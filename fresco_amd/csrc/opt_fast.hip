@@ -105,6 +105,11 @@ struct PrepArgs {
     float* loss;
     TLayout L;
     int C, h, w, K, NPART, NPB, has_t, pm_tiled, cm_tiled;
+    // frame-sharded form only: 0 = everything; 1 = the part that needs no halo frame (normalisation + copies of every
+    // local frame, signs of the interior pairs); 2 = the signs of the two pairs that touch a halo frame, nothing else.
+    // 1 followed by 2 performs, per element, exactly the operations of 0 (results identical bit for bit): the split only
+    // lets the neighbour exchange of the halo frames run under the Gram / S V launches (fresco_opt_sharded_step_part)
+    int phase;
 };
 
 __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
@@ -134,7 +139,11 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
     float lsum = 0.f;
     __shared__ __attribute__((aligned(16))) half_t cmx[4][2][8][64];  // [slice = wave][hi, lo][channel of the octet][pixel]
     __shared__ float nred[4][64];
-    const bool do_norm = fn >= 0;  // (block-uniform)
+    // (all block-uniform)
+    const bool boundary = a.has_t && !L.circular && (pj == 0 || pj == L.n_pairs - 1);  // the pair reads a halo frame
+    const bool do_signs = a.has_t && !(a.phase == 1 && boundary) && !(a.phase == 2 && !boundary);
+    const bool do_norm = fn >= 0 && a.phase != 2;
+    if (!do_signs && !do_norm) return;
     const int64_t bn = (int64_t)ck * L.n_loc + fn;
     float n = 1.f;
     if (do_norm) {
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
         if (do_norm && j == 0) a.nrm[bn * hw + p] = n;
         OTaps tb, tf;
         float mb = 0.f, mf = 0.f;
-        if (a.has_t) {
+        if (do_signs) {
             const float* fb = a.bwd_flow + (int64_t)pj * 2 * hw;
             const float* ff = a.fwd_flow + (int64_t)pj * 2 * hw;
             tb = otaps(fb[p], fb[hw + p], p % a.w, p / a.w, a.h, a.w);
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256) void opt_prep_kernel(PrepArgs a) {
             float x1[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x1[k] = c1p[(int64_t)k * hw + p];
-            if (a.has_t) {
+            if (do_signs) {
                 const float* c2p = frame_plane(a.cs, L, ck, sb, c0, C, hw);
                 uint64_t w1 = 0, w2 = 0;
 #pragma unroll
@@ -1268,9 +1277,9 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     const bool big = gram_x_layout(hw, C);
     const float kscale = 2.f / ((float)Bg * (float)C * (float)hw);
     const int parts = sync ? sync->parts : 3;
-    if (parts & 1) {
-    {
-        ProfScope ps(FRESCO_PROF_OPT_TSIGN, planes, C, hw, 0, st);
+    const int halo_split = (sync && sync->halo_split && has_t && !L.circular) ? 1 : 0;
+    auto launch_prep = [&](int phase) {
+        ProfScope ps(FRESCO_PROF_OPT_TSIGN, planes, C, hw, phase, st);
         PrepArgs pa;
         pa.cs = cs;
         pa.part = w.part;
@@ -1296,9 +1305,12 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
         pa.has_t = has_t;
         pa.pm_tiled = big ? 1 : 0;
         pa.cm_tiled = cm_tiled ? 1 : 0;
+        pa.phase = phase;
         const int nz = nck * (has_t ? L.n_pairs : L.n_loc);
         hipLaunchKernelGGL(opt_prep_kernel, dim3(hw / 64, NPBp, nz), dim3(256), 0, st, pa);
-    }
+    };
+    if (parts & 1) {
+    launch_prep(halo_split ? 1 : 0);
     float* gloss = loss ? loss + 1 : nullptr;
     if (sync && sync->wait_before_gram) (void)hipStreamWaitEvent(st, sync->wait_before_gram, 0);
     {
@@ -1411,6 +1423,7 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     if (sync && sync->record_after_sv) (void)hipEventRecord(sync->record_after_sv, st);
     }  // parts & 1
     if (!(parts & 2)) return;
+    if (halo_split) launch_prep(2);  // (the halo frames have arrived: signs of the two boundary pairs)
     if (sync && sync->wait_before_adam) (void)hipStreamWaitEvent(st, sync->wait_before_adam, 0);
     {
         ProfScope ps(FRESCO_PROF_OPT_ADAM, planes, C, hw, 0, st);

@@ -208,6 +208,9 @@ void opt_fast_begin(const OptWs& w, const float* cs, int planes, int C, int hw, 
 struct FastSync {
     hipEvent_t wait_before_gram = nullptr, record_after_gram = nullptr, record_after_sv = nullptr, wait_before_adam = nullptr;
     int parts = 3;  // 1: prep + gram + S V, 2: adam (a closure may be issued in two host calls)
+    // frame-sharded form: part 1 evaluates only what needs no halo frame, part 2 starts with the signs of the two pairs
+    // that do (PrepArgs::phase 1 / 2) -- the neighbour exchange of the halo frames then runs under Gram + S V
+    int halo_split = 0;
 };
 void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
                       const float* bwd_occ, const float* target, int nck, int C, int h, int wd, float intra_weight,

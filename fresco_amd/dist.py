@@ -27,10 +27,15 @@ not read):
      traffic is 1/world of the single-GPU pass.
 
 optimize_feature: Gram loss, normalisation, Adam and AdaIN are per frame (local); the temporal L1 term
-couples frame f with f+-1, so every Adam iteration starts with a halo exchange of the ranks' boundary
-frames (`exchange_halos`: one all-gather of 2 frames per rank, 42 MB at the largest layer) and each
-rank evaluates the n_loc+1 frame pairs touching its frames (`fresco_opt_sharded_step`).  warp_tensor's
-frame chain is a scan over frames and is not sharded (replicas).
+couples frame f with f+-1, so every Adam iteration needs the neighbours' boundary frames.  NEIGHBOUR-ONLY exchange
+(`halo_start` / `halo_finish`, round 6; rounds 1-5 all-gathered every rank's first and last frame: world x 2 slabs
+received to use 2): a rank sends its last frame to the right neighbour and its first frame to the left one -- two
+(chunk, C, h, w) slabs out, two in, whatever the world size; one slab each way when n_loc = 1 on two ranks (first frame
+= last frame, left neighbour = right neighbour).  The exchange is started asynchronously right after Adam(it - 1), runs
+under the launches of step it that read no halo frame (normalise, signs of the interior pairs, Gram, S V:
+`fresco_opt_sharded_step_part` part 1) and is waited for only in front of the two boundary pairs' signs + Adam (part 2).
+Each rank evaluates the n_loc+1 frame pairs touching its frames.  warp_tensor's frame chain is a scan over frames and is
+not sharded (replicas).
 
 The index arithmetic lives in plain functions so that it is testable on CPU (gloo, world_size 2).
 """
@@ -122,15 +127,68 @@ class FrameShard:
         term of optimize_feature: pairs f0-1 .. f0+n_loc-1 (ring order)."""
         return [(self.f0 - 1 + j) % self.N for j in range(self.n_loc + 1)]
 
-    def exchange_halos(self, cs):
-        """cs: local (chunk*n_loc, C, h, w).  Returns (halo_l, halo_r) = the current frame before / after
-        the owned range, (chunk, C, h, w) each, via one all-gather of every rank's first and last frame."""
+    # ---- halo frames of optimize_feature's temporal term: neighbour-only, asynchronous ----------------------------
+    def neighbour_exchange(self, to_left, to_right, from_left, from_right):
+        """Point-to-point ring step: `to_left` goes to rank-1, `to_right` to rank+1 (mod world); `from_left` /
+        `from_right` (preallocated, same shape) receive what the left / right neighbour sent here.  With world == 2 both
+        neighbours are the same peer: the two messages are told apart by their tags (gloo) and by the order in which
+        both sides post them (RCCL: `right-going` first on every rank).  `to_left is None` (n_loc == 1 on two ranks: one
+        frame serves both sides) sends and receives ONE message; `from_right` then aliases `from_left`.
+        Returns the list of outstanding works (empty for host-staged test backends, which complete inside)."""
+        left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        single = to_left is None
+        if self._host_staged(to_right):
+            # functional testing without RCCL (several ranks on one GPU, gloo): through host memory, blocking
+            tr = to_right.cpu()
+            fl = torch.empty_like(tr)
+            ops = [dist.P2POp(dist.isend, tr, self._global_rank(right), self.group, 1),
+                   dist.P2POp(dist.irecv, fl, self._global_rank(left), self.group, 1)]
+            if not single:
+                tl = to_left.cpu()
+                fr = torch.empty_like(tl)
+                ops += [dist.P2POp(dist.isend, tl, self._global_rank(left), self.group, 2),
+                        dist.P2POp(dist.irecv, fr, self._global_rank(right), self.group, 2)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            from_left.copy_(fl)
+            if not single:
+                from_right.copy_(fr)
+            return []
+        ops = [dist.P2POp(dist.isend, to_right, self._global_rank(right), self.group, 1),
+               dist.P2POp(dist.irecv, from_left, self._global_rank(left), self.group, 1)]
+        if not single:
+            ops += [dist.P2POp(dist.isend, to_left, self._global_rank(left), self.group, 2),
+                    dist.P2POp(dist.irecv, from_right, self._global_rank(right), self.group, 2)]
+        return [w for w in dist.batch_isend_irecv(ops) if w is not None]
+
+    def halo_start(self, cs):
+        """cs: local (chunk*n_loc, C, h, w), as the last Adam launch left it (current stream).  Starts the exchange of
+        the boundary frames with the two ring neighbours and returns a handle for `halo_finish`; nothing here waits for
+        a peer.  The handle owns packed copies of the frames sent, so `cs` may be read (not written) meanwhile."""
         x = cs.view(self.chunk, self.n_loc, *cs.shape[1:])
-        edges = torch.stack((x[:, 0], x[:, self.n_loc - 1]))  # (2, chunk, C, h, w): first, last
-        allb, _ = self.all_gather(edges)
-        left = (self.rank - 1) % self.world
-        right = (self.rank + 1) % self.world
-        return allb[left, 1], allb[right, 0]
+        first = x[:, 0].contiguous()                       # (chunk, C, h, w) -> the left neighbour's halo_r
+        if self.world == 1:                                # ring of one rank: its own last / first frame
+            return dict(halo_l=x[:, self.n_loc - 1].contiguous(), halo_r=first, works=[], keep=())
+        single = self.n_loc == 1 and self.world == 2       # one frame, one peer: a single message serves both sides
+        last = first if self.n_loc == 1 else x[:, self.n_loc - 1].contiguous()  # -> the right neighbour's halo_l
+        halo_l = torch.empty_like(first)
+        halo_r = halo_l if single else torch.empty_like(first)
+        works = self.neighbour_exchange(None if single else first, last, halo_l, halo_r)
+        nb = first.numel() * first.element_size()
+        self.halo_bytes_received = getattr(self, "halo_bytes_received", 0) + (nb if single else 2 * nb)
+        self.halo_exchanges = getattr(self, "halo_exchanges", 0) + 1
+        return dict(halo_l=halo_l, halo_r=halo_r, works=works, keep=(first, last))
+
+    def halo_finish(self, handle):
+        """-> (halo_l, halo_r) = the current frame before / after the owned range, (chunk, C, h, w) each; the current
+        stream waits for the transfers (no host wait under RCCL)."""
+        for w in handle["works"]:
+            w.wait()
+        return handle["halo_l"], handle["halo_r"]
+
+    def exchange_halos(self, cs):
+        """blocking form (start + finish); kept for callers that do not overlap the exchange"""
+        return self.halo_finish(self.halo_start(cs))
 
     def _host_staged(self, x):
         # functional testing of the multi-process path without RCCL (several ranks on one GPU): gloo, via host memory

@@ -202,15 +202,33 @@ class FeatureFlowAttention(nn.Module):
 # the dense layers on csrc/flownet.hip (GPU tensors): NHWC rows, (hi, lo) operand planes
 # ------------------------------------------------------------------------------------------------
 class _Weights:
-    """(hi, lo) fp16 planes of a layer's weight as the (N, K) matrix fresco_fn_gemm reads, made once per parameter version"""
+    """(hi, lo) fp16 planes of a layer's weight as the (N, K) matrix fresco_fn_gemm reads, made once per parameter version.
+    Range: the planes hold w * 2^10, so |w| >= 63.5 saturates; the split pass flags that on the device (ops.fn_range_guard)
+    and the verdict is kept WITH the cached planes -- `out_of_range` turns True whenever such planes are handed out, and the
+    forward that used them is recomputed with library ops (GMFlow.forward).  Staleness: the key is the parameter's version
+    counter and address; an update that bypasses the counter (`p.data.copy_()`) needs `invalidate()`."""
 
     def __init__(self):
         self.cache = {}
+        self.out_of_range = False
+
+    def invalidate(self):
+        self.cache.clear()
+        self.out_of_range = False
+
+    @staticmethod
+    def _stamp(p):
+        try:
+            return (p._version, p.data_ptr())
+        except RuntimeError:  # inference tensors track no version: never served from the cache
+            return None
 
     def get(self, p, kind, pad_cin=None):
         key = (id(p), kind)
         hit = self.cache.get(key)
-        if hit is not None and hit[0] == (p._version, p.data_ptr()):
+        stamp = self._stamp(p)
+        if hit is not None and stamp is not None and hit[0] == stamp:
+            self.out_of_range |= hit[2]
             return hit[1]
         w = p.detach().float()
         if kind == "conv":  # (cout, cin, kh, kw) -> (cout, kh, kw, cin [padded]) -> (cout, K)
@@ -218,12 +236,15 @@ class _Weights:
             if pad_cin is not None and pad_cin > w.shape[-1]:
                 w = F.pad(w, (0, pad_cin - w.shape[-1]))
             w = w.reshape(w.shape[0], -1)
-        elif kind == "stem":  # (64, 3, 7, 7) -> (7, 7, 3, 64) fp32
+        elif kind == "stem":  # (64, 3, 7, 7) -> (7, 7, 3, 64) fp32 (direct fp32 FMAs: no range limit)
             val = w.permute(2, 3, 1, 0).contiguous()
-            self.cache[key] = ((p._version, p.data_ptr()), val)
+            self.cache[key] = (stamp, val, False)
             return val
-        _, val = ops.fn_prep(w.contiguous(), scale=ops.FN_W_SCALE)
-        self.cache[key] = ((p._version, p.data_ptr()), val)
+        with ops.fn_range_guard(w.device) as g:
+            _, val = ops.fn_prep(w.contiguous(), scale=ops.FN_W_SCALE)
+        bad = g.tripped()  # (one host sync per parameter version)
+        self.out_of_range |= bad
+        self.cache[key] = (stamp, val, bad)
         return val
 
 
@@ -441,7 +462,19 @@ class GMFlow(nn.Module):
         std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
         x = torch.cat((img0, img1), 0).float()
         if x.is_cuda and os.environ.get("FRESCO_GMFLOW_LIBRARY_OPS", "0") != "1":
-            return {"flow_preds": [self._forward_native((x / 255.0 - mean) / std, splits, pred_bidir_flow)]}
+            # the dense layers' operands live as fp16 planes of x * 2^6 (weights: w * 2^10): an activation beyond +-1015 or a
+            # weight beyond +-63 would saturate there -- finite, wrong, and these flows feed occlusion thresholds and pixel
+            # correspondences.  Every producer kernel flags it on the device; one word is read back per forward and the
+            # forward is recomputed with library ops (exact fp32 range) when it is set.
+            self._wts.out_of_range = False
+            with ops.fn_range_guard(x.device) as guard:
+                flow = self._forward_native((x / 255.0 - mean) / std, splits, pred_bidir_flow)
+            if not (guard.tripped() or self._wts.out_of_range):
+                return {"flow_preds": [flow]}
+            import warnings
+            warnings.warn("fresco_amd.GMFlow: an activation or weight left the range of the split-fp16 dense layers "
+                          "(|activation| < 1015, |weight| < 63); this forward is recomputed with library ops",
+                          RuntimeWarning, stacklevel=2)
         feats = self.backbone((x / 255.0 - mean) / std)
         f0, f1 = feats.chunk(2, 0)
         b, c, h, w = f0.shape

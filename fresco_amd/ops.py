@@ -259,6 +259,60 @@ def attention_f32(q, k, v, scale):
 FN_A_SCALE, FN_W_SCALE = 64.0, 1024.0
 _fn_zero_page = {}  # per device: 128 bytes of zeros, the LDS-DMA source of rows outside a GEMM (padding, tails)
 
+# Range guard of the split planes: |x * scale| beyond 65000 saturates -- finite, wrong.  Every producer ORs 1
+# into the int32 word of the innermost `fn_range_guard` of the calling thread; whoever opened the guard reads the word once
+# (one host sync per flow-network forward) and recomputes with library ops when it is set.
+import threading as _threading
+
+_fn_guard = _threading.local()
+
+
+class fn_range_guard:
+    """with fn_range_guard(device) as g: ... producers ...;  g.tripped() -> bool (synchronises)"""
+
+    def __init__(self, device):
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def __enter__(self):
+        self._outer = getattr(_fn_guard, "cur", None)
+        _fn_guard.cur = self
+        return self
+
+    def __exit__(self, *exc):
+        _fn_guard.cur = self._outer
+        return False
+
+    def tripped(self):
+        return bool(int(self.flag.item()) != 0)
+
+
+def _fn_flag_ptr(device):
+    g = getattr(_fn_guard, "cur", None)
+    if g is None:
+        return None
+    if g.flag.device != device:
+        raise ValueError("fn_range_guard on %s, operands on %s" % (g.flag.device, device))
+    return g.flag.data_ptr()
+
+
+def _fn_f32_operand(t, name, like):
+    """optional fp32 side operand (bias, gamma, mean, residual ...) of a flownet.hip kernel: the kernels read raw fp32 words,
+    so a .half() module or a strided view must not get through as it is"""
+    if t is None:
+        return None
+    if not t.is_cuda or t.device != like.device:
+        raise ValueError("fresco_amd: %s on %s, operands on %s" % (name, t.device, like.device))
+    return _f32c(t)
+
+
+def _fn_rows_table(t, name, like, n=None):
+    if t is None:
+        return None
+    if t.dtype != torch.int32 or not t.is_contiguous() or t.device != like.device or (n is not None and t.numel() != n):
+        raise ValueError("fresco_amd: %s must be a contiguous int32 table%s on the operands' device"
+                         % (name, "" if n is None else " of %d rows" % n))
+    return t
+
 
 def fn_prep(x, mean=None, rstd=None, residual=None, rows_per_img=0, relu_a=False, relu_b=False, want_f32=False,
             want_split=True, ld=None, out_split=None, scale=FN_A_SCALE):
@@ -268,6 +322,7 @@ def fn_prep(x, mean=None, rstd=None, residual=None, rows_per_img=0, relu_a=False
     _need_gpu(x)
     x = _f32c(x)
     M, C = x.shape
+    mean, rstd, residual = (_fn_f32_operand(t, n_, x) for t, n_ in ((mean, "mean"), (rstd, "rstd"), (residual, "residual")))
     y = torch.empty_like(x) if want_f32 else None
     hi = lo = None
     ldo = C
@@ -278,7 +333,8 @@ def fn_prep(x, mean=None, rstd=None, residual=None, rows_per_img=0, relu_a=False
         hi = torch.empty(M, ldo, dtype=torch.float16, device=x.device)
         lo = torch.empty(M, ldo, dtype=torch.float16, device=x.device)
     rc = _lib.load().fresco_fn_prep(x.data_ptr(), _ptr(mean), _ptr(rstd), _ptr(residual), _ptr(y), _ptr(hi), _ptr(lo), M, C,
-                                    int(ldo), int(rows_per_img), int(relu_a), int(relu_b), float(scale), _stream())
+                                    int(ldo), int(rows_per_img), int(relu_a), int(relu_b), float(scale),
+                                    _fn_flag_ptr(x.device), _stream())
     _lib.check(rc, "fresco_fn_prep(M=%d,C=%d,ld=%d)" % (M, C, ldo))
     return y, ((hi, lo) if hi is not None else None)
 
@@ -321,6 +377,9 @@ def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want
         M = n_img * OH * OW
         cargs = (n_img, H, W, kh, kw, stride, pad)
     dev = ah.device
+    bias = _fn_f32_operand(bias, "bias", ah)
+    a_rows = _fn_rows_table(a_rows, "a_rows", ah, M)
+    out_rows = _fn_rows_table(out_rows, "out_rows", ah, M)
     out = out_f32 if out_f32 is not None else (torch.empty(M, N, dtype=torch.float32, device=dev) if want_f32 else None)
     oh = ol = None
     ldo = N
@@ -339,7 +398,8 @@ def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want
     lib = _lib.load()
     rc = lib.fresco_fn_gemm(ah.data_ptr(), al.data_ptr(), lda, wh.data_ptr(), wl.data_ptr(), _ptr(bias), _ptr(out),
                             _ptr(oh), _ptr(ol), N, int(ldo), M, N, K, int(act), 1.0 / (FN_A_SCALE * FN_W_SCALE),
-                            FN_A_SCALE, *cargs, _ptr(stats), zeros.data_ptr(), _ptr(a_rows), _ptr(out_rows), _stream())
+                            FN_A_SCALE, *cargs, _ptr(stats), zeros.data_ptr(), _ptr(a_rows), _ptr(out_rows),
+                            _fn_flag_ptr(dev), _stream())
     _lib.check(rc, "fresco_fn_gemm(M=%d,N=%d,K=%d,conv=%s)" % (M, N, K, conv))
     res = (out, ((oh, ol) if oh is not None else None))
     if instance_norm_eps is None:
@@ -359,6 +419,7 @@ def fn_layernorm(x, gamma, beta, residual=None, eps=1e-5, want_f32=True, want_sp
     _need_gpu(x)
     x = _f32c(x)
     M, C = x.shape
+    gamma, beta, residual = (_fn_f32_operand(t, n_, x) for t, n_ in ((gamma, "gamma"), (beta, "beta"), (residual, "residual")))
     y = torch.empty_like(x) if want_f32 else None
     oh = ol = None
     ldo = C
@@ -368,7 +429,8 @@ def fn_layernorm(x, gamma, beta, residual=None, eps=1e-5, want_f32=True, want_sp
         oh = torch.empty(M, C, dtype=torch.float16, device=x.device)
         ol = torch.empty(M, C, dtype=torch.float16, device=x.device)
     rc = _lib.load().fresco_fn_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(residual), _ptr(y), _ptr(oh),
-                                         _ptr(ol), C, int(ldo), M, C, float(eps), FN_A_SCALE, _stream())
+                                         _ptr(ol), C, int(ldo), M, C, float(eps), FN_A_SCALE, _fn_flag_ptr(x.device),
+                                         _stream())
     _lib.check(rc, "fresco_fn_layernorm(M=%d,C=%d)" % (M, C))
     return y, ((oh, ol) if oh is not None else None)
 
@@ -669,12 +731,16 @@ def opt_run(cs, prep, target, intra_weight, iters, chunk, lr=0.2, betas=(0.9, 0.
 
 def opt_run_sharded(cs, prep_pairs, target, intra_weight, iters, chunk, N_total, exchange, lr=0.2,
                     betas=(0.9, 0.999), eps=1e-8, workspace=None):
-    """Frame-sharded optimize_feature loop (fresco_opt_sharded_begin / _step).
+    """Frame-sharded optimize_feature loop (fresco_opt_sharded_begin / _step_part).
 
     cs: local (chunk*n_loc, C, h, w) fp32 contiguous, updated in place.
     prep_pairs = (fwd_flow, bwd_flow, fwd_occ, bwd_occ) for the n_loc+1 local frame pairs, or None.
-    exchange(cs) -> (halo_l, halo_r): current frame before / after the owned range, (chunk, C, h, w) each;
-    called before every step (it is where the inter-GPU traffic happens)."""
+    exchange: where the inter-GPU traffic happens.  Either an object with `halo_start(cs) -> handle` and
+    `halo_finish(handle) -> (halo_l, halo_r)` (fresco_amd.dist.FrameShard): the exchange of the frames Adam(it-1) left
+    behind is started, the launches of step `it` that read no halo frame run (part 1), then the halos are waited for and
+    the boundary pairs' signs + Adam follow (part 2).  Or a plain callable `exchange(cs) -> (halo_l, halo_r)` (blocking,
+    called before every undivided step).  halo_l / halo_r: the current frame before / after the owned range,
+    (chunk, C, h, w) each.  Both forms give identical bits."""
     _need_gpu(cs)
     assert cs.dtype == torch.float32 and cs.is_contiguous()
     Bt, C, h, w = cs.shape
@@ -693,16 +759,28 @@ def opt_run_sharded(cs, prep_pairs, target, intra_weight, iters, chunk, N_total,
     rc = lib.fresco_opt_sharded_begin(_ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]), ws.data_ptr(),
                                       ws.numel(), chunk, n_loc, N_total, C, h, w, has_s, _stream())
     _lib.check(rc, "fresco_opt_sharded_begin")
+    overlapped = hasattr(exchange, "halo_start") and hasattr(exchange, "halo_finish")
+
+    def step(it, halo_l, halo_r, part):
+        rc = lib.fresco_opt_sharded_step_part(cs.data_ptr(), _ptr(halo_l), _ptr(halo_r), _ptr(keep[0]), _ptr(keep[1]),
+                                              _ptr(keep[2]), _ptr(keep[3]), _ptr(target), ws.data_ptr(), ws.numel(),
+                                              chunk, n_loc, N_total, C, h, w, float(intra_weight), it, float(lr),
+                                              float(betas[0]), float(betas[1]), float(eps), part, _stream())
+        _lib.check(rc, "fresco_opt_sharded_step_part(it=%d, part=%d)" % (it, part))
+
     for it in range(1, iters + 1):
-        halo_l = halo_r = None
-        if has_t:
+        if not has_t:
+            step(it, None, None, 3)
+        elif overlapped:
+            handle = exchange.halo_start(cs)           # asynchronous: the frames Adam(it-1) produced
+            step(it, None, None, 1)                    # normalise, interior signs, Gram, S V: under the transfer
+            halo_l, halo_r = exchange.halo_finish(handle)
+            halo_l, halo_r = _f32c(halo_l), _f32c(halo_r)
+            step(it, halo_l, halo_r, 2)                # boundary signs + Adam
+        else:
             halo_l, halo_r = exchange(cs)
             halo_l, halo_r = _f32c(halo_l), _f32c(halo_r)
-        rc = lib.fresco_opt_sharded_step(cs.data_ptr(), _ptr(halo_l), _ptr(halo_r), _ptr(keep[0]), _ptr(keep[1]),
-                                         _ptr(keep[2]), _ptr(keep[3]), _ptr(target), ws.data_ptr(), ws.numel(),
-                                         chunk, n_loc, N_total, C, h, w, float(intra_weight), it, float(lr),
-                                         float(betas[0]), float(betas[1]), float(eps), _stream())
-        _lib.check(rc, "fresco_opt_sharded_step(it=%d)" % it)
+            step(it, halo_l, halo_r, 3)
     return cs
 
 

@@ -40,8 +40,11 @@ def optimize_feature(sample, flows, occs, correlation_matrix=[], intra_weight=1e
         if prep is not None:
             idx = torch.tensor(shard.pair_index(), device=cs.device)
             prep = tuple(t.index_select(0, idx) for t in prep)
+        # (an object with halo_start / halo_finish gets the overlapped neighbour exchange; anything else that offers
+        # exchange_halos the blocking form)
+        exch = shard if hasattr(shard, "halo_start") else shard.exchange_halos
         ops.opt_run_sharded(cs, prep, target, float(intra_weight), int(iters), unet_chunk_size, shard.N,
-                            shard.exchange_halos, workspace=_workspace)
+                            exch, workspace=_workspace)
     else:
         ops.opt_run(cs, prep, target, float(intra_weight), int(iters), unet_chunk_size, workspace=_workspace)
     return adaptive_instance_normalization(cs.to(sample.dtype), sample)

@@ -23,17 +23,37 @@ def flow_warp(feature, flow, mask=False, padding_mode="zeros"):
 _derived = {}
 
 
+def _version_of(t):
+    """autograd version counter, or None when the tensor does not track one (torch.inference_mode tensors raise)"""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def _cached(kind, srcs, extra, build):
     import weakref
-    key = (kind, extra) + tuple((t.data_ptr(), tuple(t.shape), t._version, str(t.device)) for t in srcs)
+    vers = [_version_of(t) for t in srcs]
+    if any(v is None for v in vers):
+        return build()  # inference tensors: an in-place update would be invisible -> never cached
+    key = (kind, extra) + tuple((t.data_ptr(), tuple(t.shape), v, str(t.device)) for t, v in zip(srcs, vers))
     hit = _derived.get(key)
     if hit is not None and all(r() is t for r, t in zip(hit[0], srcs)):
         return hit[1]
+    # a miss: entries whose source tensors have died release their GPU tensors now, not when 33 have piled up
+    for k in [k for k, (refs, _) in _derived.items() if any(r() is None for r in refs)]:
+        del _derived[k]
     if len(_derived) > 32:
         _derived.clear()
     val = build()
     _derived[key] = ([weakref.ref(t) for t in srcs], val)
     return val
+
+
+def invalidate_cache():
+    """drop every cached derived tensor (resized flows, pooled occlusions, warped saliency).  Needed only after a
+    `t.data.copy_()`-style update of a flow / occlusion / saliency tensor, which does not bump its version counter."""
+    _derived.clear()
 
 
 def _prep_flow_occ(h, flows, occs, with_dilate):

@@ -228,7 +228,9 @@ int fresco_attn_f32_guarded(const float* q, const float* k, const float* v, floa
  * producer (fresco_fn_prep / fresco_fn_layernorm / fresco_fn_gemm's epilogue); products are hi hi + hi lo + lo hi.
  * The planes hold x * split_scale (a power of two: the matrix pipe flushes fp16 subnormals, so lo pieces must stay normal
  * numbers; fresco_amd uses 2^6 for activations, |x| < 1000, and 2^10 for weights, |w| < 60; beyond that the scaled value
- * saturates); fresco_fn_gemm multiplies its fp32 accumulators by acc_scale = 1 / (scale_A * scale_W) before the bias.
+ * saturates -- finite, wrong -- and the producer ORs 1 into the caller's `range_flag` word (int32 in device memory, cleared
+ * by the caller, may be NULL): fresco_amd's flow network checks it once per forward and recomputes with library ops);
+ * fresco_fn_gemm multiplies its fp32 accumulators by acc_scale = 1 / (scale_A * scale_W) before the bias.
  * Activations are NHWC: rows m = (image, y, x), channels contiguous -- the transformer's (B, L, C) token layout. */
 
 /* out[m][n] = act( sum_k A(m, k) W[n][k] + bias[n] ),  m < M, n < N, K % 32 == 0.
@@ -246,7 +248,8 @@ int fresco_attn_f32_guarded(const float* q, const float* k, const float* v, floa
 int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, const void* w_hi, const void* w_lo, const float* bias,
                    float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M, int N, int K, int act,
                    float acc_scale, float split_scale, int n_img, int H, int W, int kh, int kw, int stride, int pad,
-                   void* stats, const void* zeros, const int32_t* a_rows, const int32_t* out_rows, void* stream);
+                   void* stats, const void* zeros, const int32_t* a_rows, const int32_t* out_rows, int32_t* range_flag,
+                   void* stream);
 
 /* nn.InstanceNorm2d statistics (affine=False, biased variance): x (n_img * rows, C) fp32 NHWC -> mean, rstd = 1 / sqrt(var +
  * eps), (n_img, C) each.  fp64 partial sums in a fixed order.  C <= 256. */
@@ -260,12 +263,13 @@ int fresco_fn_colstats_finish(const void* stats, float* mean, float* rstd, int n
  * C .. ldo-1 zeroed (K padding of the product that reads them).  C % 4 == 0, ldo % 4 == 0. */
 int fresco_fn_prep(const float* x, const float* mean, const float* rstd, const float* residual, float* y, void* out_hi,
                    void* out_lo, int64_t M, int C, int ldo, int rows_per_img, int relu_a, int relu_b, float split_scale,
-                   void* stream);
+                   int32_t* range_flag, void* stream);
 
 /* nn.LayerNorm(128) (+ residual): y = residual + ((x - mean) / sqrt(var + eps)) gamma + beta on (M, 128) fp32 rows; fp32 y
  * (row stride ldy) and / or fp16 planes (row stride ldo). */
 int fresco_fn_layernorm(const float* x, const float* gamma, const float* beta, const float* residual, float* y, void* out_hi,
-                        void* out_lo, int64_t ldy, int64_t ldo, int64_t M, int C, float eps, float split_scale, void* stream);
+                        void* out_lo, int64_t ldy, int64_t ldo, int64_t M, int C, float eps, float split_scale,
+                        int32_t* range_flag, void* stream);
 
 /* The encoder's stem: Conv2d(3, 64, 7, stride 2, padding 3, bias=False), direct fp32 FMAs.  x (n_img, H, W, 3) NHWC,
  * w (7, 7, 3, 64) = weight.permute(2, 3, 1, 0), out (n_img, OH, OW, 64) NHWC. */
@@ -371,6 +375,19 @@ int fresco_opt_sharded_step(float* cs, const float* halo_l, const float* halo_r,
                             size_t workspace_bytes, int chunk, int n_loc, int N_total, int C, int h, int w,
                             float intra_weight, int it, float lr, float beta1, float beta2, float eps,
                             void* stream);
+/* The same step in two host calls, so that the neighbour exchange of the halo frames can run UNDER the launches that do
+ * not read them.  part = 1: normalisation, the residual signs of the interior pairs, Gram and S V products (halo_l /
+ * halo_r are not read and may be NULL); part = 2: the residual signs of the two pairs that touch a halo frame, then
+ * Adam (halos required); part = 3: both = fresco_opt_sharded_step.  Part 1 followed by part 2 performs, per element,
+ * exactly the operations of the undivided step: results are identical bit for bit.  Typical loop of a rank:
+ * start the (asynchronous) exchange of the frames Adam(it-1) produced -> part 1 of step it -> wait for the halos ->
+ * part 2 of step it. */
+int fresco_opt_sharded_step_part(float* cs, const float* halo_l, const float* halo_r,
+                                 const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                                 const float* bwd_occ, const float* target, void* workspace,
+                                 size_t workspace_bytes, int chunk, int n_loc, int N_total, int C, int h, int w,
+                                 float intra_weight, int it, float lr, float beta1, float beta2, float eps,
+                                 int part, void* stream);
 
 /* Gram target of get_intraframe_paras (DH:889-895): T[b] = V V^T, V = rows of x (B,C,h,w)
  * viewed as (B, hw, C) and L2-normalised; fp32 (B,hw,hw).  workspace: B*C*hw + 33*B*hw floats

@@ -109,6 +109,74 @@ def _worker(rank, world, port, N, chunk, HW, C, ret):
         dist.destroy_process_group()
 
 
+def _halo_worker(rank, world, port, N, chunk, ret):
+    """Neighbour-only halo exchange of optimize_feature's temporal term, in the loop form the sharded optimiser uses:
+    start (asynchronous) -> local work -> finish -> boundary work, over several iterations of a stand-in update in which
+    every frame mixes with its ring neighbours (what the temporal L1 term does to the dependencies)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fresco_amd.dist import FrameShard
+
+        g = torch.Generator().manual_seed(5)
+        C, h, w = 3, 4, 5
+        X = torch.randn(chunk * N, C, h, w, generator=g)
+        sh = FrameShard(N, chunk, rank, world)
+        sel = sh.local_batch_index()
+        slab = chunk * C * h * w * 4
+        ok = True
+        # single-process run of the stand-in loop (every rank can afford it)
+        ref = X.clone().view(chunk, N, C, h, w)
+        for it in range(3):
+            ref = ref + 0.25 * torch.roll(ref, 1, 1) - 0.5 * torch.roll(ref, -1, 1)
+        cs = X[sel].contiguous()
+        n_loc = sh.n_loc
+        for it in range(3):
+            before = getattr(sh, "halo_bytes_received", 0)
+            hnd = sh.halo_start(cs)
+            local = cs.clone()                                   # (stands for the launches that read no halo frame)
+            hl, hr = sh.halo_finish(hnd)
+            got = sh.halo_bytes_received - before
+            single = n_loc == 1 and world == 2
+            # what crossed the fabric into this rank: two slabs (one when a single frame serves both sides), not 2 * world
+            ok &= got == (slab if single else 2 * slab)
+            Xg = None
+            x = local.view(chunk, n_loc, C, h, w)
+            prev = torch.cat((hl.unsqueeze(1), x[:, :-1]), 1)    # frame f-1 of every local frame
+            nxt = torch.cat((x[:, 1:], hr.unsqueeze(1)), 1)      # frame f+1
+            cs = (x + 0.25 * prev - 0.5 * nxt).reshape(chunk * n_loc, C, h, w).contiguous()
+        ok &= torch.equal(cs, ref.reshape(chunk * N, C, h, w)[sel])  # exactly the single-process result
+        ok &= sh.halo_exchanges == 3
+        # the blocking form returns the same frames
+        hl, hr = sh.exchange_halos(X[sel].contiguous())
+        Xg = X.view(chunk, N, C, h, w)
+        ok &= torch.equal(hl, Xg[:, (sh.f0 - 1) % N]) and torch.equal(hr, Xg[:, (sh.f0 + sh.n_loc) % N])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N", [(2, 2), (2, 4), (4, 4), (4, 8)])
+def test_halo_neighbour_exchange_gloo(world, N):
+    """2 slabs received per Adam iteration whatever the world size (1 when n_loc = 1 on two ranks), results equal to the
+    single-process loop exactly"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_halo_worker, args=(world, _free_port(), N, 2, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_halo_ring_of_one_rank():
+    from fresco_amd.dist import FrameShard
+
+    sh = FrameShard(4, 2, 0, 1)
+    X = torch.randn(8, 3, 4, 5)
+    hl, hr = sh.exchange_halos(X)
+    Xg = X.view(2, 4, 3, 4, 5)
+    assert torch.equal(hl, Xg[:, 3]) and torch.equal(hr, Xg[:, 0]) and getattr(sh, "halo_bytes_received", 0) == 0
+
+
 @pytest.mark.parametrize("N,chunk", [(4, 2), (6, 2)])
 def test_frame_shard_gather_and_remap_gloo(N, chunk):
     world = 2

@@ -192,3 +192,37 @@ def test_gmflow_unidirectional_equals_first_half_of_bidirectional():
     one = m(imgs, imgs[nxt], **kw)["flow_preds"][-1]
     assert tuple(one.shape) == (N, 2, H, W) and tuple(both.shape) == (2 * N, 2, H, W)
     assert float(_epe(one, both[:N]).max()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_gmflow_out_of_range_operands_fall_back_to_library_ops(monkeypatch):
+    """the native dense layers hold operands as fp16 planes of x * 2^6 / w * 2^10; a weight beyond +-63 or an
+    activation beyond +-1015 saturates there (finite, wrong).  The forward must notice (device-side range word, one read per
+    forward), warn, and return what the library-ops path returns -- like the attention kernel's guarded entry does."""
+    import warnings
+    m, _ = _model("cuda")
+    N, H, W = CASES["b"]
+    imgs = cf.gmflow_frames(N, H, W).cuda()
+    nxt = list(range(1, N)) + [0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # in range: no warning
+        base = m(imgs, imgs[nxt], **KW)["flow_preds"][-1]
+    # (a) a weight beyond the plane range: one FFN weight of the first transformer block
+    lin = m.transformer.layers[0].cross_attn_ffn.mlp[0]
+    with torch.no_grad():
+        lin.weight[0, 0] = 100.0
+    with pytest.warns(RuntimeWarning, match="left the range"):
+        got = m(imgs, imgs[nxt], **KW)["flow_preds"][-1]
+    monkeypatch.setenv("FRESCO_GMFLOW_LIBRARY_OPS", "1")
+    want = m(imgs, imgs[nxt], **KW)["flow_preds"][-1]
+    monkeypatch.delenv("FRESCO_GMFLOW_LIBRARY_OPS")
+    assert torch.equal(got, want) and bool(torch.isfinite(got).all())
+    # (b) in-range weights, an out-of-range ACTIVATION: the FFN's hidden layer (no norm in front of the second product)
+    with torch.no_grad():
+        lin.weight[0, 0] = base.new_tensor(0.0)
+        lin.weight[1] *= 2000.0 / float(lin.weight[1].abs().max()) * 0.03   # |w| <= 60: in range; hidden unit 1 ~ 1e3 .. 1e4
+    with pytest.warns(RuntimeWarning, match="left the range"):
+        got = m(imgs, imgs[nxt], **KW)["flow_preds"][-1]
+    monkeypatch.setenv("FRESCO_GMFLOW_LIBRARY_OPS", "1")
+    want = m(imgs, imgs[nxt], **KW)["flow_preds"][-1]
+    assert torch.equal(got, want)

@@ -161,3 +161,76 @@ def test_fn_gemm_row_tables():
     _, sp = ops.fn_gemm(xs, ws, N, K, out_rows=t, want_f32=False, want_split=True)
     rec = (sp[0].float() + sp[1].float()) / ops.FN_A_SCALE
     assert float((rec.cpu().double() - back).abs().max()) < bar + 2 ** -20 * float(back.abs().max())
+
+
+def test_fn_range_flag_is_raised_by_every_producer():
+    """the (hi, lo) planes hold x * 2^6 (weights: w * 2^10) and saturate at 65000 -- finite, wrong.  Every
+    producer (fn_prep, fn_layernorm, the GEMM epilogue) must say so through the range word of the enclosing guard, and must
+    NOT raise it for in-range operands."""
+    import fresco_amd.ops as ops
+    g = synth.gen(77)
+    x = (torch.randn(256, 128, generator=g) * 3.0).to(DEV)
+    w = (torch.randn(128, 128, generator=g) * 0.05).to(DEV)
+    gam, bet = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    with ops.fn_range_guard(x.device) as ok:
+        _, xs = ops.fn_prep(x)
+        _, ws = ops.fn_prep(w, scale=ops.FN_W_SCALE)
+        ops.fn_gemm(xs, ws, 128, 128, want_split=True)
+        ops.fn_layernorm(x, gam, bet, want_split=True)
+    assert not ok.tripped()
+    big = x.clone()
+    big[17, 5] = 1016.0                                   # 1016 * 64 = 65024 > 65000
+    with ops.fn_range_guard(x.device) as g1:
+        ops.fn_prep(big)
+    assert g1.tripped()
+    with ops.fn_range_guard(x.device) as g1b:             # (no planes requested: nothing is split, nothing can saturate)
+        ops.fn_prep(big, want_f32=True, want_split=False)
+    assert not g1b.tripped()
+    wbig = w.clone()
+    wbig[3, 3] = -64.0                                    # 64 * 1024 = 65536
+    with ops.fn_range_guard(x.device) as g2:
+        ops.fn_prep(wbig, scale=ops.FN_W_SCALE)
+    assert g2.tripped()
+    with ops.fn_range_guard(x.device) as g3:              # in-range operands, out-of-range RESULT planes (30 * 128 * 0.5 = 1920)
+        _, xs3 = ops.fn_prep(torch.full((256, 128), 30.0, device=DEV))
+        _, ws3 = ops.fn_prep(torch.full((128, 128), 0.5, device=DEV), scale=ops.FN_W_SCALE)
+        assert not g3.tripped()
+        out, _ = ops.fn_gemm(xs3, ws3, 128, 128, want_split=True)
+    assert g3.tripped() and abs(float(out[0, 0]) - 1920.0) < 1e-2   # (the fp32 result itself is exact: only the planes clamp)
+    with ops.fn_range_guard(x.device) as g4:
+        ops.fn_gemm(xs3, ws3, 128, 128, want_split=False)            # fp32 output only: no planes, no flag
+    assert not g4.tripped()
+    with ops.fn_range_guard(x.device) as g5:
+        ops.fn_layernorm(x, gam * 500.0, bet, want_split=True)       # LayerNorm output ~ N(0, 1) * 500 reaches 1015
+    assert g5.tripped()
+    with ops.fn_range_guard(x.device) as g6:                         # a NaN is out of range too
+        bad = x.clone()
+        bad[0, 0] = float("nan")
+        ops.fn_prep(bad)
+    assert g6.tripped()
+
+
+def test_fn_side_operands_are_checked():
+    """bias / gamma / beta / mean / rstd / residual are read as raw fp32 words by the kernels -- a .half() or
+    strided tensor is converted on the way in, a table of the wrong dtype is refused"""
+    import fresco_amd.ops as ops
+    g = synth.gen(5)
+    x = torch.randn(64, 128, generator=g).to(DEV)
+    w = (torch.randn(128, 128, generator=g) * 0.05).to(DEV)
+    b = torch.randn(128, generator=g).to(DEV)
+    _, xs = ops.fn_prep(x)
+    _, ws = ops.fn_prep(w, scale=ops.FN_W_SCALE)
+    ref, _ = ops.fn_gemm(xs, ws, 128, 128, bias=b)
+    half_bias, _ = ops.fn_gemm(xs, ws, 128, 128, bias=b.half())
+    assert float((half_bias - ref).abs().max()) < 2e-3              # (fp16 rounding of the bias, not garbage)
+    strided = torch.stack((b, b), 1)[:, 0]
+    got, _ = ops.fn_gemm(xs, ws, 128, 128, bias=strided)
+    assert torch.equal(got, ref)
+    res = torch.randn(64, 256, generator=g).to(DEV)[:, ::2]          # non-contiguous residual
+    y1, _ = ops.fn_layernorm(x, torch.ones(128, device=DEV).half(), torch.zeros(128, device=DEV), residual=res)
+    y2, _ = ops.fn_layernorm(x, torch.ones(128, device=DEV), torch.zeros(128, device=DEV), residual=res.contiguous())
+    assert torch.equal(y1, y2)
+    with pytest.raises(ValueError):
+        ops.fn_gemm(xs, ws, 128, 128, a_rows=torch.arange(64, device=DEV))           # int64 table
+    with pytest.raises(ValueError):
+        ops.fn_gemm(xs, ws, 128, 128, bias=b.cpu())

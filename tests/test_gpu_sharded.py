@@ -56,6 +56,27 @@ class ThreadShard:
         from fresco_amd.dist import FrameShard
         return FrameShard.exchange_cf(self, kv_loc, plan)
 
+    # neighbour-only halo exchange of optimize_feature (dist.FrameShard.neighbour_exchange, emulated)
+    def neighbour_exchange(self, to_left, to_right, from_left, from_right):
+        got = self._exchange((to_left, to_right))
+        left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        from_left.copy_(got[left][1])           # what the left neighbour sent to ITS right
+        if to_left is not None:
+            from_right.copy_(got[right][0])     # what the right neighbour sent to its left
+        return []
+
+    def halo_start(self, cs):
+        from fresco_amd.dist import FrameShard
+        return FrameShard.halo_start(self, cs)
+
+    def halo_finish(self, handle):
+        from fresco_amd.dist import FrameShard
+        return FrameShard.halo_finish(self, handle)
+
+    def exchange_halos(self, cs):
+        from fresco_amd.dist import FrameShard
+        return FrameShard.exchange_halos(self, cs)
+
     def temporal(self, *a):
         from fresco_amd.dist import FrameShard
         return FrameShard.temporal(self, *a)
@@ -113,11 +134,13 @@ def test_sharded_processor_equals_single_gpu(world, N, keep, mode):
         assert d < 5e-4, (world, mode, d)
 
 
+@pytest.mark.parametrize("overlapped", [True, False])
 @pytest.mark.parametrize("world", [1, 2, 4])
-def test_sharded_optimize_feature_equals_single_gpu(world):
-    """frame-sharded optimize_feature (halo exchange every Adam step) == the single-GPU loop.  Same kernels,
-    same summation orders -> the raw optimised features agree exactly (checked through the public function,
-    i.e. after AdaIN, to a rounding-level tolerance)."""
+def test_sharded_optimize_feature_equals_single_gpu(world, overlapped):
+    """frame-sharded optimize_feature (neighbour-only halo exchange every Adam step) == the single-GPU loop.  Same
+    kernels, same summation orders -> the optimised features agree EXACTLY, in the overlapped two-part form (exchange
+    under the launches that read no halo frame) and in the blocking undivided form; a rank receives two slabs per
+    iteration whatever the world size."""
     import fresco_amd
     from fresco_amd.dist import FrameShard
 
@@ -138,13 +161,21 @@ def test_sharded_optimize_feature_equals_single_gpu(world):
         try:
             base = FrameShard(N, chunk, r, world)
             sh = ThreadShard(base, slots, barrier)
-            sh.exchange_halos = lambda cs: FrameShard.exchange_halos(sh, cs)
             sh.pair_index = base.pair_index
+            if not overlapped:  # an exchange object without halo_start: the blocking, undivided step
+                class Blocking:
+                    N = sh.N
+                    pair_index = staticmethod(base.pair_index)
+                    exchange_halos = staticmethod(sh.exchange_halos)
+                shard_arg = Blocking()
+            else:
+                shard_arg = sh
             sel = base.local_batch_index().to(DEV)
             # every emulated rank needs its own scratch (real ranks are separate processes)
             outs[r] = (sel, fresco_amd.optimize_feature(x.index_select(0, sel).contiguous(), flows, occs,
                                                         [target.index_select(0, sel).contiguous()], iters=4,
-                                                        shard=sh, _workspace=fresco_amd.ops.Workspace()))
+                                                        shard=shard_arg, _workspace=fresco_amd.ops.Workspace()),
+                       getattr(sh, "halo_bytes_received", 0), getattr(sh, "halo_exchanges", 0))
         except Exception as e:  # pragma: no cover
             errs.append(e)
             barrier.abort()
@@ -154,9 +185,10 @@ def test_sharded_optimize_feature_equals_single_gpu(world):
     [t.join() for t in ts]
     assert not errs, errs
     torch.cuda.synchronize()
-    for sel, o in outs:
-        d = float((o - ref.index_select(0, sel)).abs().max())
-        assert d < 1e-5, (world, d)
+    slab = chunk * x.shape[1] * x.shape[2] * x.shape[3] * 4
+    for sel, o, nbytes, nex in outs:
+        assert torch.equal(o, ref.index_select(0, sel)), (world, float((o - ref.index_select(0, sel)).abs().max()))
+        assert nex == (0 if world == 1 else 4) and nbytes == (0 if world == 1 else 4 * 2 * slab), (world, nex, nbytes, slab)
 
 
 def test_sharded_warp_tensor_replicas():

@@ -77,6 +77,7 @@ def measure(iters=20, N=8, R=512, dev="cuda", verbose=False, baselines=True, rep
     total = 0.0
     per_layer, kern, torch_ms, cpu_ms = [], {}, [], []
     per_layer_stats, total_median = [], 0.0
+    miss_extra = []
     for C, h in LAYERS:
         hw = h * h
         x = torch.randn(2 * N, C, h, h, generator=g).half().to(dev)
@@ -99,6 +100,18 @@ def measure(iters=20, N=8, R=512, dev="cuda", verbose=False, baselines=True, rep
                                     max=round(1e3 * max(kept), 3), runs=[round(1e3 * t, 3) for t in kept]))
         total += mean
         total_median += med
+        # The timed runs above hit fresco_amd.warp's cache of the tensors derived from flows / occlusions / saliency (resized
+        # flows, pooled + dilated occlusions, warped saliency): constants of a batch of frames, which the pipeline computes
+        # once per layer and batch and reuses over its 10 - 15 optimised steps.  One more call with the cache emptied (warm
+        # allocator) gives the cost of that miss; the line carries it separately and amortised over 10 steps.
+        from fresco_amd import warp as _warp
+        _warp.invalidate_cache()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fresco_amd.optimize_feature(x, flows, occs, [tgt], iters=iters)
+        fresco_amd.warp_tensor(out, flows, occs, sal, 2)
+        torch.cuda.synchronize()
+        miss_extra.append(max(0.0, 1e3 * ((time.perf_counter() - t0) - med)))
         # instrumented run: per-kernel means
         lib.fresco_prof_enable(4096)
         fresco_amd.optimize_feature(x, flows, occs, [tgt], iters=iters)
@@ -166,7 +179,14 @@ def measure(iters=20, N=8, R=512, dev="cuda", verbose=False, baselines=True, rep
     res = dict(ms_per_step=round(1e3 * total, 2), per_layer_ms=per_layer, ms_per_step_median=round(1e3 * total_median, 2),
                per_layer_stats=per_layer_stats,
                timing="1 warm-up + %d timed runs per layer; ms_per_step / per_layer_ms = mean of ALL %d (nothing dropped); median, "
-                      "min, max and every run in per_layer_stats" % (reps, reps),
+                      "min, max and every run in per_layer_stats.  The timed runs find the flow / occlusion / saliency-derived "
+                      "tensors in fresco_amd.warp's per-batch cache (as steps 2.. of a keyframe batch do); the cost of a miss is "
+                      "derived_tensor_miss_ms" % (reps, reps),
+               derived_tensor_miss_ms=dict(per_layer=[round(v, 3) for v in miss_extra], total=round(sum(miss_extra), 3),
+                                           ms_per_step_with_miss_amortised_over_10_steps=round(1e3 * total + sum(miss_extra) / 10.0, 2),
+                                           note="extra time of one call per layer with the cache emptied (resize / max-pool / "
+                                                "dilate / saliency warps); paid once per batch of frames and layer; rounds 1-4 "
+                                                "paid it on every call"),
                workload="cfg3 extra work per denoising step: optimize_feature (%d Adam iterations, intra_weight 100) + "
                         "feature-space warp_tensor at the inputs of the four up-blocks, %d frames %dx%d" % (iters, N, R, R),
                roofline=_dominant_roofline(kern),
