@@ -399,7 +399,34 @@ def timed_workload(N, R, device, shard_args, steps, warmup, barrier, max_over_ra
             run_step(proc, ctrl, layers, SCHEDULE[s % len(SCHEDULE)], refs, paras, masks)
         barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    # parity beside the timing (one GPU): the leg's own up_blocks.3 / up_blocks.2 calls at the FULL batch (B = 2N) against the
+    # reference's op sequence on the same tensors (oracle/torch_path.py: checker only, after the timed region)
+    parity = None
+    if shard is None:
+        try:
+            from oracle import torch_path as TP
+            parity = {}
+            with torch.no_grad():
+                for mode in ("cf_temporal", "cf"):
+                    set_mode(ctrl, mode, refs, paras, masks)
+                    for l in (layers[0], layers[3]):
+                        a = l["attn"]
+                        fwd, _, tm, cfm = params[l["down"]]
+                        kw = dict(use_cf=True, cf_mask=cfm.to(device))
+                        if mode == "cf_temporal":
+                            kw.update(fwd_map=fwd[:, 0].to(device), tmask=tm[:, 0].to(device))
+                        ours = proc(a, l["hidden_local"])
+                        want = TP.processor_call(l["hidden"], a.to_q.weight, a.to_k.weight, a.to_v.weight, a.to_out[0].weight,
+                                                 a.to_out[0].bias, 8, **kw)
+                        parity["%s/%s" % ("L2" if l["down"] == 16 else "L3", mode)] = round(
+                            float((ours.float() - want.float()).abs().max()), 6)
+                        del ours, want
+            parity = dict(max_abs_delta=max(parity.values()), per_call=parity, bar=1e-3,
+                          note="|ours - the reference's op sequence| on the fp16 outputs of the leg's own calls at B = %d" % (2 * N))
+        except Exception as e:  # noqa: BLE001 -- recorded, not fatal
+            parity = dict(error="%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else ""))
     return dict(workload="cfg5's batch (BASELINE.json configs[4]): %d frames %dx%d, %s" % (N, R, R, "frame-sharded" if shard is not None else "one GPU"),
+                parity=parity,
                 steps=steps, value=round(steps / dt, 3), unit="denoising-steps/sec", ms_per_step=round(1e3 * dt / steps, 4),
                 scaling="strong",
                 note="companion of `value` on the batch whose per-frame work is 16x config 2's; the same leg runs at every "

@@ -38,6 +38,8 @@ SIGNATURES = {
     "fresco_attn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fresco_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i64, _f, _f, _vp]),
     "fresco_attn_fwd_ld": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i64, _f, _f, _i64, _i64, _vp]),
+    "fresco_attn_kvproj_supported": (_i, [_i, _i, _i]),
+    "fresco_attn_fwd_kvproj": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _f, _i64, _vp]),
     "fresco_temporal_attn_ld": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i64, _i64, _i64, _vp]),
     "fresco_temporal_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "fresco_temporal_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),

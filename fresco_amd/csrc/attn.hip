@@ -152,6 +152,200 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const half_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// kvproj_pack (round 6): the K | V projection of the SELECTED rows and the pack in ONE launch, for layer calls whose only
+// reader of K and V is the cross-frame pass (cross-frame-only steps: 7 of the 15 of the schedule).  Before: fresco_linear_rows
+// (K | V of the 2 x M gathered hidden rows -> HBM, 15 - 18 us) then kv_pack_kernel (gather again, transpose, pad -> image,
+// 9 - 13 us), two latency-bound launches in front of the flash kernel.  Here a workgroup owns one 64-key tile of one CFG
+// half and 160 output features of K and of V (4 heads at D = 40, 2 at D = 80): the 64 gathered hidden rows are staged in
+// LDS once (odd 16-byte row stride: conflict-free fragment reads), each of the 5 waves streams its 32 weight rows of W_k
+// and of W_v straight from L2 into MFMA fragments (no LDS: nothing is shared between waves), and the accumulators ARE the
+// image's pieces -- K as C[feature][key] (A = W_k, B = x: a lane's 4 consecutive features of a key are 8 bytes of the
+// key's chunk), V^T as C[key][feature] (A = x, B = W_v: a lane's registers 8 kc' .. 8 kc' + 7 are the 8 keys of one
+// 16-byte V^T chunk, in the C-tile key order the flash kernel's PV product consumes).  The constant parts of the image
+// (ones column of K, ones row / zero rows of V^T) and max |k|^2 per (head, tile) are written alongside (partial sums per
+// 4 features in LDS, added in a fixed order: run-to-run identical).  K and V never exist in HBM.
+// Numerics: one fp32 accumulation chain per output in natural k order (linear_kernel: two chains, permuted k) -- the fp16
+// K / V values can differ from the two-launch path's in the last place; parity is against the oracle, as everywhere.
+// grid (nT, H*D/160, G), 320 threads.
+// ---------------------------------------------------------------------------------------------
+template <int KIN, int D>
+struct KvProjCfg {
+    static constexpr int ROWB = KIN * 2 + 16;  // LDS bytes per staged hidden row: an odd number of 16-byte chunks
+    static constexpr int HPW = 160 / D;        // heads per workgroup
+    static constexpr int NPART = D / 4;        // partial sums of |k|^2 per key and head (one per 4 features)
+    static constexpr int XS_BYTES = 64 * ROWB;
+    static constexpr int LDS_BYTES = XS_BYTES + HPW * NPART * 64 * 4 + 64 * 4;
+};
+
+template <int KIN, int D>
+__global__ __launch_bounds__(320, KIN == 320 ? 3 : 2) void kvproj_pack_kernel(const half_t* __restrict__ x, int64_t x_ld,
+                                                           const int32_t* __restrict__ x_rows,
+                                                           const half_t* __restrict__ Wk,
+                                                           const half_t* __restrict__ Wv, char* __restrict__ img,
+                                                           float* __restrict__ ktmax, int H, int M, int nT) {
+    using Cfg = AttnCfg<D>;
+    using PC = KvProjCfg<KIN, D>;
+    constexpr int ROWB = PC::ROWB, HPW = PC::HPW, NPART = PC::NPART;
+    constexpr int NKS = KIN / 16;         // MFMA k-steps
+    // k-steps per pipeline stage = one 128-byte line of every weight row: a lane (row, hi) takes the 64-byte half line
+    // [64 hi, 64 hi + 64) of the line as its fragments of the stage's four k-steps (the contraction order is free as long as
+    // the hidden-row fragments follow it) -- four back-to-back loads of one line, of which three hit in L1; with the natural
+    // order (16 bytes of every other 32) a line is touched by four instructions one pipeline step apart and has left the
+    // 32 KB L1 in between: weight loads 10 us of this launch's 24 (profiles/r06_kvproj_ablation.txt)
+    constexpr int SK = 4;
+    constexpr int NST = NKS / SK;
+    constexpr int CPR = KIN / 8;          // 16-byte chunks per hidden row
+    constexpr int NXL = 64 * CPR / 320;   // staging loads per thread
+    static_assert(NKS % SK == 0 && (64 * CPR) % 320 == 0 && 160 % D == 0 && D % 8 == 0, "shapes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem;
+    float* n2p = reinterpret_cast<float*>(smem + PC::XS_BYTES);
+    int32_t* rows = reinterpret_cast<int32_t*>(n2p + HPW * NPART * 64);
+    const int tile = blockIdx.x, fg = blockIdx.y, g = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    if (tid < 64) {
+        const int m = tile * 64 + tid;
+        rows[tid] = m < M ? x_rows[(int64_t)g * M + m] : -1;
+    }
+    const int ft = fg * 5 + wave;  // this wave's 32-feature tile of K and of V
+    const half_t* wkp = Wk + (int64_t)(ft * 32 + l31) * KIN + hi * 32;
+    const half_t* wvp = Wv + (int64_t)(ft * 32 + l31) * KIN + hi * 32;
+    // Software pipeline, one stage ahead: the weight fragments of stage s + 1 are requested before the products of stage s
+    // (hipcc on its own sinks every load to its use: load -> wait -> MFMA, one L2 round trip per k-step -- 28 us for this
+    // launch; the sched_barriers pin the batches).  Stage 0 is requested before the hidden rows are gathered.
+    half8_t fk[2][SK], fv[2][SK];
+    auto fetch = [&](int st, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SK; ++i) {
+            fk[buf][i] = *reinterpret_cast<const half8_t*>(wkp + st * 64 + i * 8);
+            fv[buf][i] = *reinterpret_cast<const half8_t*>(wvp + st * 64 + i * 8);
+        }
+    };
+#ifndef KVP_ABL
+#define KVP_ABL 0
+#endif
+    if (!(KVP_ABL & 2)) fetch(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // rows[]
+    {   // gather the 64 hidden rows into LDS: all of a thread's loads in flight, then its writes
+        uint4 xv[NXL];
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int c = tid + i * 320;
+            const int row = c / CPR, dc = c % CPR;
+            const int32_t r = rows[row];
+            xv[i] = make_uint4(0, 0, 0, 0);
+            if (r >= 0 && !(KVP_ABL & 4)) xv[i] = *reinterpret_cast<const uint4*>(x + (int64_t)r * x_ld + dc * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int c = tid + i * 320;
+            *reinterpret_cast<uint4*>(xs + (c / CPR) * ROWB + (c % CPR) * 16) = xv[i];
+        }
+    }
+    floatx16 ak[2], av[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ak[b][r] = av[b][r] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < NST && !(KVP_ABL & 2)) fetch(st + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SK; ++i) {
+            const int kb = (st * 64 + hi * 32 + i * 8) * 2;  // byte offset inside a staged row (same k order as the weights)
+            const half8_t x0 = *reinterpret_cast<const half8_t*>(xs + l31 * ROWB + kb);
+            const half8_t x1 = *reinterpret_cast<const half8_t*>(xs + (32 + l31) * ROWB + kb);
+            ak[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fk[buf][i], x0, ak[0], 0, 0, 0);
+            ak[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fk[buf][i], x1, ak[1], 0, 0, 0);
+            av[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, fv[buf][i], av[0], 0, 0, 0);
+            av[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, fv[buf][i], av[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((KVP_ABL & 1) && ak[0][0] + av[1][3] != 12345.f) return;  // (ablation: no epilogue)
+    // ---- K pieces: lane (key l31 of block b, hi), registers 4j .. 4j+3 = features 32 ft + 8 j + 4 hi + (0..3)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int key = b * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f0 = ft * 32 + 8 * j + 4 * hi;
+            const int head = f0 / D, dd = f0 - head * D;
+            half4_t w;
+            float n2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w[e] = (half_t)ak[b][4 * j + e];
+                n2 = fmaf((float)w[e], (float)w[e], n2);
+            }
+            char* dst = img + ((int64_t)(g * H + head) * (nT + 1) + tile) * Cfg::TILE;
+            *reinterpret_cast<half4_t*>(dst + ((dd >> 3) * 64 + key) * 16 + (dd & 7) * 2) = w;
+            n2p[((head - fg * HPW) * NPART + (dd >> 2)) * 64 + key] = n2;
+        }
+    }
+    // ---- V^T pieces: lane (feature 32 ft + l31, hi), registers 8 kc' .. 8 kc' + 7 = keys of chunk (kc = 2 b + kc', cc = hi)
+    {
+        const int f = ft * 32 + l31;
+        const int head = f / D, d = f - head * D;
+        char* dst = img + ((int64_t)(g * H + head) * (nT + 1) + tile + 1) * Cfg::TILE + Cfg::KTILE;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) {
+                half8_t w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (half_t)av[b][8 * kq + e];
+                *reinterpret_cast<half8_t*>(dst + (((2 * b + kq) * 2 + hi) * Cfg::DPV + d) * 16) = w;
+            }
+    }
+    // ---- constant parts of the image for this workgroup's heads
+    {
+        constexpr int KPAD = (Cfg::DPK - D) / 8;         // pad chunks of K per key (the first one carries the ones column)
+        constexpr int VPAD = Cfg::DPV - D;               // pad rows of V^T (the first one is all ones)
+        constexpr int PER_HEAD = KPAD * 64 + VPAD * 8;
+        for (int i = tid; i < HPW * PER_HEAD; i += 320) {
+            const int hl = i / PER_HEAD, c = i % PER_HEAD;
+            const int head = fg * HPW + hl;
+            char* base = img + ((int64_t)(g * H + head) * (nT + 1) + tile) * Cfg::TILE;
+            if (c < KPAD * 64) {
+                const int pc = c / 64, key = c % 64;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                if (Cfg::MCOL && pc == 0 && rows[key] >= 0) val.x = 0x3C00u;  // K[key][D] = 1.0 (running max rides in the QK MFMA)
+                *reinterpret_cast<uint4*>(base + ((D / 8 + pc) * 64 + key) * 16) = val;
+            } else {
+                const int c2 = c - KPAD * 64;
+                const int pr = c2 / 8, kcc = c2 % 8;     // pad row, (kc, cc) chunk
+                const int kc = kcc >> 1, cc = kcc & 1;
+                half8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int key = kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * cc;
+                    o[e] = (Cfg::ONES && pr == 0 && rows[key] >= 0) ? (half_t)1 : (half_t)0;
+                }
+                *reinterpret_cast<half8_t*>(base + Cfg::TILE + Cfg::KTILE + (kcc * Cfg::DPV + D + pr) * 16) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- max |k|^2 of the tile per head: parts added in a fixed order, maximum over the 64 keys
+    if (wave < HPW) {
+        float n2 = 0.f;
+#pragma unroll
+        for (int p_ = 0; p_ < NPART; ++p_) n2 += n2p[(wave * NPART + p_) * 64 + lane];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, off, 64));
+        if (lane == 0) ktmax[(int64_t)(g * H + fg * HPW + wave) * nT + tile] = n2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // flash attention: grid (H * nQblk * B), 512 threads = 8 waves x QB blocks of 32 query rows
 // blockIdx.x = (b * nQblk + qblk) * H + h   -> head h lands on XCD (h % 8): each XCD's L2 holds
 // only its own heads' packed key images.
@@ -684,6 +878,62 @@ extern "C" int fresco_attn_fwd_ld(const void* q, const void* k, const void* v, c
             return FRESCO_EUNSUPPORTED;
     }
 #undef FRESCO_ATTN_CASE
+}
+
+namespace fresco {
+template <int KIN, int D>
+static int launch_kvproj_attn(const half_t* q, const half_t* x, int64_t x_ld, const int32_t* x_rows, const half_t* Wk,
+                              const half_t* Wv, half_t* out, char* ws, int B, int H, int Lq, int n_groups, int M,
+                              float scale, int64_t q_ld, hipStream_t st) {
+    using Cfg = AttnCfg<D>;
+    const int nT = ntiles_of(M);
+    char* img = ws;
+    float* ktmax = reinterpret_cast<float*>(ws + align_up((size_t)n_groups * H * (nT + 1) * Cfg::TILE, 256));
+    {
+        ProfScope ps(FRESCO_PROF_KV_PACK, n_groups, H, M, -D, st);  // (d < 0: the fused projection + pack launch)
+        constexpr int lds = KvProjCfg<KIN, D>::LDS_BYTES;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_pack_kernel<KIN, D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((kvproj_pack_kernel<KIN, D>), dim3(nT, H * D / 160, n_groups), dim3(320), lds, st, x, x_ld, x_rows,
+                           Wk, Wv, img, ktmax, H, M, nT);
+    }
+    if constexpr (D <= 48 && Cfg::MCOL) {
+        const int grid2 = H * ((Lq + 511) / 512) * B;
+        if (Lq > 256 && grid2 < device_cus())
+            launch_flash<D, 1>(q, img, out, B, H, Lq, M, nT, n_groups, scale, 0.f, q_ld, ktmax, st);
+        else
+            launch_flash<D, 2>(q, img, out, B, H, Lq, M, nT, n_groups, scale, 0.f, q_ld, ktmax, st);
+    } else {
+        launch_flash<D, 1>(q, img, out, B, H, Lq, M, nT, n_groups, scale, 0.f, q_ld, ktmax, st);
+    }
+    return check_launch();
+}
+}  // namespace fresco
+
+extern "C" int fresco_attn_kvproj_supported(int H, int D, int K_in) {
+    return (H > 0 && (int64_t)H * D == K_in && ((D == 40 && K_in == 320) || (D == 80 && K_in == 640))) ? 1 : 0;
+}
+
+extern "C" int fresco_attn_fwd_kvproj(const void* q, const void* x, int64_t x_ld, const int32_t* x_rows, const void* Wk,
+                                      const void* Wv, void* out, void* workspace, size_t workspace_bytes, int B, int H,
+                                      int Lq, int D, int n_groups, int M, int K_in, float scale, int64_t q_ld,
+                                      void* stream) {
+    if (!q || !x || !x_rows || !Wk || !Wv || !out || !workspace) return FRESCO_EINVAL;
+    if (B <= 0 || H <= 0 || Lq <= 0 || D <= 0 || n_groups <= 0 || M <= 0 || K_in <= 0) return FRESCO_EINVAL;
+    if (B % n_groups != 0 || !(scale > 0.f)) return FRESCO_EINVAL;
+    if (q_ld < (int64_t)H * D || q_ld % 8 != 0 || x_ld < K_in || x_ld % 8 != 0) return FRESCO_EINVAL;
+    if (!fresco_attn_kvproj_supported(H, D, K_in)) return FRESCO_EUNSUPPORTED;
+    if (workspace_bytes < attn_ws_bytes(n_groups, H, M, D)) return FRESCO_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const half_t* qh = static_cast<const half_t*>(q);
+    const half_t* xh = static_cast<const half_t*>(x);
+    const half_t* wk = static_cast<const half_t*>(Wk);
+    const half_t* wv = static_cast<const half_t*>(Wv);
+    half_t* oh = static_cast<half_t*>(out);
+    char* ws = static_cast<char*>(workspace);
+    if (D == 40)
+        return launch_kvproj_attn<320, 40>(qh, xh, x_ld, x_rows, wk, wv, oh, ws, B, H, Lq, n_groups, M, scale, q_ld, st);
+    return launch_kvproj_attn<640, 80>(qh, xh, x_ld, x_rows, wk, wv, oh, ws, B, H, Lq, n_groups, M, scale, q_ld, st);
 }
 
 extern "C" int fresco_attn_fwd(const void* q, const void* k, const void* v, const int32_t* kv_rows,

@@ -166,11 +166,15 @@ class FrameShard:
         the boundary frames with the two ring neighbours and returns a handle for `halo_finish`; nothing here waits for
         a peer.  The handle owns packed copies of the frames sent, so `cs` may be read (not written) meanwhile."""
         x = cs.view(self.chunk, self.n_loc, *cs.shape[1:])
-        first = x[:, 0].contiguous()                       # (chunk, C, h, w) -> the left neighbour's halo_r
+        # PRIVATE copies (clone, not .contiguous(): with n_loc == 1 the slice already is contiguous and would alias cs):
+        # the transfer may still be reading them when the caller's next launch writes cs
+        first = x[:, 0].clone(memory_format=torch.contiguous_format)   # (chunk, C, h, w) -> the left neighbour's halo_r
         if self.world == 1:                                # ring of one rank: its own last / first frame
-            return dict(halo_l=x[:, self.n_loc - 1].contiguous(), halo_r=first, works=[], keep=())
+            return dict(halo_l=x[:, self.n_loc - 1].clone(memory_format=torch.contiguous_format), halo_r=first, works=[],
+                        keep=())
         single = self.n_loc == 1 and self.world == 2       # one frame, one peer: a single message serves both sides
-        last = first if self.n_loc == 1 else x[:, self.n_loc - 1].contiguous()  # -> the right neighbour's halo_l
+        # -> the right neighbour's halo_l
+        last = first if self.n_loc == 1 else x[:, self.n_loc - 1].clone(memory_format=torch.contiguous_format)
         halo_l = torch.empty_like(first)
         halo_r = halo_l if single else torch.empty_like(first)
         works = self.neighbour_exchange(None if single else first, last, halo_l, halo_r)

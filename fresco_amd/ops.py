@@ -229,6 +229,39 @@ def attention(q, k, v, heads, scale, *, kv_rows=None, n_groups=None, M=None, gro
     return out
 
 
+def attention_kvproj_supported(heads, head_dim, in_features):
+    return bool(_lib.load().fresco_attn_kvproj_supported(int(heads), int(head_dim), int(in_features)))
+
+
+def attention_kvproj(q, hidden, x_rows, w_k, w_v, heads, scale, n_groups, M, workspace=None):
+    """Cross-frame pass whose K | V projection of the selected rows is fused into the key pack (fresco_attn_fwd_kvproj).
+
+    q (B, Lq, C) fp16; hidden (..., K_in) fp16 whose leading dims flatten to rows; x_rows int32 (n_groups * M): key m of
+    group g = row x_rows[g * M + m] of `hidden` (in range: the caller's table, checked once where it is built);
+    w_k, w_v (C, K_in) fp16 contiguous -- the live weights of bias-free nn.Linear modules.  Returns (B, Lq, C)."""
+    _need_gpu(q, hidden, x_rows, w_k, w_v)
+    if any(t.dtype != torch.float16 for t in (q, hidden, w_k, w_v)) or x_rows.dtype != torch.int32:
+        raise TypeError("fresco_amd.attention_kvproj: fp16 tensors and an int32 row table required")
+    B, Lq, C = q.shape
+    D = C // heads
+    K_in = hidden.shape[-1]
+    if w_k.shape != (C, K_in) or w_v.shape != (C, K_in) or not (w_k.is_contiguous() and w_v.is_contiguous()):
+        raise ValueError("attention_kvproj: contiguous (%d, %d) weights expected" % (C, K_in))
+    if x_rows.numel() != n_groups * M or not x_rows.is_contiguous():
+        raise ValueError("attention_kvproj: x_rows must hold n_groups * M = %d entries" % (n_groups * M))
+    q, q_ld, _ = _rows(q)
+    hidden, x_ld, _ = _rows(hidden)
+    lib = _lib.load()
+    ws_bytes = lib.fresco_attn_workspace_bytes(n_groups, heads, M, D)
+    ws = (workspace or _default_ws).get(ws_bytes, q.device)
+    out = torch.empty((B, Lq, C), dtype=q.dtype, device=q.device)
+    rc = lib.fresco_attn_fwd_kvproj(q.data_ptr(), hidden.data_ptr(), x_ld, x_rows.data_ptr(), w_k.data_ptr(), w_v.data_ptr(),
+                                    out.data_ptr(), ws.data_ptr(), ws.numel(), B, heads, Lq, D, n_groups, M, K_in,
+                                    float(scale), q_ld, _stream())
+    _lib.check(rc, "fresco_attn_fwd_kvproj(B=%d,H=%d,Lq=%d,D=%d,groups=%d,M=%d,K=%d)" % (B, heads, Lq, D, n_groups, M, K_in))
+    return out
+
+
 def attention_f32(q, k, v, scale):
     """softmax(scale * q k^T) v at fp32 accuracy (fresco_attn_f32_guarded): q (B,Lq,D), k (B,Lk,D), v (B,Lk,Dv) ->
     (B,Lq,Dv).  One head; batch entries are independent problems (windows).  When several 128-query workgroups share a

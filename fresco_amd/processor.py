@@ -39,6 +39,9 @@ class FRESCOAttnProcessor2_0:
         self.fuse_projections = True  # q/k/v (and to_out at C = 320) through fresco_linear when they are plain Linears
         # cross-frame-only calls (no temporal pass) read K and V of the selected tokens only: project just those
         self.sparse_kv_projection = True
+        # ... and (round 6) project them INSIDE the key pack: one launch instead of fresco_linear_rows + kv_pack, K and V
+        # never reach HBM (fresco_attn_fwd_kvproj; plain bias-free fp16 to_k / to_v of a supported width only)
+        self.fuse_kv_pack = True
 
     # ---- fused projections ---------------------------------------------------------------------------
     def _project(self, attn, x, names, outs=None, x_rows=None):
@@ -192,6 +195,7 @@ class FRESCOAttnProcessor2_0:
 
         ctrl = self.controller
         crossattn = encoder_hidden_states is not None
+        fused_kv = None
         if not crossattn:
             encoder_hidden_states = hidden_states
             if ctrl and ctrl.store:
@@ -216,8 +220,20 @@ class FRESCOAttnProcessor2_0:
                 mask = self._cf_mask(ctrl, hw_)
                 nf = hidden_states.shape[0] // chunk_
                 rows_all = self._sel_rows(mask, chunk_, nf, hw_, hidden_states.device)  # flat rows of both CFG halves
-                key, value = self._project(attn, hidden_states, ("to_k", "to_v"), x_rows=rows_all)
-                key, value = key.view(chunk_, -1, key.shape[-1]), value.view(chunk_, -1, value.shape[-1])
+                if (self.fuse_kv_pack and self.fuse_projections and hidden_states.dtype == torch.float16
+                        and hidden_states.is_cuda and not ctrl.use_intraattn
+                        and _plain_linear(attn.to_k, False) and _plain_linear(attn.to_v, False)
+                        and attn.to_k.weight.is_contiguous() and attn.to_v.weight.is_contiguous()
+                        and attn.to_k.out_features == attn.to_v.out_features == query.shape[-1]
+                        and attn.to_k.out_features % attn.heads == 0
+                        and ops.attention_kvproj_supported(attn.heads, attn.to_k.out_features // attn.heads,
+                                                           attn.to_k.in_features)):
+                    # K | V of the selected rows are projected inside the key pack of the cross-frame pass below
+                    fused_kv = (rows_all, attn.to_k.weight.detach(), attn.to_v.weight.detach(), rows_all.numel() // chunk_)
+                    key = value = None
+                else:
+                    key, value = self._project(attn, hidden_states, ("to_k", "to_v"), x_rows=rows_all)
+                    key, value = key.view(chunk_, -1, key.shape[-1]), value.view(chunk_, -1, value.shape[-1])
             else:
                 query, key, value = self._project(attn, hidden_states, ("to_q", "to_k", "to_v"))
         else:
@@ -236,7 +252,7 @@ class FRESCOAttnProcessor2_0:
             query, key, value = query.half(), key.half(), value.half()
 
         heads = attn.heads
-        head_dim = key.shape[-1] // heads
+        head_dim = query.shape[-1] // heads
         sm_scale = 1.0 / math.sqrt(head_dim)
         fresco = bool(ctrl) and not crossattn
         chunk = self.unet_chunk_size
@@ -271,6 +287,9 @@ class FRESCOAttnProcessor2_0:
                 hs = self._masked_attention(q_att, k0, v0, heads, sm_scale, mask_bias)
             else:
                 hs = self._masked_attention(q_att, key, value, heads, sm_scale, mask_bias)
+        elif fresco and ctrl.use_cfattn and sparse_kv and fused_kv is not None:
+            hs = ops.attention_kvproj(q_att, hidden_states, fused_kv[0], fused_kv[1], fused_kv[2], heads, sm_scale,
+                                      n_groups=chunk, M=fused_kv[3], workspace=self._ws)
         elif fresco and ctrl.use_cfattn and sparse_kv:
             hs = ops.attention(q_att, key, value, heads, sm_scale, n_groups=chunk, M=key.shape[1],
                                group_rows=key.shape[1], workspace=self._ws)

@@ -134,6 +134,24 @@ int fresco_attn_fwd_ld(const void* q, const void* k, const void* v, const int32_
                        int n_groups, int M, int64_t group_rows,
                        float scale, float diag_bias, int64_t q_ld, int64_t kv_ld, void* stream);
 
+/* Cross-frame pass with the K | V projection of the selected rows FUSED into the key pack (round 6) -- for layer calls
+ * whose only reader of K and V is the cross-frame pass (DH:201-247 on the cross-frame-only steps): replaces
+ * attn.to_k / attn.to_v on the gathered rows (DH:214-215 restricted to the tokens DH:239-247 keep) + the pack.
+ *   x      : hidden states, fp16 rows of K_in features, row r at x + r*x_ld
+ *   x_rows : int32 (n_groups * M): key m of group g is row x_rows[g*M + m] of x (rows may repeat; must be in range --
+ *            the table is not checked on the device)
+ *   Wk, Wv : (H*D, K_in) row-major fp16 weights of the bias-free projections (read where they live, every call)
+ *   q, out, workspace (fresco_attn_workspace_bytes(n_groups, H, M, D)), B, H, Lq, D, n_groups, M, scale, q_ld: as
+ *   fresco_attn_fwd_ld; batch element b uses key group b / (B / n_groups).
+ * K = x[rows] Wk^T and V = x[rows] Wv^T are rounded to fp16 exactly once (as the two-launch path rounds them) and go
+ * straight into the packed key image: they never exist in HBM.  Supported: (D, K_in) = (40, 320), (80, 640) with
+ * H*D == K_in (SD-1.5's decoder self-attentions); fresco_attn_kvproj_supported says so, anything else returns
+ * FRESCO_EUNSUPPORTED and the caller uses fresco_linear_rows + fresco_attn_fwd_ld. */
+int fresco_attn_kvproj_supported(int H, int D, int K_in);
+int fresco_attn_fwd_kvproj(const void* q, const void* x, int64_t x_ld, const int32_t* x_rows, const void* Wk,
+                           const void* Wv, void* out, void* workspace, size_t workspace_bytes, int B, int H, int Lq,
+                           int D, int n_groups, int M, int K_in, float scale, int64_t q_ld, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * (a4)  Temporal-guided (FLATTEN) attention -- replaces DH:309-367: 3 rearrange+gather round
  * trips, the per-pixel N x N masked SDPA and the inverse gather.

@@ -216,7 +216,8 @@ def test_gmflow_out_of_range_operands_fall_back_to_library_ops(monkeypatch):
     monkeypatch.setenv("FRESCO_GMFLOW_LIBRARY_OPS", "1")
     want = m(imgs, imgs[nxt], **KW)["flow_preds"][-1]
     monkeypatch.delenv("FRESCO_GMFLOW_LIBRARY_OPS")
-    assert torch.equal(got, want) and bool(torch.isfinite(got).all())
+    # (two runs of the library path are not bit-identical on every box: MIOpen's convolutions may use atomics)
+    assert bool(torch.isfinite(got).all()) and float(_epe(got, want).max()) < 2e-2 * max(1.0, float(want.abs().max()))
     # (b) in-range weights, an out-of-range ACTIVATION: the FFN's hidden layer (no norm in front of the second product)
     with torch.no_grad():
         lin.weight[0, 0] = base.new_tensor(0.0)
@@ -225,4 +226,4 @@ def test_gmflow_out_of_range_operands_fall_back_to_library_ops(monkeypatch):
         got = m(imgs, imgs[nxt], **KW)["flow_preds"][-1]
     monkeypatch.setenv("FRESCO_GMFLOW_LIBRARY_OPS", "1")
     want = m(imgs, imgs[nxt], **KW)["flow_preds"][-1]
-    assert torch.equal(got, want)
+    assert bool(torch.isfinite(got).all()) and float(_epe(got, want).max()) < 2e-2 * max(1.0, float(want.abs().max()))

@@ -489,3 +489,54 @@ def test_processor_attention_mask_fully_masked_rows(C, heads):
     assert bool(torch.isfinite(out).all())
     _check(out, ref, atol=1e-3, rtol=2e-3, what="fully masked rows D=%d" % D)
 
+
+
+@pytest.mark.parametrize("layer,N,R", [("L3", 4, 256), ("L2", 4, 256), ("L3", 8, 512), ("L2", 8, 512)])
+@pytest.mark.parametrize("masked", [True, False])
+def test_fused_kv_projection_pack(layer, N, R, masked):
+    """Round 6: on cross-frame-only calls the K | V projection of the selected rows runs INSIDE the key pack
+    (fresco_attn_fwd_kvproj: K and V never reach HBM).  Against the fp32 oracle at the usual bar, and against the two-launch
+    path (fresco_linear_rows + kv_pack): the fp16 K / V values may differ in the last place (one accumulation chain in
+    natural k order vs two chains in permuted order), so the outputs agree to fp16 rounding, not bit for bit.
+    masked=False: controller.attn_mask None -> every frame attends to frame 0's HW keys."""
+    import fresco_amd
+    case = synth.make_attention_case(N, R, layer, seed=21 + N)
+    if not masked:
+        case = dict(case)
+        case["cf_mask"] = torch.zeros_like(case["cf_mask"])
+        case["cf_mask"][0] = True
+    outs = {}
+    for fused in (True, False):
+        ctrl = synth.controller_for(case, "cf", DEV)
+        if not masked:
+            ctrl.attn_mask = None
+        proc = fresco_amd.FRESCOAttnProcessor2_0(2, ctrl)
+        proc.fuse_kv_pack = fused
+        attn = copy.deepcopy(case["attn"]).to(DEV).half()
+        with torch.no_grad():
+            outs[fused] = proc(attn, case["hidden"].to(DEV).half())
+    ref32 = synth.oracle_attention(case, "cf", round_dtype=None, device=DEV if N > 4 else None)
+    e_f = _check(outs[True], ref32, atol=1e-3, rtol=1e-3, what="fused %s" % layer)
+    e_u = _check(outs[False], ref32, atol=1e-3, rtol=1e-3, what="two-launch %s" % layer)
+    d = float((outs[True].float() - outs[False].float()).abs().max())
+    print("fused K|V projection + pack, %s N=%d masked=%s: max err vs fp32 oracle %.2e (two-launch path %.2e), fused vs "
+          "two-launch %.2e" % (layer, N, masked, e_f, e_u, d))
+    assert d < 1e-3
+    assert e_f < 2.0 * e_u + 1e-4  # (no worse than the path it replaces)
+
+
+def test_fused_kv_projection_pack_is_deterministic_and_sees_weight_updates():
+    import fresco_amd
+    case = synth.make_attention_case(4, 256, "L3", seed=33)
+    ctrl = synth.controller_for(case, "cf", DEV)
+    proc = fresco_amd.FRESCOAttnProcessor2_0(2, ctrl)
+    attn = copy.deepcopy(case["attn"]).to(DEV).half()
+    x = case["hidden"].to(DEV).half()
+    with torch.no_grad():
+        a = proc(attn, x)
+        b = proc(attn, x)
+        assert torch.equal(a, b)
+        attn.to_v.weight.mul_(0.5)       # the kernel reads the live weights: V halves, so does the output (to_out is linear)
+        c = proc(attn, x)
+    bias = attn.to_out[0].bias.float()
+    assert float(((c.float() - bias) - 0.5 * (a.float() - bias)).abs().max()) < 2e-3

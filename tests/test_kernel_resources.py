@@ -45,6 +45,11 @@ def test_flash_and_projection_kernels_fit_two_waves_per_simd(tmp_path):
     for pat in (r"attn_flash_kernelILi40ELi2E", r"attn_flash_kernelILi80ELi1E"):  # up_blocks.3 / up_blocks.2
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+    # the fused K | V projection + pack launch: 5-wave workgroups; at K = 320 two per CU (268 workgroups must not need a
+    # second round) -> <= 168 registers; at K = 640 one per CU (93 KB of LDS, 136 workgroups)
+    for pat, cap in ((r"kvproj_pack_kernelILi320ELi40E", 168), (r"kvproj_pack_kernelILi640ELi80E", 256)):
+        r = _one(k, pat)
+        assert r["vgpr"] + r["agpr"] <= cap and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
     k = _listing("proj.hip", tmp_path)
     for pat in (r"linear_kernelILi320ELi8E", r"linear_kernelILi640ELi8E"):
         r = _one(k, pat)

@@ -33,7 +33,7 @@ import bench  # noqa: E402  (synthetic FRESCO parameters of the headline bench)
 import bench_opt  # noqa: E402
 import fresco_amd  # noqa: E402
 from fresco_amd import ops  # noqa: E402
-from standin_unet import ControlNet, UNet  # noqa: E402
+from standin_unet import ControlNet, UNet, reinit_unit_gain  # noqa: E402
 
 
 class TorchPathProcessor:
@@ -106,13 +106,22 @@ def timed(fn, reps=3):
 class Harness:
     """stand-in UNet + ControlNet (initialised ON the GPU from a fixed seed) + the synthetic FRESCO parameters of bench.py"""
 
-    def __init__(self, N=8, R=512, dev="cuda", seed=0):
+    def __init__(self, N=8, R=512, dev="cuda", seed=0, init="default"):
+        """init: "default" = torch's default initialisation (rounds 4-5: a decoder with an input -> output gain of tens);
+        "unit_gain" = standin_unet.reinit_unit_gain (variance-preserving: a perturbation of a layer output reaches the UNet
+        output with gain ~ 1, as a trained network's would)"""
         self.N, self.R, self.dev = N, R, torch.device(dev)
+        self.init = init
         B, lat = 2 * N, R // 8
         torch.manual_seed(seed)
         with torch.device(self.dev):
             self.unet = UNet().half().eval()
             self.cnet = ControlNet().half().eval()
+        if init == "unit_gain":
+            reinit_unit_gain(self.unet, seed + 1)
+            reinit_unit_gain(self.cnet, seed + 2)
+        self.perturb = None      # (layer index, amplitude): the gain probe adds +-amplitude to that FRESCO layer's output
+        self.last_unet_out = None
         g = torch.Generator().manual_seed(seed)
         self.g = g
         lat0 = torch.randn(1, 4, lat, lat, generator=g).repeat(N, 1, 1, 1)  # repeat_noise: one initial latent for all frames (:152-153)
@@ -138,8 +147,9 @@ class Harness:
 
     def use(self, kind):
         p = {"ours": self.proc, "ref": TorchPathProcessor(self.st), "ref32": TorchPathProcessor(self.st, torch.float32)}.get(kind)
-        for a, s in zip(self.layers, self.stock):
-            a.processor = p if p is not None else s
+        for i, (a, s) in enumerate(zip(self.layers, self.stock)):
+            base = p if p is not None else s
+            a.processor = base if self.perturb is None or self.perturb[0] != i else _Perturbed(base, self.perturb[1])
         self.kind = kind
 
     def set_mode(self, mode):
@@ -154,6 +164,7 @@ class Harness:
         down, mid = self.cnet(x, t, self.ctx, self.cond)
         out = self.unet(x, t, self.ctx, down_block_additional_residuals=down, mid_block_additional_residual=mid,
                         return_dict=False)[0]
+        self.last_unet_out = out
         eu, et = out.chunk(2)
         return eu + 7.5 * (et - eu)
 
@@ -178,7 +189,119 @@ class Harness:
         return traj
 
 
+class _Perturbed:
+    """gain probe: a processor whose output is moved by +-amp per element (fixed pseudo-random signs); amp = "ulp": ONE
+    element (the middle one of batch row 0) is moved to the next fp16 number -- the smallest deviation from the
+    reference's layer output that an implementation which is not bit-identical to it can have"""
+
+    def __init__(self, base, amp):
+        self.base, self.amp = base, amp
+
+    def __call__(self, attn, hidden_states, *a, **kw):
+        out = self.base(attn, hidden_states, *a, **kw)
+        if self.amp == "ulp":
+            out = out.clone()
+            flat = out.view(-1)
+            i = out[0].numel() // 2 + 7
+            flat[i:i + 1] = torch.nextafter(flat[i:i + 1], flat[i:i + 1] * 2 + 1)
+            return out
+        g = torch.Generator(device=out.device).manual_seed(4321)
+        sgn = torch.randint(0, 2, out.shape, generator=g, device=out.device).to(out.dtype) * 2 - 1
+        return out + self.amp * sgn
+
+
 LOOP_MODES = ["full", "cf_temporal", "cf_temporal", "cf", "cf", "cf"]
+
+
+@torch.no_grad()
+def measure_gain(h, amp=1e-3, mode="cf"):
+    """How far the stand-in network carries a perturbation of ONE FRESCO layer's output (Next #4 i): the
+    reference's op sequence twice on identical inputs, the second time with +-amp added to every element of layer k's output
+    -> max |delta| of the UNet output (before classifier-free guidance), of the guided eps, and of the latents after one
+    step at t = 951, each divided by amp.  amp = 1e-3: far enough above the fp16 grid of O(1) activations (4.9e-4) to get
+    through, small enough to stay linear; fp32 latents on both sides."""
+    t = h.sched.timesteps[0]
+    lat = h.latents.float()
+
+    def run():
+        h.use("ref")
+        h.set_mode(mode)
+        e = h.eps(lat.half(), t).float()
+        gen = torch.Generator(device=h.dev).manual_seed(99)
+        return h.last_unet_out.float().clone(), e.clone(), reference_step(h.sched, e, t, lat, gen)
+
+    h.perturb = None
+    u0, e0, l0 = run()
+    # the floor under everything below: the SAME call a second time (nothing perturbed).  PyTorch's convolution / GEMM kernels
+    # around the six layers are not all run-to-run deterministic on this GPU (atomics, split-K): whatever this shows is a
+    # deviation the reference path has from ITSELF
+    u0b, e0b, l0b = run()
+    repeat = dict(unet_output_max_abs_delta=round(float((u0b - u0).abs().max()), 7),
+                  unet_output_elements_changed=int((u0b != u0).sum()), unet_output_elements=int(u0.numel()),
+                  guided_eps_max_abs_delta=round(float((e0b - e0).abs().max()), 7),
+                  latent_max_abs_delta_one_step=round(float((l0b - l0).abs().max()), 7))
+    per_layer = []
+    for k in range(len(h.layers)):
+        h.perturb = (k, amp)
+        u1, e1, l1 = run()
+        per_layer.append(dict(layer="up_blocks.%d.attentions.%d" % (2 + k // 3, k % 3),
+                              unet_output_gain=round(float((u1 - u0).abs().max()) / amp, 3),
+                              unet_output_gain_rms=round(float((u1 - u0).pow(2).mean().sqrt()) / amp, 4),
+                              guided_eps_gain=round(float((e1 - e0).abs().max()) / amp, 3),
+                              latent_gain_one_step=round(float((l1 - l0).abs().max()) / amp, 3)))
+    # the smallest possible deviation: ONE element of ONE layer output moved by one fp16 ulp
+    one_ulp = []
+    for k in (0, len(h.layers) - 1):
+        h.perturb = (k, "ulp")
+        u1, e1, l1 = run()
+        one_ulp.append(dict(layer="up_blocks.%d.attentions.%d" % (2 + k // 3, k % 3),
+                            unet_output_max_abs_delta=round(float((u1 - u0).abs().max()), 7),
+                            unet_output_elements_changed=int((u1 != u0).sum()),
+                            guided_eps_max_abs_delta=round(float((e1 - e0).abs().max()), 7),
+                            latent_max_abs_delta_one_step=round(float((l1 - l0).abs().max()), 7)))
+    h.perturb = None
+    h.use("stock")
+    worst = max(per_layer, key=lambda r: r["latent_gain_one_step"])
+    return dict(amplitude=amp, per_layer=per_layer, reference_run_to_run=dict(
+                    repeat, note="the reference op sequence in the six layers, the stand-in UNet + ControlNet around them, "
+                                 "identical inputs, run twice: max |run 2 - run 1|"),
+                one_fp16_ulp_in_one_element=dict(
+                    probes=one_ulp,
+                    note="ONE element (of 21 M / 10 M) of one FRESCO layer's output moved to the next fp16 number, everything "
+                         "else identical: what the fp16 network itself makes of the smallest deviation an implementation that is "
+                         "not bit-identical to the reference can have.  The UNet's own fp16 output grid is 9.8e-4 in [1, 2): one "
+                         "flipped rounding there is 9.8e-4 x the guidance factor x the step factor in the latents"), worst_layer=worst["layer"], unet_output_gain=worst["unet_output_gain"],
+                guided_eps_gain=worst["guided_eps_gain"], latent_gain_one_step=worst["latent_gain_one_step"],
+                cfg_factor=round(worst["guided_eps_gain"] / max(worst["unet_output_gain"], 1e-12), 3),
+                step_factor=round(worst["latent_gain_one_step"] / max(worst["guided_eps_gain"], 1e-12), 4),
+                note="max |delta| / amplitude for a +-amplitude perturbation of every element of one FRESCO layer's output "
+                     "(reference op sequence on both sides, identical inputs, step at t = 951): the stand-in network's own "
+                     "amplification, then classifier-free guidance (eu + 7.5 (et - eu)), then the DDPM update")
+
+
+@torch.no_grad()
+def measure_eps_level(h, mode="cf_temporal"):
+    """Step 1 of the loop, identical inputs on both sides: |ours - reference op sequence| of the UNet output BEFORE the
+    classifier-free-guidance combine, of the guided eps, and of the latents after the update (Next #4 iii)"""
+    t = h.sched.timesteps[0]
+    lat = h.latents.float()
+    got = {}
+    for kind in ("ours", "ref", "ref32"):
+        h.use(kind)
+        h.set_mode(mode)
+        e = h.eps(lat.half(), t).float()
+        gen = torch.Generator(device=h.dev).manual_seed(99)
+        got[kind] = (h.last_unet_out.float().clone(), e.clone(), reference_step(h.sched, e, t, lat, gen))
+    h.use("stock")
+    d = lambda a, b, i: float((got[a][i] - got[b][i]).abs().max())
+    return dict(mode=mode,
+                ours_vs_reference=dict(unet_output=round(d("ours", "ref", 0), 7), guided_eps=round(d("ours", "ref", 1), 7),
+                                       latent_after_step=round(d("ours", "ref", 2), 7)),
+                reference_own_fp16_noise=dict(unet_output=round(d("ref", "ref32", 0), 7), guided_eps=round(d("ref", "ref32", 1), 7),
+                                              latent_after_step=round(d("ref", "ref32", 2), 7)),
+                unet_output_abs_max=round(float(got["ref"][0].abs().max()), 3),
+                note="fp32 scheduler arithmetic, the SAME update on all sides (isolates the six layers); "
+                     "reference_own_fp16_noise = the reference op sequence vs itself with the six layers in fp32")
 
 
 def measure_latent_delta(h, modes=LOOP_MODES):
@@ -202,6 +325,9 @@ def measure_latent_delta(h, modes=LOOP_MODES):
                         latent_abs_max=round(float(ref[-1].abs().max()), 3))
     out["steps"] = len(modes)
     out["modes"] = modes
+    out["init"] = h.init
+    out["standin_gain"] = measure_gain(h)
+    out["eps_level_step1"] = measure_eps_level(h)
     out["bar"] = ("per step: delta <= 1.5 x the reference path's own fp16 noise + 1e-3 (tests/test_gpu_latent_delta.py); the north "
                   "star's absolute 1e-3 holds per layer call (torch_gpu_baseline.max_abs_delta), not over a loop: the reference op "
                   "sequence against itself with the six layers in fp32 is 1.3e-2 apart after ONE step on this network")
@@ -267,6 +393,17 @@ def measure(N=8, R=512, dev="cuda", with_opt=True, with_delta=True, verbose=Fals
         del targets
     if with_delta:
         res["latent_delta"] = measure_latent_delta(h)
+        # the same six steps on a UNIT-GAIN stand-in (variance-preserving initialisation): does the north star's absolute
+        # 1e-3 hold over the loop when the network itself does not amplify?
+        del h
+        torch.cuda.empty_cache()
+        h = Harness(N, R, dev, init="unit_gain")
+        ug = measure_latent_delta(h)
+        res["latent_delta"]["unit_gain_standin"] = dict(
+            fp32_latents=ug["fp32_latents"], fp16_latents=ug["fp16_latents"], standin_gain=ug["standin_gain"],
+            eps_level_step1=ug["eps_level_step1"],
+            note="tools/standin_unet.reinit_unit_gain: N(0, 1 / fan_in) weights, residual branches damped to 0.3 -- the same "
+                 "module tree, the same six steps, the same comparison")
     h.use("stock")
     if verbose:
         print(json.dumps(res, indent=1))

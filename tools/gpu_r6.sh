@@ -14,6 +14,20 @@ for S in "$@"; do
   newtests)
     timeout 1200 python -m pytest tests/test_gpu_cfg45.py tests/test_gpu_latent_delta.py tests/test_gpu_attn32.py -m gpu -q -s --tb=short -p no:cacheprovider > $OUT/pytest_new_$TAG.log 2>&1
     grep -E "opt N=|warp_tensor N=|cfg5 L2|latent delta|passed|failed|FAILED|ERROR|Error" $OUT/pytest_new_$TAG.log | head -60 ;;
+  r6new)
+    timeout 2400 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_flownet.py tests/test_gmflow.py tests/test_gpu_cfg45.py -m gpu -q -s --tb=short -p no:cacheprovider -k "sharded_optimize or range or side_operands or out_of_range or full_batch or cfg5_full" > $OUT/pytest_r6new_$TAG.log 2>&1
+    grep -E "cfg5|opt FULL|passed|failed|FAILED|ERROR|Error|assert" $OUT/pytest_r6new_$TAG.log | head -60 ;;
+  kvtests)
+    timeout 1800 python -m pytest tests/test_gpu_attention.py tests/test_gpu_fullsize.py tests/test_gpu_sharded.py tests/test_gmflow.py tests/test_gpu_integration.py -m gpu -q -s --tb=short -p no:cacheprovider -k "${KEXPR:-fused or processor or sharded_optimize or out_of_range or integration}" > $OUT/pytest_kv_$TAG.log 2>&1
+    grep -E "fused K|passed|failed|FAILED|ERROR|Error|assert" $OUT/pytest_kv_$TAG.log | head -60 ;;
+  qbench)
+    timeout 900 python bench.py --no-cpu-baseline --no-aux > $OUT/qbench_$TAG.json 2> $OUT/qbench_$TAG.err; python - <<PYEOF
+import json
+r=json.loads(open("$OUT/qbench_$TAG.json").read().strip().splitlines()[-1])
+print(r["value"], r["ms_per_step"], r["timing"]["ms_per_step_all"], r["roofline"]["avg_launch_us"], r["host_issue_ms_per_step"])
+for k,v in r["kernel_avg_us"].items(): print("  ", k, v)
+PYEOF
+    tail -3 $OUT/qbench_$TAG.err ;;
   smoke)
     python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; tail -4 $OUT/smoke_$TAG.log ;;
   bench)

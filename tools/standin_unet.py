@@ -222,3 +222,34 @@ class UNet(_Encoder):
     def fresco_self_attentions(self):
         """the six decoder self-attentions FRESCO replaces (keys up_blocks.2.* / up_blocks.3.*, attn1), in call order"""
         return [t.transformer_blocks[0].attn1 for i in (2, 3) for t in self.up_blocks[i].attentions]
+
+
+def reinit_unit_gain(model, seed=0, branch=0.3):
+    """Variance-preserving re-initialisation (Next #4): torch's default init (uniform, var = 1 / (3 fan_in))
+    plus un-damped residual branches gives this stand-in decoder an input -> output gain of several tens, which SD-1.5's
+    trained weights do not have.  Here every Linear / Conv2d weight is N(0, 1 / fan_in) (unit gain on unit-variance input),
+    biases are zero, and the LAST layer of every residual branch (ResnetBlock2D.conv2, Attention.to_out[0],
+    BasicTransformerBlock.ff_out, Transformer2DModel.proj_out) is scaled by `branch`, so that a block maps unit-variance
+    features to variance 1 + branch^2 and a perturbation passes with gain ~ 1.  Deterministic for a seed; weights are drawn
+    on the CPU generator and copied, so CPU / GPU construction give the same network."""
+    g = torch.Generator().manual_seed(seed)
+    last = set()
+    for m in model.modules():
+        if isinstance(m, ResnetBlock2D):
+            last.add(m.conv2)
+        elif isinstance(m, Attention):
+            last.add(m.to_out[0])
+        elif isinstance(m, BasicTransformerBlock):
+            last.add(m.ff_out)
+        elif isinstance(m, Transformer2DModel):
+            last.add(m.proj_out)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                w = m.weight
+                fan_in = w[0].numel()
+                val = torch.randn(w.shape, generator=g) * (1.0 / math.sqrt(fan_in)) * (branch if m in last else 1.0)
+                w.copy_(val.to(w.dtype))
+                if m.bias is not None:
+                    m.bias.zero_()
+    return model
