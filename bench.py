@@ -460,6 +460,10 @@ def sharded_vs_single(layers, params, N, device, shard, proc, ctrl, refs, paras,
             if rank == 0:
                 c1 = fresco_amd.AttentionControl()
                 p1 = fresco_amd.FRESCOAttnProcessor2_0(2, c1)
+                # (the sharded branch projects K | V of the exchanged rows with fresco_linear; the comparator does the same --
+                # the fused projection + pack of the single-GPU path rounds K / V identically but accumulates in another
+                # order, 1 fp16 ulp of the output -- so that this check stays an EXACT test of the exchange logic)
+                p1.fuse_kv_pack = False
                 set_mode(c1, mode, [l["ref"] for l in layers], paras, masks)
                 worst = 0.0
                 for l, g in zip(layers, got):

@@ -810,6 +810,7 @@ static size_t opt_ws_layout(OptWs* w, char* basep, int chunk, int N, int C, int 
     tmp.vph = has_s ? carve<half_t>(p, E) : nullptr;
     tmp.vpl = has_s ? carve<half_t>(p, E) : nullptr;
     tmp.ssign = has_s ? carve<int8_t>(p, B * hw * hw) : nullptr;
+    tmp.gpart = (has_s && hw <= 64) ? carve<float>(p, B * 8 * 64 * 64) : nullptr;
     if (w) *w = tmp;
     return (size_t)(p - basep);
 }
@@ -980,6 +981,7 @@ static OptWs ws_half(const OptWs& w, int ck0, int N, int NP, int C, int hw) {
         o.vph += E;
         o.vpl += E;
         o.ssign += pl * hw * hw;
+        if (o.gpart) o.gpart += pl * 8 * 64 * 64;
     }
     if (o.sgn1) {
         const size_t e8 = (size_t)ck0 * NP * ((C + 7) / 8) * 8 * hw;

@@ -468,6 +468,116 @@ __global__ __launch_bounds__(NW * 64) void gram16s_kernel(const half_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same Gram step for planes of ONE 64 x 64 tile (the 8 x 8 input of up_blocks.0) as two launches (round 6).  At
+// batch 16 gram16s_kernel is 16 workgroups: 16 CUs issue all of the launch's row-strided 16-byte fragment loads, which a
+// CU's texture-address unit sustains at ~9 B/clk (profiles/r06_kvproj_ablation.txt measured the same rate for the same
+// access pattern) -- 26 us for 31 Mflop per plane while 240 CUs idle.  Here every split-K slice is a one-wave workgroup
+// of its own (grid (tiles, NW, planes): 128 CUs share the loads), leaving its partial tile in the workspace, and a second
+// launch adds the NW partials in wave order and writes the signs.  Each partial is the sum gram16s_kernel<NW>'s wave w
+// forms -- same k-steps, same MFMA order -- and they are added in the same order: the signs are bit-identical (tested).
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64) void gram16sp_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
+                                                      float* __restrict__ gpart, int C, int hw) {
+    const int lane = threadIdx.x & 63, wave = blockIdx.y;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nt = hw / 64;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt, b = blockIdx.z;
+    const int p0 = ti * 64, q0 = tj * 64;
+    const half_t* hb = vph + (int64_t)b * hw * C;
+    const half_t* lb = vpl + (int64_t)b * hw * C;
+    const int64_t ra0 = (int64_t)(p0 + l31) * C + hi * 8, ra1 = ra0 + (int64_t)32 * C;
+    const int64_t rb0 = (int64_t)(q0 + l31) * C + hi * 8, rb1 = rb0 + (int64_t)32 * C;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    struct Frag {
+        half8_t ah[2], al[2], bh[2], bl[2];
+    };
+    auto loadf = [&](int ks, Frag& f) __attribute__((always_inline)) {
+        const int k = ks * 16;
+        f.ah[0] = *reinterpret_cast<const half8_t*>(hb + ra0 + k);
+        f.ah[1] = *reinterpret_cast<const half8_t*>(hb + ra1 + k);
+        f.al[0] = *reinterpret_cast<const half8_t*>(lb + ra0 + k);
+        f.al[1] = *reinterpret_cast<const half8_t*>(lb + ra1 + k);
+        f.bh[0] = *reinterpret_cast<const half8_t*>(hb + rb0 + k);
+        f.bh[1] = *reinterpret_cast<const half8_t*>(hb + rb1 + k);
+        f.bl[0] = *reinterpret_cast<const half8_t*>(lb + rb0 + k);
+        f.bl[1] = *reinterpret_cast<const half8_t*>(lb + rb1 + k);
+    };
+    auto compute = [&](const Frag& f) __attribute__((always_inline)) {  // (the product order of gram16s_kernel)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[jj], acc[i][jj], 0, 0, 0);
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[jj], acc[i][jj], 0, 0, 0);
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[jj], acc[i][jj], 0, 0, 0);
+            }
+    };
+    const int nks = C / 16;
+    Frag f0, f1;
+    int ks = wave;
+    if (ks < nks) loadf(ks, f0);
+    while (ks < nks) {
+        if (ks + NW < nks) loadf(ks + NW, f1);
+        compute(f0);
+        ks += NW;
+        if (ks >= nks) break;
+        if (ks + NW < nks) loadf(ks + NW, f0);
+        compute(f1);
+        ks += NW;
+    }
+    float* mine = gpart + (((int64_t)b * gridDim.x + blockIdx.x) * NW + wave) * 4096;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + jj * 32 + l31] = acc[i][jj][r];
+}
+
+// grid (tiles, 1, planes), 256 threads: thread = 16 consecutive entries of one row (as gram16s_kernel's reduction)
+__global__ __launch_bounds__(256) void gram16sr_kernel(const float* __restrict__ gpart, const float* __restrict__ target,
+                                                       int8_t* __restrict__ sgn_out, int NW, int hw, int s_tiled) {
+    const int tid = threadIdx.x;
+    const int nt = hw / 64;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt, b = blockIdx.z;
+    const int p0 = ti * 64, q0 = tj * 64;
+    const int row = tid >> 2, cq = (tid & 3) * 16;
+    const float* part = gpart + ((int64_t)b * gridDim.x + blockIdx.x) * NW * 4096;
+    float g[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) g[e] = 0.f;
+    for (int w = 0; w < NW; ++w) {  // fixed order
+        const float* src = part + (int64_t)w * 4096 + row * 64 + cq;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const floatx4 t = *reinterpret_cast<const floatx4*>(src + e4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e4 * 4 + e] += t[e];
+        }
+    }
+    const int gp = p0 + row, gq = q0 + cq;
+    const float* tg = target + ((int64_t)b * hw + gp) * hw + gq;
+    u32x4 packed;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        const floatx4 t = *reinterpret_cast<const floatx4*>(tg + e4 * 4);
+        uint32_t wv = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv |= (uint32_t)(uint8_t)sign_byte(g[e4 * 4 + e] - t[e]) << (8 * e);
+        packed[e4] = wv;
+    }
+    s_store_piece(sgn_out, packed, b, gp, gq, hw, s_tiled);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Gram step for the big planes (hw % 256 == 0, hw >= 512, C % 32 == 0): gram16y_kernel below.  Shared pieces: the tile
 // walk -- tiles (ti, tj) of 256 x 128 pixels with tj >= 2 ti in units of 128 pixels; the 128-row half of a tile that lies
 // BELOW the diagonal (only when tj == 2 ti) is the mirror image of its neighbour's upper half and is not written; halves
@@ -1274,7 +1384,11 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
     const int NCT = (C + 127) / 128;  // channel tiles of the S V kernels
     const bool cm_tiled = sv_tiled_layout(hw, C);
     const bool small = hw <= 256 && C % 32 == 0;
-    const bool big = gram_x_layout(hw, C);
+    // (round 6 experiment: FRESCO_GRAM_TILED_MIN_HW=256 sends the 16 x 16 planes to the DMA-staged 128 x 128 tile kernel instead
+    // of gram16s_kernel, whose row-strided 16-byte fragment loads sustain ~9 B/clk/CU; read per call: the tests switch it)
+    const char* mh_env = getenv("FRESCO_GRAM_TILED_MIN_HW");
+    const int min_hw = mh_env ? atoi(mh_env) : 512;
+    const bool big = gram_x_layout(hw, C, min_hw > 0 ? min_hw : 512);
     const float kscale = 2.f / ((float)Bg * (float)C * (float)hw);
     const int parts = sync ? sync->parts : 3;
     const int halo_split = (sync && sync->halo_split && has_t && !L.circular) ? 1 : 0;
@@ -1360,7 +1474,13 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
             // (the wave count is the split of the contraction, i.e. part of the arithmetic: chosen by the size of the WHOLE
             // problem, so that one CFG half alone, or a rank's frame shard, rounds exactly as the undivided batch does)
             // 8 waves (an 8-way split of K) up to 16 x 16 planes at batch 16: the launch is a latency chain of K steps
-            if (nt * nt * Bg < 512) {
+            const char* sp_env = getenv("FRESCO_GRAM_SPLIT_WG");  // (read per call: "0" keeps the one-launch form; tests)
+            if (nt * nt * Bg < 512 && nt * nt * planes <= 64 && w.gpart && !gloss && hw <= 64 && !(sp_env && sp_env[0] == '0')) {
+                // one 64 x 64 tile per plane: every split-K slice on a CU of its own, then the ordered sum (same bits)
+                hipLaunchKernelGGL(gram16sp_kernel<8>, dim3(nt * nt, 8, planes), dim3(64), 0, st, w.vph, w.vpl, w.gpart, C, hw);
+                hipLaunchKernelGGL(gram16sr_kernel, dim3(nt * nt, 1, planes), dim3(256), 0, st, w.gpart, target, w.ssign, 8, hw,
+                                   cm_tiled ? 1 : 0);
+            } else if (nt * nt * Bg < 512) {
                 constexpr int lds = 8 * 64 * GS_RS * 4;
                 static const bool once = [] {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16s_kernel<8>),

@@ -181,7 +181,9 @@ __host__ __device__ __forceinline__ bool sv_tiled_layout(int hw, int C) { return
 // (the condition under which gram16y_kernel runs: the pixel-major operand copies are then stored pre-tiled AND swizzled:
 // [plane][pixel tile of 128][channel chunk of 16][128 pixels][2 x 16-byte units], the two units of pixel row r swapped
 // when (r >> 3) & 1 -- the image a linear LDS-DMA copy needs for conflict-free ds_read_b128 on 32-byte rows)
-__host__ __device__ __forceinline__ bool gram_x_layout(int hw, int C) { return hw % 256 == 0 && hw >= 512 && C % 32 == 0; }
+__host__ __device__ __forceinline__ bool gram_x_layout(int hw, int C, int min_hw = 512) {
+    return hw % 256 == 0 && hw >= min_hw && C % 32 == 0;
+}
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 struct AdamArgs {
@@ -191,6 +193,7 @@ struct AdamArgs {
 // the caller-provided workspace of one optimize_feature call, carved by opt_ws_layout (opt.hip)
 struct OptWs {
     float *grad, *m, *v, *vt, *dvt, *nrm, *wgt, *part, *dotp;
+    float* gpart;  // planes <= 64 pixels: the 8 split-K partial tiles of the Gram product per plane (gram16sp / gram16sr)
     half_t *vh, *vl, *vph, *vpl;
     int8_t *sgn1, *sgn2, *ssign;
     int *rowptr, *cursor, *src;

@@ -254,3 +254,30 @@ def test_launch_forms_are_bit_identical(C, h, w, monkeypatch):
     ref = outs[("0", "0")]
     for k, v in outs.items():
         assert torch.equal(ref, v), (k, int((ref != v).sum()))
+
+
+@pytest.mark.parametrize("N", [8, 4])
+def test_split_workgroup_gram_of_one_tile_planes_is_bit_identical(N, monkeypatch):
+    """Round 6: at the 8 x 8 input of up_blocks.0 (one 64 x 64 Gram tile per plane) every split-K slice of the Gram product
+    runs as a workgroup of its own and a second launch adds the 8 partial tiles in wave order (gram16sp / gram16sr) instead
+    of 16 workgroups doing all of it (gram16s): each partial is the same sum in the same order, so the features after the
+    pipeline's 20 Adam iterations must be IDENTICAL; one stream and two (the halves' slices of the partial-tile workspace)."""
+    import fresco_amd.ops as ops
+    from fresco_amd.warp import _prep_flow_occ
+    C, h = 1280, 8
+    g = synth.gen(77 + N)
+    x = torch.randn(2 * N, C, h, h, generator=g)
+    flows, occs = synth.make_flows(N, 512, g)
+    target = O.gram_target(torch.randn(2 * N, C, h, h, generator=g)).to(DEV)
+    prep = _prep_flow_occ(h, [f.to(DEV) for f in flows], [o.to(DEV) for o in occs], with_dilate=False)
+    outs = {}
+    for form in ("0", "1"):
+        for split in ("0", "1"):
+            monkeypatch.setenv("FRESCO_GRAM_SPLIT_WG", form)
+            monkeypatch.setenv("FRESCO_OPT_SPLIT", split)
+            cs = x.to(DEV).clone()
+            ops.opt_run(cs, prep, target, 100.0, 20, 2)
+            outs[(form, split)] = cs
+    ref = outs[("0", "0")]
+    for k, v in outs.items():
+        assert torch.equal(ref, v), (k, int((ref != v).sum()))

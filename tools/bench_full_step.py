@@ -214,6 +214,45 @@ LOOP_MODES = ["full", "cf_temporal", "cf_temporal", "cf", "cf", "cf"]
 
 
 @torch.no_grad()
+def measure_repeatability(h, mode="cf"):
+    """The same call twice, nothing changed, per processor kind -- and once more with PyTorch asked for deterministic
+    convolution / GEMM algorithms (torch.backends.cudnn.deterministic: MIOpen on ROCm).  fresco_amd's kernels are run-to-run
+    bit-identical (tests/test_gpu_opt.py, test_gpu_attention.py); whatever `ours` shows here comes from the PyTorch kernels
+    of the stand-in network around the six layers."""
+    t = h.sched.timesteps[0]
+    lat = h.latents.float()
+
+    def run(kind):
+        h.use(kind)
+        h.set_mode(mode)
+        e = h.eps(lat.half(), t).float()
+        gen = torch.Generator(device=h.dev).manual_seed(99)
+        return h.last_unet_out.float().clone(), reference_step(h.sched, e, t, lat, gen)
+
+    out = {}
+    for det in (False, True):
+        prev = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+        if det:
+            torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+        try:
+            for kind in ("ref", "ours"):
+                a, la = run(kind)
+                b, lb = run(kind)
+                out["%s%s" % (kind, "_deterministic_algorithms" if det else "")] = dict(
+                    unet_output_max_abs_delta=round(float((a - b).abs().max()), 7),
+                    unet_output_elements_changed=int((a != b).sum()),
+                    latent_max_abs_delta_one_step=round(float((la - lb).abs().max()), 7))
+        finally:
+            torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = prev
+    h.use("stock")
+    out["unet_output_elements"] = int(a.numel())
+    out["note"] = ("identical inputs, identical processors, run twice: max |run 2 - run 1| of the UNet output and of the latents "
+                   "after one step at t = 951.  Non-zero for `ours` (whose six layers are bit-reproducible) = the stand-in "
+                   "network's own PyTorch kernels are not run-to-run deterministic on this GPU")
+    return out
+
+
+@torch.no_grad()
 def measure_gain(h, amp=1e-3, mode="cf"):
     """How far the stand-in network carries a perturbation of ONE FRESCO layer's output (Next #4 i): the
     reference's op sequence twice on identical inputs, the second time with +-amp added to every element of layer k's output
@@ -304,9 +343,23 @@ def measure_eps_level(h, mode="cf_temporal"):
                      "reference_own_fp16_noise = the reference op sequence vs itself with the six layers in fp32")
 
 
-def measure_latent_delta(h, modes=LOOP_MODES):
+def measure_latent_delta(h, modes=LOOP_MODES, deterministic=False):
     """max |latent(ours) - latent(reference op sequence)| after every step, fp16 and fp32 latents, + the reference path's
-    own fp16 noise (same op sequence with the six layers in fp32) as the yardstick"""
+    own fp16 noise (same op sequence with the six layers in fp32) as the yardstick.
+    deterministic=True: the whole measurement with torch.backends.cudnn.deterministic (MIOpen's deterministic convolution
+    algorithms): round 6 found that the stand-in network's PyTorch kernels are NOT run-to-run reproducible by default on this
+    GPU (two identical runs of the reference path are 2.4e-3 apart at the UNet output, 0.015 in the latents after one step)
+    and ARE with this switch -- only then does a difference between two paths measure the paths and not the library."""
+    prev = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+    if deterministic:
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    try:
+        return _measure_latent_delta(h, modes, deterministic)
+    finally:
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = prev
+
+
+def _measure_latent_delta(h, modes, deterministic):
     out = {}
     for tag, f32 in (("fp16_latents", False), ("fp32_latents", True)):
         ours = h.loop("ours", modes, f32)
@@ -326,7 +379,10 @@ def measure_latent_delta(h, modes=LOOP_MODES):
     out["steps"] = len(modes)
     out["modes"] = modes
     out["init"] = h.init
+    out["pytorch_algorithms"] = "deterministic (torch.backends.cudnn.deterministic)" if deterministic else "default"
     out["standin_gain"] = measure_gain(h)
+    if not deterministic:
+        out["run_to_run"] = measure_repeatability(h)
     out["eps_level_step1"] = measure_eps_level(h)
     out["bar"] = ("per step: delta <= 1.5 x the reference path's own fp16 noise + 1e-3 (tests/test_gpu_latent_delta.py); the north "
                   "star's absolute 1e-3 holds per layer call (torch_gpu_baseline.max_abs_delta), not over a loop: the reference op "
@@ -393,14 +449,20 @@ def measure(N=8, R=512, dev="cuda", with_opt=True, with_delta=True, verbose=Fals
         del targets
     if with_delta:
         res["latent_delta"] = measure_latent_delta(h)
+        det = measure_latent_delta(h, deterministic=True)
+        res["latent_delta"]["deterministic_algorithms"] = {k: det[k] for k in ("fp32_latents", "fp16_latents", "standin_gain",
+                                                                                "eps_level_step1", "pytorch_algorithms")}
         # the same six steps on a UNIT-GAIN stand-in (variance-preserving initialisation): does the north star's absolute
         # 1e-3 hold over the loop when the network itself does not amplify?
         del h
         torch.cuda.empty_cache()
         h = Harness(N, R, dev, init="unit_gain")
         ug = measure_latent_delta(h)
+        ugd = measure_latent_delta(h, deterministic=True)
         res["latent_delta"]["unit_gain_standin"] = dict(
             fp32_latents=ug["fp32_latents"], fp16_latents=ug["fp16_latents"], standin_gain=ug["standin_gain"],
+            run_to_run=ug["run_to_run"],
+            deterministic_algorithms={k: ugd[k] for k in ("fp32_latents", "fp16_latents", "standin_gain", "eps_level_step1")},
             eps_level_step1=ug["eps_level_step1"],
             note="tools/standin_unet.reinit_unit_gain: N(0, 1 / fan_in) weights, residual branches damped to 0.3 -- the same "
                  "module tree, the same six steps, the same comparison")

@@ -3,7 +3,7 @@ for N in 4 8; do
   echo "== N=$N rc=$?"; python - <<PY
 import json
 try:
-    r=json.load(open("gpurun_out/bench_gloo$N.json"))
+    r=json.loads([l for l in open("gpurun_out/bench_gloo$N.json").read().splitlines() if l.startswith("{")][-1])
     print({k:r[k] for k in ("value","n_gpus","ms_per_step")}, r["sharded_vs_single_gpu_max_abs_delta"]["per_mode"], r["rank_census"]["ranks_seen"], r["exchange_timing"].get("form"), {k:v for k,v in r["cfg5"].items() if k in ("value","ms_per_step","error")}, r.get("graph_replay"), r["collectives_per_step"])
 except Exception as e:
     print("no json:", e)
