@@ -48,7 +48,14 @@ struct ProjCfg {
     // 128-byte lines (8 lanes per row); rows padded to 144 B (conflict-free ds_write_b128 of 16 rows)
     static constexpr int OROW = TF * 2 + 16;
     static constexpr int OSCR = 32 * OROW;                // per wave
-    static constexpr int BIAS_OFF = RING_BYTES + NWV * OSCR;  // [nw][N] halfs follow
+    // round 6: a wave's 32 rows of x reach their MFMA fragments through a per-wave LDS region -- coalesced global loads
+    // (consecutive lanes = consecutive 16-byte pieces of a row), K chunk by K chunk, rows of XROW bytes (an odd number of
+    // 16-byte chunks: conflict-free ds_read_b128).  The region is the wave's epilogue scratch later.
+    static constexpr int XROW = KC * 2 + 16;
+    static constexpr int XST = 32 * XROW;                 // per wave (>= OSCR)
+    static constexpr int XPL = 32 * (KC / 8) / 64;        // staging loads per lane and K chunk
+    static_assert(XST >= OSCR && (32 * (KC / 8)) % 64 == 0, "staging region");
+    static constexpr int BIAS_OFF = RING_BYTES + NWV * XST;  // [nw][N] halfs follow
 };
 
 template <int N_>
@@ -77,16 +84,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
     // wave takes k = hi*KC/2 + 8*ks .. +7 -- 160 contiguous bytes per lane and chunk instead of 16 out of
     // every 32.
     half8_t xf[Cfg::NXF];
-    {
-        // (x_rows: problem row m reads input row x_rows[m] -- the gathered form, e.g. K / V of the selected tokens only)
-        const int rr = row < M ? row : M - 1;
-        const half_t* xp = x + (int64_t)(x_rows ? x_rows[rr] : rr) * x_ld + hi * (Cfg::KC / 2);
-#pragma unroll
-        for (int kc = 0; kc < Cfg::NKC; ++kc)
-#pragma unroll
-            for (int ks = 0; ks < Cfg::KS; ++ks)
-                xf[kc * Cfg::KS + ks] = *reinterpret_cast<const half8_t*>(xp + kc * Cfg::KC + ks * 8);
-    }
     // A-tile row (lane & 31) is fed with weight row swap_bits_2_3(lane & 31): the 16 accumulator registers
     // of a lane then cover features 8*hi + (0..7) and 16 + 8*hi + (0..7) of its 32-row half of the tile
     const int frow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
@@ -149,6 +146,81 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
     stage(0, 0);
     if (AHEAD > 1 && nsteps > 1) stage(1, 1);
     if (AHEAD > 2 && nsteps > 2) stage(2, 2);
+    // ---- x fragments (after the first weight slabs have been requested: their DMA runs under the x loads)
+#ifndef FRESCO_PROJ_X_DIRECT
+#define FRESCO_PROJ_X_DIRECT 0
+#endif
+    if (FRESCO_PROJ_X_DIRECT) {
+        // (rounds 1-5, kept as an A/B build switch: every lane loads its own row's fragments straight from global memory --
+        // 64 rows one row stride apart per instruction; the texture-address path serves that at ~9 B/clk/CU: 7.6 us for the
+        // 164 KB of a workgroup at K = 320, 15 us for the 328 KB at K = 640)
+        const int rr = row < M ? row : M - 1;
+        const half_t* xp = x + (int64_t)(x_rows ? x_rows[rr] : rr) * x_ld + hi * (Cfg::KC / 2);
+#pragma unroll
+        for (int kc = 0; kc < Cfg::NKC; ++kc)
+#pragma unroll
+            for (int ks = 0; ks < Cfg::KS; ++ks)
+                xf[kc * Cfg::KS + ks] = *reinterpret_cast<const half8_t*>(xp + kc * Cfg::KC + ks * 8);
+    } else {
+        // (x_rows: problem row m reads input row x_rows[m] -- the gathered form, e.g. K / V of the selected tokens only)
+        // Piece q = j * 64 + lane of the wave's 32 x (KC / 8) pieces of a K chunk: row q / (KC / 8), piece q % (KC / 8) --
+        // consecutive lanes read consecutive 16 bytes of a row (KC * 2 contiguous bytes per row: ~10 lines per instruction
+        // instead of 64).  The next chunk's loads are in flight while this chunk goes through LDS.
+        constexpr int PPR = Cfg::KC / 8;
+        char* xst = smem + Cfg::RING_BYTES + wave * Cfg::XST;
+        const int row0w = blockIdx.x * (NWV * 32) + wave * 32;
+        uint32_t src16[Cfg::XPL];  // source piece index (16-byte units from x: x_ld % 8 == 0; tensors below 64 GB)
+        int dst[Cfg::XPL];
+#pragma unroll
+        for (int j = 0; j < Cfg::XPL; ++j) {
+            const int q = j * 64 + lane;
+            const int r = q / PPR, dc = q % PPR;
+            const int rr = min(row0w + r, M - 1);
+            src16[j] = (uint32_t)((int64_t)(x_rows ? x_rows[rr] : rr) * (x_ld >> 3) + dc);
+            dst[j] = r * Cfg::XROW + dc * 16;
+        }
+        // (plain macros, not lambdas over array references: hipcc keeps such arrays in scratch memory)
+#define PROJ_LOAD_CHUNK(KCI, T)                                                              \
+    _Pragma("unroll") for (int j = 0; j < Cfg::XPL; ++j)                                      \
+        T[j] = *reinterpret_cast<const xu4_t*>(x + ((int64_t)src16[j] << 3) + (KCI) * Cfg::KC);
+#define PROJ_FLUSH_CHUNK(KCI, T)                                                             \
+    {                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < Cfg::XPL; ++j)                                  \
+            *reinterpret_cast<xu4_t*>(xst + dst[j]) = T[j];                                   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                               \
+        __builtin_amdgcn_wave_barrier();                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                               \
+        _Pragma("unroll") for (int ks = 0; ks < Cfg::KS; ++ks)                                \
+            xf[(KCI) * Cfg::KS + ks] = *reinterpret_cast<const half8_t*>(                     \
+                xst + l31 * Cfg::XROW + (hi * (Cfg::KC / 2) + ks * 8) * 2);                   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                               \
+        __builtin_amdgcn_wave_barrier(); /* the region is rewritten by the next chunk */     \
+    }
+        static_assert(Cfg::NKC == 2 || Cfg::NKC == 4, "staging schedule written for 2 or 4 K chunks");
+        typedef unsigned int xu4_t __attribute__((ext_vector_type(4)));  // (a native vector: arrays of HIP's uint4 struct
+                                                                         // stay in scratch memory across the fences)
+        // every K chunk's loads are in flight before the first one goes through LDS: a staged register is dead when its
+        // fragment register becomes live, so the total stays at the K / 8 x 4 registers the fragments need anyway
+        xu4_t ta[Cfg::XPL], tb[Cfg::XPL];
+        PROJ_LOAD_CHUNK(0, ta)
+        PROJ_LOAD_CHUNK(1, tb)
+        if constexpr (Cfg::NKC == 4) {
+            xu4_t tc[Cfg::XPL], td[Cfg::XPL];
+            PROJ_LOAD_CHUNK(2, tc)
+            PROJ_LOAD_CHUNK(3, td)
+            __builtin_amdgcn_sched_barrier(0);  // (hipcc sinks loads to their uses: keep the batches in front)
+            PROJ_FLUSH_CHUNK(0, ta)
+            PROJ_FLUSH_CHUNK(1, tb)
+            PROJ_FLUSH_CHUNK(2, tc)
+            PROJ_FLUSH_CHUNK(3, td)
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            PROJ_FLUSH_CHUNK(0, ta)
+            PROJ_FLUSH_CHUNK(1, tb)
+        }
+#undef PROJ_LOAD_CHUNK
+#undef PROJ_FLUSH_CHUNK
+    }
     // biases -> LDS once (a global load inside the tile loop would make the compiler drain vmcnt there, DMA included)
     half_t* bias_s = reinterpret_cast<half_t*>(smem + Cfg::BIAS_OFF);
     const bool has_bias = b0 || b1 || b2;
@@ -160,7 +232,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
             bias_s[i] = bp ? bp[i - jb * N] : (half_t)0.f;
         }
     }
-    char* scr = smem + Cfg::RING_BYTES + wave * Cfg::OSCR;
+    char* scr = smem + Cfg::RING_BYTES + wave * Cfg::XST;  // (the wave's x staging region, free by now)
     wait_barrier(min(nsteps - 1, AHEAD - 1));
     int slot = 0, s = 0;
     for (int ft = ft0; ft < ft1; ++ft) {
@@ -226,7 +298,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_kernel(
             const int row0 = blockIdx.x * (NWV * 32) + wave * 32;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = i * 8 + (lane >> 3), ch = lane & 7;
+                int r = i * 8 + (lane >> 3);
+                const int ch = lane & 7;
+                // (keeps the 64-bit row addresses of the four stores INSIDE the tile loop: hoisted, they cost the K = 640
+                // instantiation -- 160 resident x registers -- a spill that is reloaded in every tile's store path)
+                asm volatile("" : "+v"(r));
                 const half8_t w = *reinterpret_cast<const half8_t*>(scr + r * Cfg::OROW + ch * 16);
                 if (row0 + r < M) *reinterpret_cast<half8_t*>(op + (int64_t)(row0 + r) * ld + col + ch * 8) = w;
             }
