@@ -26,6 +26,12 @@
 // (65536, 320), 56.5 vs 52.9 at (16384, 640), ties (+-1 us) on the gathered K|V launches and on to_out.  With K = 320
 // a tile's K loop is 10 chunks: DMA prologue and store epilogue per tile outweigh what the deeper ring and the second
 // workgroup per CU buy, and x is re-streamed 7.5 times.  Removed again; the resident-x form stays.
+// Round 6: the resident x fragments are no longer loaded lane-per-row straight from global memory (64 rows one row stride
+// apart per instruction: the texture-address path serves that at ~9 B/clk/CU -- profiles/r06_kvproj_ablation.txt) but in
+// coalesced form (consecutive lanes = consecutive 16 bytes of a row) through a per-wave LDS region, all K chunks' loads in
+// flight before the first goes through LDS, the weight slabs' DMA prologue requested in front of them.  Same fragments, same
+// MFMA order: bit-identical outputs.  (16384, 640): single projection 29.9 -> 25.2 us, q,k,v 54.6 -> 49.8; (65536, 320),
+// HBM-bound in that phase: 59.0 -> 58.8 (profiles/r06_ab_proj_x_staging.txt; -DFRESCO_PROJ_X_DIRECT=1 builds the old form).
 #include "common.h"
 
 namespace fresco {
