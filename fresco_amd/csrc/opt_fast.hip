@@ -468,6 +468,208 @@ __global__ __launch_bounds__(NW * 64) void gram16s_kernel(const half_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// gram16s_kernel with COALESCED operand loads (round 6).  gram16s loads its MFMA fragments straight from global memory, a
+// lane per row: 64 rows one row stride apart per instruction, which a CU's texture-address path serves at ~9 B/clk
+// (profiles/r06_kvproj_ablation.txt; 256 workgroups x 640 KB in 30 us at (1280, 16^2) is exactly that rate).  Here the
+// workgroup loads the NW k-steps of a round -- one per wave: [rows][NW * 16 channels] = NW * 32 contiguous bytes per row --
+// cooperatively and coalesced (consecutive lanes = consecutive 16 bytes of a row) into LDS, double-buffered through
+// registers, and every wave reads ITS k-step's fragments from there: the same k-steps, the same three products per step in
+// the same order, the same reduction -- bit-identical signs (tested against gram16s_kernel).  LDS: two buffers of
+// [A hi | A lo | B hi | B lo][64 rows][NW * 32 + 16 bytes] (odd 16-byte row stride), later the partial-tile buffer.
+// grid (nt*nt, 1, B), NW*64 threads.
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+struct GramCCfg {
+    static constexpr int RS = NW * 32 + 16;          // LDS bytes per staged row
+    static constexpr int BLK = 64 * RS;              // one operand block
+    static constexpr int BUF = 4 * BLK;
+    static constexpr int PPR = NW * 2;               // 16-byte pieces per row and round
+    static constexpr int NLD = 4 * 64 * PPR / (NW * 64);  // loads per thread and round (= 8)
+    static constexpr int RED = NW * 64 * GS_RS * 4;  // the partial-tile buffer of the reduction
+    static constexpr int LDS = 2 * BUF > RED ? 2 * BUF : RED;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gram16c_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
+                                                          const float* __restrict__ target, int8_t* __restrict__ sgn_out,
+                                                          float* __restrict__ loss, int C, int hw, int s_tiled) {
+    using G = GramCCfg<NW>;
+    extern __shared__ __attribute__((aligned(16))) char gc_smem[];
+    float* gs_red = reinterpret_cast<float*>(gc_smem);  // (after the K loop)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nt = hw / 64;
+    // Workgroup ids go round-robin to the 8 XCDs, each with its own L2: with the tile index fastest, the nt * nt tiles of a
+    // plane land on all eight, and every L2 pulls every plane's operand rows through the fabric (8 x 21 MB at (1280, 16^2):
+    // the launch ran at the fabric's rate, not the CUs').  All tiles of a plane on ONE XCD when the planes divide by 8.
+    int tile = blockIdx.x, b = blockIdx.z;
+    if (gridDim.z % 8 == 0) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+        const int xcd = lin & 7, slot = lin >> 3;
+        b = xcd + 8 * (slot / (int)gridDim.x);
+        tile = slot % (int)gridDim.x;
+    }
+    const int ti = tile / nt, tj = tile % nt;
+    const int p0 = ti * 64, q0 = tj * 64;
+    const half_t* hb = vph + (int64_t)b * hw * C;
+    const half_t* lb = vpl + (int64_t)b * hw * C;
+    typedef unsigned int gu4_t __attribute__((ext_vector_type(4)));
+
+    // this thread's NLD pieces of a round: (block, row, piece) -> source element offset (without the round's k offset),
+    // LDS byte offset inside a buffer
+    int64_t soff[G::NLD];
+    int doff[G::NLD], kpc[G::NLD];
+    const half_t* sbase[G::NLD];
+#pragma unroll
+    for (int j = 0; j < G::NLD; ++j) {
+        const int q = j * (NW * 64) + tid;
+        const int blk = q / (64 * G::PPR), rem = q % (64 * G::PPR);
+        const int row = rem / G::PPR, pc = rem % G::PPR;
+        sbase[j] = (blk & 1) ? lb : hb;                                   // blocks: A hi, A lo, B hi, B lo
+        soff[j] = (int64_t)((blk < 2 ? p0 : q0) + row) * C + pc * 8;
+        kpc[j] = pc * 8;
+        doff[j] = blk * G::BLK + row * G::RS + pc * 16;
+    }
+    const int nks = C / 16;
+    const int rounds = (nks + NW - 1) / NW;
+    // Three rounds of loads are in flight (three register sets), two rounds live in LDS: a round's products are ~0.2 us of
+    // matrix work, an L2 round trip ~2 us -- one round ahead left the loop latency-bound (30 -> 25 us at (1280, 16^2))
+#define GC_LOAD(RR_, TT_)                                                                          \
+    {                                                                                              \
+        const int k0_ = (RR_) * NW * 16;                                                           \
+        _Pragma("unroll") for (int j = 0; j < G::NLD; ++j) {                                        \
+            gu4_t v_ = {0u, 0u, 0u, 0u};                                                           \
+            if ((RR_) < rounds && k0_ + kpc[j] < C)                                                \
+                v_ = *reinterpret_cast<const gu4_t*>(sbase[j] + soff[j] + k0_);                    \
+            TT_[j] = v_;                                                                           \
+        }                                                                                          \
+    }
+#define GC_STORE(BI_, TT_)                                                                         \
+    _Pragma("unroll") for (int j = 0; j < G::NLD; ++j)                                              \
+        *reinterpret_cast<gu4_t*>(gc_smem + (BI_) * G::BUF + doff[j]) = TT_[j];
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    auto compute = [&](int r) __attribute__((always_inline)) {
+        const int ks = r * NW + wave;
+        if (ks < nks) {
+            const char* L = gc_smem + (r & 1) * G::BUF + wave * 32 + hi * 16;
+            half8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const half8_t*>(L + 0 * G::BLK + (i * 32 + l31) * G::RS);
+                al[i] = *reinterpret_cast<const half8_t*>(L + 1 * G::BLK + (i * 32 + l31) * G::RS);
+                bh[i] = *reinterpret_cast<const half8_t*>(L + 2 * G::BLK + (i * 32 + l31) * G::RS);
+                bl[i] = *reinterpret_cast<const half8_t*>(L + 3 * G::BLK + (i * 32 + l31) * G::RS);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {  // (the product order of gram16s_kernel)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+                }
+        }
+    };
+
+    gu4_t s0[G::NLD], s1[G::NLD], s2[G::NLD];
+    GC_LOAD(0, s0)
+    GC_LOAD(1, s1)
+    GC_LOAD(2, s2)
+    __builtin_amdgcn_sched_barrier(0);  // (hipcc sinks loads to their uses: keep the batches in front)
+    GC_STORE(0, s0)
+    __syncthreads();
+    // round r reads LDS buffer r & 1; the set that held round r + 1 is written to the other buffer behind the products of
+    // round r (its readers finished in round r - 1: the barrier at the end of that round ordered them)
+    for (int r = 0; r < rounds; r += 3) {
+        GC_LOAD(r + 3, s0)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(r);
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 1 >= rounds) break;
+        GC_STORE((r + 1) & 1, s1)
+        __syncthreads();
+        GC_LOAD(r + 4, s1)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(r + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 2 >= rounds) break;
+        GC_STORE((r + 2) & 1, s2)
+        __syncthreads();
+        GC_LOAD(r + 5, s2)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(r + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 3 >= rounds) break;
+        GC_STORE((r + 3) & 1, s0)
+        __syncthreads();
+    }
+#undef GC_LOAD
+#undef GC_STORE
+    __syncthreads();  // every wave is done with the staging buffers: they become the partial-tile buffer
+
+    // ---- reduction, target, signs: gram16s_kernel's epilogue (the staging buffers are dead: the loop ended on a barrier)
+    float* mine = gs_red + (size_t)wave * 64 * GS_RS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * GS_RS + jj * 32 + l31] = acc[i][jj][r];
+    __syncthreads();
+    float lsum = 0.f;
+    if (tid < 256) {  // 256 pieces of 16 consecutive entries of one row
+        const int row = tid >> 2, cq = (tid & 3) * 16;
+        float g[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) g[e] = 0.f;
+        for (int w = 0; w < NW; ++w) {  // fixed order
+            const float* src = gs_red + ((size_t)w * 64 + row) * GS_RS + cq;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const floatx4 t = *reinterpret_cast<const floatx4*>(src + e4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e4 * 4 + e] += t[e];
+            }
+        }
+        const int gp = p0 + row, gq = q0 + cq;
+        const float* tg = target + ((int64_t)b * hw + gp) * hw + gq;
+        u32x4 packed;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const floatx4 t = *reinterpret_cast<const floatx4*>(tg + e4 * 4);
+            uint32_t wv = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = g[e4 * 4 + e] - t[e];
+                lsum += fabsf(d);
+                wv |= (uint32_t)(uint8_t)sign_byte(d) << (8 * e);
+            }
+            packed[e4] = wv;
+        }
+        s_store_piece(sgn_out, packed, b, gp, gq, hw, s_tiled);
+    }
+    if (loss) {
+        const float tot = wave_sum(lsum);
+        __syncthreads();
+        if (lane == 0) gs_red[wave] = tot;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += gs_red[w];
+            atomicAdd(loss, t);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same Gram step for planes of ONE 64 x 64 tile (the 8 x 8 input of up_blocks.0) as two launches (round 6).  At
 // batch 16 gram16s_kernel is 16 workgroups: 16 CUs issue all of the launch's row-strided 16-byte fragment loads, which a
 // CU's texture-address unit sustains at ~9 B/clk (profiles/r06_kvproj_ablation.txt measured the same rate for the same
@@ -1474,12 +1676,36 @@ void opt_fast_closure(const OptWs& w, float* cs, const float* fwd_flow, const fl
             // (the wave count is the split of the contraction, i.e. part of the arithmetic: chosen by the size of the WHOLE
             // problem, so that one CFG half alone, or a rank's frame shard, rounds exactly as the undivided batch does)
             // 8 waves (an 8-way split of K) up to 16 x 16 planes at batch 16: the launch is a latency chain of K steps
+            // FRESCO_GRAM_COOP (read per call; tests): "0" = gram16s_kernel's lane-per-row fragment loads (rounds 3-5),
+            // default = gram16c_kernel's coalesced cooperative staging (same bits)
+            const char* co_env = getenv("FRESCO_GRAM_COOP");
+            const bool coop = !(co_env && co_env[0] == '0');
             const char* sp_env = getenv("FRESCO_GRAM_SPLIT_WG");  // (read per call: "0" keeps the one-launch form; tests)
             if (nt * nt * Bg < 512 && nt * nt * planes <= 64 && w.gpart && !gloss && hw <= 64 && !(sp_env && sp_env[0] == '0')) {
                 // one 64 x 64 tile per plane: every split-K slice on a CU of its own, then the ordered sum (same bits)
                 hipLaunchKernelGGL(gram16sp_kernel<8>, dim3(nt * nt, 8, planes), dim3(64), 0, st, w.vph, w.vpl, w.gpart, C, hw);
                 hipLaunchKernelGGL(gram16sr_kernel, dim3(nt * nt, 1, planes), dim3(256), 0, st, w.gpart, target, w.ssign, 8, hw,
                                    cm_tiled ? 1 : 0);
+            } else if (coop && nt * nt * Bg < 512) {
+                constexpr int lds = GramCCfg<8>::LDS;
+                static const bool once = [] {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16c_kernel<8>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    return true;
+                }();
+                (void)once;
+                hipLaunchKernelGGL(gram16c_kernel<8>, dim3(nt * nt, 1, planes), dim3(512), lds, st, w.vph, w.vpl, target,
+                                   w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
+            } else if (coop) {
+                constexpr int lds = GramCCfg<4>::LDS;
+                static const bool once = [] {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16c_kernel<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    return true;
+                }();
+                (void)once;
+                hipLaunchKernelGGL(gram16c_kernel<4>, dim3(nt * nt, 1, planes), dim3(256), lds, st, w.vph, w.vpl, target,
+                                   w.ssign, gloss, C, hw, cm_tiled ? 1 : 0);
             } else if (nt * nt * Bg < 512) {
                 constexpr int lds = 8 * 64 * GS_RS * 4;
                 static const bool once = [] {

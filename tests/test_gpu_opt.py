@@ -281,3 +281,32 @@ def test_split_workgroup_gram_of_one_tile_planes_is_bit_identical(N, monkeypatch
     ref = outs[("0", "0")]
     for k, v in outs.items():
         assert torch.equal(ref, v), (k, int((ref != v).sum()))
+
+
+@pytest.mark.parametrize("N,C,h,w", [(8, 1280, 16, 16), (16, 256, 16, 16), (4, 96, 8, 16), (8, 1280, 8, 8), (3, 40, 8, 8)])
+def test_cooperative_gram_staging_is_bit_identical(N, C, h, w, monkeypatch):
+    """Round 6: gram16c_kernel stages the operands of gram16s_kernel's k-steps cooperatively, with coalesced loads, through
+    LDS instead of loading every fragment lane-per-row from global memory: the same k-steps per wave, the same products in
+    the same order, the same reduction -- the features after 10 Adam iterations must be IDENTICAL.  8-wave and 4-wave split
+    (batch 16 / 32 at 16 x 16), a K that is not a whole number of rounds (C = 96, 40), one-tile planes with the split-
+    workgroup form on and off."""
+    import fresco_amd.ops as ops
+    from fresco_amd.warp import _prep_flow_occ
+    g = synth.gen(N * 1000 + C + h)
+    x = torch.randn(2 * N, C, h, w, generator=g)
+    bwd = torch.tensor([0.8, -1.2]).view(1, 2, 1, 1) + 0.3 * torch.randn(N, 2, 4 * h, 4 * w, generator=g)
+    flows = [-bwd, bwd]
+    occs = [(torch.rand(N, 4 * h, 4 * w, generator=g) < 0.1).float() for _ in range(2)]
+    target = O.gram_target(torch.randn(2 * N, C, h, w, generator=g)).to(DEV)
+    prep = _prep_flow_occ(h, [f.to(DEV) for f in flows], [o.to(DEV) for o in occs], with_dilate=False)
+    outs = {}
+    for coop in ("0", "1"):
+        for splitwg in ("0", "1"):
+            monkeypatch.setenv("FRESCO_GRAM_COOP", coop)
+            monkeypatch.setenv("FRESCO_GRAM_SPLIT_WG", splitwg)
+            cs = x.to(DEV).clone()
+            ops.opt_run(cs, prep, target, 100.0, 10, 2)
+            outs[(coop, splitwg)] = cs
+    ref = outs[("0", "0")]
+    for k, v in outs.items():
+        assert torch.equal(ref, v), (k, int((ref != v).sum()))
