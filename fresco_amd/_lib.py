@@ -71,6 +71,9 @@ SIGNATURES = {
     "fresco_chan_mean_std": (_i, [_vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "fresco_opt_workspace_bytes": (_sz, [_i] * 7),
     "fresco_opt_run": (_i, [_vp] * 7 + [_sz, _i, _i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _vp]),
+    "fresco_ctx_create": (_i, [_vp]),
+    "fresco_ctx_destroy": (_i, [_vp]),
+    "fresco_opt_run_ctx": (_i, [_vp] * 8 + [_sz, _i, _i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _vp]),
     "fresco_opt_loss_grad": (_i, [_vp] * 9 + [_sz, _i, _i, _i, _i, _i, _f, _vp]),
     "fresco_opt_sharded_workspace_bytes": (_sz, [_i] * 7),
     "fresco_opt_sharded_begin": (_i, [_vp] * 5 + [_sz, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -23,6 +23,7 @@
 //   v_mfma_f32_32x32x16_f16 per fp32-accurate product, operands by LDS-DMA from pre-tiled copies, 16 waves per CU)
 //   adam_update    temporal gradient + norm backward + Adam step, fused, fp32 state
 #include "opt_shared.h"
+#include <new>
 #include <stdlib.h>
 #include <atomic>
 
@@ -1001,19 +1002,14 @@ static OptWs ws_half(const OptWs& w, int ck0, int N, int NP, int C, int hw) {
 // free-running pipelines fall back into lockstep within two iterations (profiles/r04_opt_trace_split.txt);
 // 4: as 3, and a half's adam (+ next prep) additionally waits for the OTHER half's Gram launch to finish, so that the
 // HBM-bound launches run beside the S V launch (the least memory-hungry one), never beside a Gram launch.
-struct SideStream {
-    std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call at a time uses the side stream; a concurrent caller runs on one stream
+struct SideStream {  // = the caller's fresco_ctx: nothing of this is process-wide any more (round 6; SURVEY 8b: "no global state")
+    std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call at a time uses a context; a concurrent caller on the SAME context runs on one stream
+    int device = -1;                           // the device its stream / events were created on (first use)
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
     hipEvent_t sv_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // [half][iteration parity]
     hipEvent_t gram_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][iteration parity]
 };
-static SideStream* side_stream() {  // (the slot of the current device; its stream / events are created by its first owner)
-    static SideStream tab[32];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    return &tab[dev];
-}
 static void side_stream_destroy(SideStream& t) {  // call with t.busy held
     auto drop = [](hipEvent_t& e) {
         if (e) (void)hipEventDestroy(e);
@@ -1028,7 +1024,10 @@ static void side_stream_destroy(SideStream& t) {  // call with t.busy held
     t.s = nullptr;
 }
 static bool side_stream_ready(SideStream& t) {  // call with t.busy held
-    if (t.s) return true;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (t.s) return t.device == dev;  // (a context serves the device it was first used on; elsewhere: one stream)
+    t.device = dev;
     if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) {
         t.s = nullptr;
         return false;
@@ -1053,11 +1052,10 @@ static int opt_split_mode(int planes_hw) {
     return planes_hw >= 2048 ? 1 : 0;  // (8 frames: 16 x 16 planes and up; 2.83 -> 2.70, 9.3 -> 8.3, 29.9 -> 29.8 ms per layer; 8 x 8 planes are launch-bound)
 }
 
-extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
-                              const float* bwd_occ, const float* target, void* workspace,
-                              size_t workspace_bytes, int chunk, int N, int C, int h, int w,
-                              float intra_weight, int iters, float lr, float beta1, float beta2, float eps,
-                              void* stream) {
+static int opt_run_impl(SideStream* ctx, float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                        const float* bwd_occ, const float* target, void* workspace, size_t workspace_bytes, int chunk,
+                        int N, int C, int h, int w, float intra_weight, int iters, float lr, float beta1, float beta2,
+                        float eps, void* stream) {
     int has_t = 0, has_s = 0;
     if (int rc = opt_common_checks(cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, workspace,
                                    workspace_bytes, chunk, N, C, h, w, &has_t, &has_s, intra_weight))
@@ -1073,7 +1071,7 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
     const TLayout L = {N, N, 1, nullptr, nullptr};
     if (opt_fast_ok(C, h, w, has_s)) {
         const int hw = h * w;
-        SideStream* sd = (chunk == 2 && !prof_active() && iters > 0) ? side_stream() : nullptr;
+        SideStream* sd = (chunk == 2 && !prof_active() && iters > 0) ? ctx : nullptr;  // (no context: one stream)
         int split = sd ? opt_split_mode(N * hw) : 0;
         if (split && sd->busy.test_and_set(std::memory_order_acquire)) split = 0;  // (another host thread owns the side stream)
         struct Release {
@@ -1162,6 +1160,45 @@ extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd
         opt_closure(ws, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, chunk, N, C, h, w, intra_weight,
                     has_t, has_s, 0, nullptr, nullptr, adam_args(it, lr, beta1, beta2, eps), st, L, chunk * N);
     return check_launch();
+}
+
+extern "C" int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                              const float* bwd_occ, const float* target, void* workspace,
+                              size_t workspace_bytes, int chunk, int N, int C, int h, int w,
+                              float intra_weight, int iters, float lr, float beta1, float beta2, float eps,
+                              void* stream) {
+    return opt_run_impl(nullptr, cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, workspace, workspace_bytes, chunk, N, C, h,
+                        w, intra_weight, iters, lr, beta1, beta2, eps, stream);
+}
+
+extern "C" int fresco_ctx_create(void** ctx) {
+    if (!ctx) return FRESCO_EINVAL;
+    *ctx = new (std::nothrow) SideStream();
+    return *ctx ? FRESCO_OK : FRESCO_EINVAL;
+}
+
+extern "C" int fresco_ctx_destroy(void* ctx) {
+    if (!ctx) return FRESCO_OK;
+    SideStream* t = static_cast<SideStream*>(ctx);
+    if (t->busy.test_and_set(std::memory_order_acquire)) return FRESCO_EINVAL;  // (in use by a call)
+    if (t->s) {
+        int cur = -1;
+        const bool sw = hipGetDevice(&cur) == hipSuccess && cur != t->device && t->device >= 0;
+        if (sw) (void)hipSetDevice(t->device);
+        (void)hipStreamSynchronize(t->s);
+        side_stream_destroy(*t);
+        if (sw) (void)hipSetDevice(cur);
+    }
+    delete t;
+    return FRESCO_OK;
+}
+
+extern "C" int fresco_opt_run_ctx(void* ctx, float* cs, const float* fwd_flow, const float* bwd_flow, const float* fwd_occ,
+                                  const float* bwd_occ, const float* target, void* workspace, size_t workspace_bytes,
+                                  int chunk, int N, int C, int h, int w, float intra_weight, int iters, float lr,
+                                  float beta1, float beta2, float eps, void* stream) {
+    return opt_run_impl(static_cast<SideStream*>(ctx), cs, fwd_flow, bwd_flow, fwd_occ, bwd_occ, target, workspace,
+                        workspace_bytes, chunk, N, C, h, w, intra_weight, iters, lr, beta1, beta2, eps, stream);
 }
 
 extern "C" int fresco_opt_loss_grad(const float* cs, const float* fwd_flow, const float* bwd_flow,

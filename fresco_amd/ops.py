@@ -74,6 +74,43 @@ class Workspace:
         return self.buf
 
 
+class OptContext:
+    """A fresco_ctx (include/fresco_hip.h): the side stream + events the two-pipeline form of fresco_opt_run_ctx uses.  Owned
+    by the caller -- the library keeps no process-wide stream table; one context per host thread and device."""
+
+    def __init__(self):
+        import ctypes
+        p = ctypes.c_void_p()
+        _lib.check(_lib.load().fresco_ctx_create(ctypes.byref(p)), "fresco_ctx_create")
+        self.ptr = p
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                _lib.load().fresco_ctx_destroy(self.ptr)
+                self.ptr = None
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+class _PerThreadContexts:
+    def __init__(self):
+        import threading
+        self._tls = threading.local()
+
+    def get(self, device):
+        table = getattr(self._tls, "table", None)
+        if table is None:
+            table = self._tls.table = {}
+        ctx = table.get(device)
+        if ctx is None:
+            ctx = table[device] = OptContext()
+        return ctx
+
+
+_opt_contexts = _PerThreadContexts()
+
+
 class _PerStreamWorkspace:
     """Default scratch when the caller passes none: one grow-only buffer per (thread, device, stream), so
     that concurrent callers on different streams or threads never share scratch memory."""
@@ -745,7 +782,7 @@ def _opt_args(cs, prep, target, chunk):
 
 
 def opt_run(cs, prep, target, intra_weight, iters, chunk, lr=0.2, betas=(0.9, 0.999), eps=1e-8,
-            workspace=None):
+            workspace=None, context=None):
     """`iters` Adam steps on cs (chunk*N, C, h, w) fp32 contiguous, in place (fresco_opt_run).
     prep = (fwd_flow, bwd_flow, fwd_occ, bwd_occ) at feature resolution, or None."""
     _need_gpu(cs)
@@ -755,7 +792,8 @@ def opt_run(cs, prep, target, intra_weight, iters, chunk, lr=0.2, betas=(0.9, 0.
     has_t, has_s = int(prep is not None), int(target is not None and intra_weight > 0)
     nbytes = lib.fresco_opt_workspace_bytes(chunk, N, C, h, w, has_t, has_s)
     ws = (workspace or _default_ws).get(nbytes, cs.device)
-    rc = lib.fresco_opt_run(cs.data_ptr(), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
+    ctx = context or _opt_contexts.get(cs.device)
+    rc = lib.fresco_opt_run_ctx(ctx.ptr, cs.data_ptr(), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
                             _ptr(target), ws.data_ptr(), ws.numel(), chunk, N, C, h, w, float(intra_weight),
                             int(iters), float(lr), float(betas[0]), float(betas[1]), float(eps), _stream())
     _lib.check(rc, "fresco_opt_run(chunk=%d,N=%d,C=%d,h=%d,w=%d)" % (chunk, N, C, h, w))

@@ -350,10 +350,14 @@ int fresco_chan_mean_std(const void* x, float* mean, float* stdv, int rows, int 
  *   iters Adam steps (lr, beta1, beta2, eps as torch.optim.Adam); no autograd: analytic
  *   gradients.  The adjoint of the bilinear warp is evaluated as a deterministic gather over a
  *   per-call CSR of the tap matrix (no atomics), so results are run-to-run reproducible.
- *   With chunk == 2 and N * h * w >= 2048 fresco_opt_run runs the two CFG halves (independent
- *   problems) as two pipelines: one on `stream`, one on an internal side stream that is forked from
- *   and joined back into `stream` by events inside the call -- the caller sees ordinary stream order
- *   (FRESCO_OPT_SPLIT=0 keeps everything on `stream`; the results are bit-identical either way).
+ *   fresco_opt_run keeps everything on `stream` and touches no state outside its arguments.
+ *   fresco_opt_run_ctx(ctx, ...) -- the same call with a context (fresco_ctx_create / _destroy: a side stream + events,
+ *   created on first use on the device current then, owned by the CALLER; round 6: the library keeps no process-wide
+ *   stream table any more) -- runs, with chunk == 2 and N * h * w >= 2048, the two CFG halves (independent problems) as two
+ *   pipelines: one on `stream`, one on the context's side stream, forked from and joined back into `stream` by events
+ *   inside the call -- the caller sees ordinary stream order (FRESCO_OPT_SPLIT=0 keeps everything on `stream`; the
+ *   results are bit-identical either way).  One call at a time per context (a second concurrent call on the same context,
+ *   or a call on another device than the context's, runs on one stream); use one context per host thread / stream.
  *
  *   fresco_opt_loss_grad evaluates the closure once: grad (same shape as cs) and, if loss != NULL,
  *   loss[0] = temporal term, loss[1] = spatial term (device floats).  Test / debugging entry.
@@ -367,6 +371,15 @@ int fresco_opt_run(float* cs, const float* fwd_flow, const float* bwd_flow,
                    int chunk, int N, int C, int h, int w,
                    float intra_weight, int iters, float lr, float beta1, float beta2, float eps,
                    void* stream);
+
+int fresco_ctx_create(void** ctx);
+int fresco_ctx_destroy(void* ctx); /* waits for the context's stream; FRESCO_EINVAL while a call is using it */
+int fresco_opt_run_ctx(void* ctx, float* cs, const float* fwd_flow, const float* bwd_flow,
+                       const float* fwd_occ, const float* bwd_occ, const float* target,
+                       void* workspace, size_t workspace_bytes,
+                       int chunk, int N, int C, int h, int w,
+                       float intra_weight, int iters, float lr, float beta1, float beta2, float eps,
+                       void* stream);
 
 int fresco_opt_loss_grad(const float* cs, const float* fwd_flow, const float* bwd_flow,
                          const float* fwd_occ, const float* bwd_occ, const float* target,

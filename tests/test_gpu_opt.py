@@ -310,3 +310,44 @@ def test_cooperative_gram_staging_is_bit_identical(N, C, h, w, monkeypatch):
     ref = outs[("0", "0")]
     for k, v in outs.items():
         assert torch.equal(ref, v), (k, int((ref != v).sum()))
+
+
+def test_opt_context_owns_the_side_stream():
+    """Round 6 (no global state): the two-pipeline form of the Adam loop runs on a side stream that belongs to a
+    caller-owned context (fresco_ctx_create / fresco_opt_run_ctx); the context-free entry fresco_opt_run keeps everything on
+    the caller's stream.  Same bits either way, and two host threads with a context each run side by side."""
+    import threading
+    import fresco_amd.ops as ops
+    from fresco_amd import _lib
+    from fresco_amd.warp import _prep_flow_occ
+    case = synth.make_opt_case(4, 128, 32, 128, seed=9)   # N * hw = 4096 >= 2048: the two-stream form is taken with a context
+    x = case["x"].to(DEV)
+    prep = _prep_flow_occ(32, [f.to(DEV) for f in case["flows"]], [o.to(DEV) for o in case["occs"]], with_dilate=False)
+    tgt = case["target"].to(DEV)
+    a = x.clone()
+    ops.opt_run(a, prep, tgt, 100.0, 6, 2, context=ops.OptContext())
+    # the context-free C entry
+    lib = _lib.load()
+    b = x.clone()
+    nbytes = lib.fresco_opt_workspace_bytes(2, 4, 128, 32, 32, 1, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    rc = lib.fresco_opt_run(b.data_ptr(), prep[0].data_ptr(), prep[1].data_ptr(), prep[2].data_ptr(), prep[3].data_ptr(),
+                            tgt.data_ptr(), ws.data_ptr(), ws.numel(), 2, 4, 128, 32, 32, 100.0, 6, 0.2, 0.9, 0.999, 1e-8,
+                            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    outs = [None, None]
+
+    def work(i):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            c = x.clone()
+            ops.opt_run(c, prep, tgt, 100.0, 6, 2, workspace=ops.Workspace(), context=ops.OptContext())
+            st.synchronize()
+            outs[i] = c
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert torch.equal(outs[0], a) and torch.equal(outs[1], a)
