@@ -490,7 +490,7 @@ struct GramCCfg {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void gram16c_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
+__global__ __launch_bounds__(NW * 64, 2) void gram16c_kernel(const half_t* __restrict__ vph, const half_t* __restrict__ vpl,
                                                           const float* __restrict__ target, int8_t* __restrict__ sgn_out,
                                                           float* __restrict__ loss, int C, int hw, int s_tiled) {
     using G = GramCCfg<NW>;
