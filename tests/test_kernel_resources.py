@@ -63,9 +63,10 @@ def test_gram_and_sv_kernels_fit_four_waves_per_simd(tmp_path):
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 128 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
     # the small-plane Gram kernels of round 6: 8-wave / 4-wave workgroups, one per CU by LDS -> two waves per SIMD
-    for pat in (r"gram16c_kernelILi8E", r"gram16c_kernelILi4E", r"gram16sp_kernelILi8E"):
+    # (gram16sp: one-wave workgroups, one per CU at the batch it is used for -- a whole SIMD's registers are its own)
+    for pat, cap in ((r"gram16c_kernelILi8E", 256), (r"gram16c_kernelILi4E", 256), (r"gram16sp_kernelILi8E", 512)):
         r = _one(k, pat)
-        assert r["vgpr"] + r["agpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
+        assert r["vgpr"] + r["agpr"] <= cap and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
     for pat in (r"gram16z_kernelILb0E", r"gram16z_kernelILb1E"):  # launch_bounds(256, 3): three 4-wave workgroups per CU
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 168 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
