@@ -88,7 +88,10 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                                                          int K, int act, float acc_scale, float split_scale,
                                                          double* __restrict__ stats, const void* __restrict__ zeros,
                                                          const int32_t* __restrict__ a_rows,
-                                                         const int32_t* __restrict__ out_rows, int32_t* range_flag) {
+                                                         const int32_t* __restrict__ out_rows, int32_t* range_flag,
+                                                         int out_cb, int64_t out_bs) {
+    // out_cb > 0 (fp32 output only): the N columns are out_cb-wide BLOCKS that go to separate (M, out_cb) matrices out_bs
+    // floats apart (row stride ldc) -- q | k | v of one source in ONE product, each landing in a matrix of its own
     // a_rows / out_rows (linear layers; NULL = identity): problem row m reads input row a_rows[m] and its results go to output
     // row out_rows[m] -- the token gather / scatter of the (shifted-)window attention folded into the projections around it
     constexpr int BM = FN_BM, BK = FN_BK, NS = FN_NS;
@@ -252,7 +255,13 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                 if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU() (exact, erf form)
                 acc[i][j][r] = v;
                 const bool ok = nok && m < M;
-                if (out && ok) out[(int64_t)((out_rows && m < M) ? out_rows[m] : m) * ldc + n] = v;
+                if (out && ok) {
+                    const int64_t mrow = (int64_t)((out_rows && m < M) ? out_rows[m] : m) * ldc;
+                    if (out_cb > 0)
+                        out[(int64_t)(n / out_cb) * out_bs + mrow + (n % out_cb)] = v;
+                    else
+                        out[mrow + n] = v;
+                }
                 if (stats && ok) {
                     s1 += (double)v;
                     s2 += (double)v * (double)v;
@@ -556,13 +565,16 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
                               const float* bias, float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M,
                               int N, int K, int act, float acc_scale, float split_scale, int n_img, int H, int W, int kh,
                               int kw, int stride, int pad, void* stats, const void* zeros, const int32_t* a_rows,
-                              const int32_t* out_rows, int32_t* range_flag, void* stream) {
+                              const int32_t* out_rows, int32_t* range_flag, int out_col_block, int64_t out_block_stride,
+                              void* stream) {
     if (!zeros) return FRESCO_EINVAL;
     if ((a_rows || out_rows) && (kh > 0 || stats)) return FRESCO_EUNSUPPORTED;
     if (!a_hi || !a_lo || !w_hi || !w_lo || (!out && !out_hi) || (out_hi && !out_lo) || M <= 0 || N <= 0 || K <= 0)
         return FRESCO_EINVAL;
     if (K % 32 != 0 || lda % 8 != 0 || act < 0 || act > 2) return FRESCO_EUNSUPPORTED;
-    if ((out && ldc < N) || (out_hi && ldo < N)) return FRESCO_EINVAL;
+    if (out_col_block < 0 || (out_col_block > 0 && (!out || N % out_col_block != 0 || ldc < out_col_block || out_block_stride <= 0)))
+        return FRESCO_EINVAL;
+    if ((out && out_col_block == 0 && ldc < N) || (out_hi && ldo < N)) return FRESCO_EINVAL;
     if (out_hi && (N % 8 != 0 || ldo % 8 != 0)) return FRESCO_EUNSUPPORTED;
     FnConv cv = {0, 0, 1, 0, 0, 0, 0, 0, 0, 0};
     if (kh > 0) {
@@ -595,14 +607,16 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
-                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows, range_flag);
+                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows, range_flag, out_col_block,
+                           out_block_stride);
     } else {
         constexpr int BN = 128;
         const int lds = FN_NS * (2 * FN_BM * 64 + 2 * BN * 64);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
-                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows, range_flag);
+                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows, range_flag, out_col_block,
+                           out_block_stride);
     }
     return check_launch();
 }

@@ -247,6 +247,22 @@ class _Weights:
         self.cache[key] = (stamp, val, bad)
         return val
 
+    def get_stacked(self, params):
+        """planes of the row-stacked weights of several nn.Linear layers of one input (q | k | v as ONE product): the
+        single layers' planes concatenated, cached per version of every member"""
+        key = tuple(id(p) for p in params) + ("stack",)
+        stamps = tuple(self._stamp(p) for p in params)
+        hit = self.cache.get(key)
+        if hit is not None and None not in stamps and hit[0] == stamps:
+            self.out_of_range |= hit[2]
+            return hit[1]
+        parts = [self.get(p, "lin") for p in params]
+        bad = any(self.cache[(id(p), "lin")][2] for p in params)
+        val = (torch.cat([h for h, _ in parts], 0).contiguous(), torch.cat([l for _, l in parts], 0).contiguous())
+        self.out_of_range |= bad
+        self.cache[key] = (stamps, val, bad)
+        return val
+
 
 def _conv(wts, x_split, conv, n, H, W, stride, act=0, want_f32=True, want_split=False, pad_cin=None, norm=None):
     """Conv2d on the NHWC tensor behind the planes x_split -> rows (n * OH * OW, cout); norm: the InstanceNorm2d module that
@@ -310,9 +326,22 @@ def _layer_native(layer, wts, src, src_s, tgt_s, grows):
     B, L, C = src.shape
     table, spans = grows
     lin = lambda p: wts.get(p.weight, "lin")
-    q, _ = ops.fn_gemm(src_s, lin(layer.q_proj), C, C, a_rows=table)
-    k, _ = ops.fn_gemm(tgt_s, lin(layer.k_proj), C, C, a_rows=table)
-    v, _ = ops.fn_gemm(tgt_s, lin(layer.v_proj), C, C, a_rows=table)
+    # q | k | v of one source (self-attention) as ONE product with three output matrices, k | v of the other image's tokens
+    # (cross-attention) as one with two: the operand rows are read once instead of three / two times (round 6)
+    fuse = os.environ.get("FRESCO_GMFLOW_FUSE_QKV", "1") != "0"  # (A/B switch)
+    if fuse and src_s is tgt_s:
+        qkv, _ = ops.fn_gemm(src_s, wts.get_stacked((layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight)), 3 * C, C,
+                             a_rows=table, out_blocks=3)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+    elif fuse:
+        q, _ = ops.fn_gemm(src_s, lin(layer.q_proj), C, C, a_rows=table)
+        kv, _ = ops.fn_gemm(tgt_s, wts.get_stacked((layer.k_proj.weight, layer.v_proj.weight)), 2 * C, C, a_rows=table,
+                            out_blocks=2)
+        k, v = kv[0], kv[1]
+    else:
+        q, _ = ops.fn_gemm(src_s, lin(layer.q_proj), C, C, a_rows=table)
+        k, _ = ops.fn_gemm(tgt_s, lin(layer.k_proj), C, C, a_rows=table)
+        v, _ = ops.fn_gemm(tgt_s, lin(layer.v_proj), C, C, a_rows=table)
     scale = 1.0 / math.sqrt(C)
     outs_ = []
     for off, G, n in spans:

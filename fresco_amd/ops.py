@@ -426,7 +426,7 @@ def fn_colstats(x, n_img, eps=1e-5):
 
 
 def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want_split=False, out_split=None,
-            instance_norm_eps=None, a_rows=None, out_rows=None, out_f32=None):
+            instance_norm_eps=None, a_rows=None, out_rows=None, out_f32=None, out_blocks=0):
     """act(A W^T + bias) (fresco_fn_gemm).  a = (hi, lo) planes, (rows, lda); w = (hi, lo) planes (N, K).
     conv = (n_img, H, W, kh, kw, stride, pad): implicit im2col of the NHWC tensor behind `a` (K = kh kw cin).
     a_rows / out_rows (linear layers): int32 (M) tables -- problem row m reads input row a_rows[m], writes output row
@@ -450,7 +450,16 @@ def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want
     bias = _fn_f32_operand(bias, "bias", ah)
     a_rows = _fn_rows_table(a_rows, "a_rows", ah, M)
     out_rows = _fn_rows_table(out_rows, "out_rows", ah, M)
-    out = out_f32 if out_f32 is not None else (torch.empty(M, N, dtype=torch.float32, device=dev) if want_f32 else None)
+    # out_blocks = n > 1: W holds n stacked projections; the result is (n, M, N / n) fp32 -- every projection's rows contiguous
+    ocb, obs, ldc = 0, 0, N
+    if out_blocks and out_blocks > 1:
+        if N % out_blocks or out_f32 is not None or want_split or out_split is not None or conv is not None:
+            raise ValueError("fn_gemm: out_blocks needs a plain fp32 linear product whose N divides into the blocks")
+        ocb = N // out_blocks
+        out = torch.empty(out_blocks, M, ocb, dtype=torch.float32, device=dev)
+        obs, ldc = M * ocb, ocb
+    else:
+        out = out_f32 if out_f32 is not None else (torch.empty(M, N, dtype=torch.float32, device=dev) if want_f32 else None)
     oh = ol = None
     ldo = N
     if out_split is not None:
@@ -467,9 +476,9 @@ def fn_gemm(a, w, N, K, bias=None, act=0, conv=None, M=None, want_f32=True, want
         zeros = _fn_zero_page[dev] = torch.zeros(64, dtype=torch.float16, device=dev)
     lib = _lib.load()
     rc = lib.fresco_fn_gemm(ah.data_ptr(), al.data_ptr(), lda, wh.data_ptr(), wl.data_ptr(), _ptr(bias), _ptr(out),
-                            _ptr(oh), _ptr(ol), N, int(ldo), M, N, K, int(act), 1.0 / (FN_A_SCALE * FN_W_SCALE),
+                            _ptr(oh), _ptr(ol), int(ldc), int(ldo), M, N, K, int(act), 1.0 / (FN_A_SCALE * FN_W_SCALE),
                             FN_A_SCALE, *cargs, _ptr(stats), zeros.data_ptr(), _ptr(a_rows), _ptr(out_rows),
-                            _fn_flag_ptr(dev), _stream())
+                            _fn_flag_ptr(dev), int(ocb), int(obs), _stream())
     _lib.check(rc, "fresco_fn_gemm(M=%d,N=%d,K=%d,conv=%s)" % (M, N, K, conv))
     res = (out, ((oh, ol) if oh is not None else None))
     if instance_norm_eps is None:

@@ -267,7 +267,11 @@ int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, const void* 
                    float* out, void* out_hi, void* out_lo, int64_t ldc, int64_t ldo, int M, int N, int K, int act,
                    float acc_scale, float split_scale, int n_img, int H, int W, int kh, int kw, int stride, int pad,
                    void* stats, const void* zeros, const int32_t* a_rows, const int32_t* out_rows, int32_t* range_flag,
-                   void* stream);
+                   int out_col_block, int64_t out_block_stride, void* stream);
+/* out_col_block > 0 (fp32 output only, N % out_col_block == 0): column n of the product goes to matrix n / out_col_block of
+ * out_col_block columns (row stride ldc >= out_col_block), the matrices out_block_stride floats apart -- several projections of
+ * one input as ONE product (W = their weight rows stacked), every projection's rows contiguous (round 6: q | k | v and k | v of the
+ * flow network's attention layers).  0: one (M, ldc) matrix. */
 
 /* nn.InstanceNorm2d statistics (affine=False, biased variance): x (n_img * rows, C) fp32 NHWC -> mean, rstd = 1 / sqrt(var +
  * eps), (n_img, C) each.  fp64 partial sums in a fixed order.  C <= 256. */

@@ -234,3 +234,29 @@ def test_fn_side_operands_are_checked():
         ops.fn_gemm(xs, ws, 128, 128, a_rows=torch.arange(64, device=DEV))           # int64 table
     with pytest.raises(ValueError):
         ops.fn_gemm(xs, ws, 128, 128, bias=b.cpu())
+
+
+def test_fn_gemm_stacked_projections_in_one_product():
+    """Round 6: q | k | v of one input as ONE product (weights stacked, out_blocks = 3): every projection lands in a matrix of its
+    own, bit-identical to three separate products (a column's accumulation does not depend on the tiling of N); with a
+    row table, as the flow network's window attention uses it."""
+    import fresco_amd.ops as ops
+    g = synth.gen(31)
+    M, C = 3000, 128
+    x = torch.randn(M, C, generator=g).to(DEV)
+    ws = [(torch.randn(C, C, generator=g) * 0.05).to(DEV) for _ in range(3)]
+    table = torch.randperm(M, generator=g).to(torch.int32).to(DEV)
+    _, xs = ops.fn_prep(x)
+    planes = [ops.fn_prep(w, scale=ops.FN_W_SCALE)[1] for w in ws]
+    stacked = (torch.cat([p[0] for p in planes], 0).contiguous(), torch.cat([p[1] for p in planes], 0).contiguous())
+    for nb in (3, 2):
+        st = (stacked[0][: nb * C].contiguous(), stacked[1][: nb * C].contiguous())
+        fused, _ = ops.fn_gemm(xs, st, nb * C, C, a_rows=table, out_blocks=nb)
+        assert tuple(fused.shape) == (nb, M, C)
+        for i in range(nb):
+            single, _ = ops.fn_gemm(xs, planes[i], C, C, a_rows=table)
+            assert torch.equal(fused[i], single), i
+    ref = x.double()[table.long()] @ ws[1].double().t()
+    assert float((fused[1].double() - ref).abs().max()) < _bar(x.abs().double()[table.long()] @ ws[1].abs().double().t())
+    with pytest.raises(ValueError):
+        ops.fn_gemm(xs, stacked, 3 * C, C, out_blocks=3, want_split=True)
