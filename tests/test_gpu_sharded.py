@@ -4,6 +4,7 @@ whose FrameShard collectives are barrier-synchronised in-process exchanges, so t
 _unpack around the trajectory all-to-all) and the processor's sharded branch are exercised exactly as under RCCL.  Result must equal the single-GPU
 processor's rows for the same global batch."""
 import copy
+import os
 import threading
 
 import pytest
@@ -223,3 +224,73 @@ def test_sharded_warp_tensor_replicas():
     assert not errs, errs
     for sel, o in outs:
         assert torch.equal(o, ref.index_select(0, sel))
+
+
+def _opt_worker(rank, world, port, N, ret, backend="gloo"):
+    """one REAL process per rank (gloo, both on cuda:0: collectives staged through the host): the frame-sharded
+    optimize_feature with the overlapped neighbour exchange, against the single-process loop computed by rank 0"""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev_index = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fresco_amd
+        from fresco_amd.dist import FrameShard
+        case = synth.make_opt_case(N, 24, 16, 64, seed=11)
+        x = case["x"].to(DEV)
+        flows = [f.to(DEV) for f in case["flows"]]
+        occs = [o.to(DEV) for o in case["occs"]]
+        target = case["target"].to(DEV)
+        sh = FrameShard(N, 2, rank, world)
+        sel = sh.local_batch_index().to(DEV)
+        out = fresco_amd.optimize_feature(x.index_select(0, sel).contiguous(), flows, occs,
+                                          [target.index_select(0, sel).contiguous()], iters=4, shard=sh)
+        torch.cuda.synchronize()
+        ref = fresco_amd.optimize_feature(x, flows, occs, [target], iters=4)
+        slab = 2 * x.shape[1] * x.shape[2] * x.shape[3] * 4
+        single = sh.n_loc == 1 and world == 2
+        ok = torch.equal(out, ref.index_select(0, sel))
+        ok = ok and sh.halo_exchanges == 4 and sh.halo_bytes_received == 4 * (1 if single else 2) * slab
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N", [4, 2])
+def test_sharded_optimize_feature_two_processes_gloo(N):
+    """the same check with REAL processes and a real process group (gloo: the collectives go through host memory), so that
+    dist.batch_isend_irecv, the tags of the two messages to one peer and the start / finish protocol run as they will under
+    RCCL; N = 2: one frame per rank (one message serves both halos)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_opt_worker, args=(2, port, N, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.skipif(os.environ.get("FRESCO_TEST_RCCL") != "1" or torch.cuda.device_count() < 2,
+                    reason="opt-in (FRESCO_TEST_RCCL=1) and needs two GPUs: the build and test boxes have one")
+@pytest.mark.parametrize("N", [4, 2])
+def test_sharded_optimize_feature_two_processes_rccl(N):
+    """the same on RCCL, one GPU per rank: opt-in, for whoever has a multi-GPU node (no builder box has had one)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_opt_worker, args=(2, port, N, ret, "nccl"), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
