@@ -239,29 +239,36 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
         const int n = n0 + wn * WN + j * 32 + l31;
         bcol[j] = (bias && n < N) ? bias[n] : 0.f;
     }
+    // The output row of every accumulator register, BEFORE the stores (-1: a row outside the problem).  With the out_rows
+    // table looked up inside the store loop hipcc put an s_waitcnt vmcnt(0) in front of every store -- on this target it
+    // counts stores as well, so the 32 x NB stores of a lane left one at a time, each behind the previous one's round trip:
+    // ~19 us of a 27 us workgroup at (65536, 128, 128), with or without a table (round 6, tools/ubench_fn_gemm.py).
+    int orow[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = fn_row_of(cv, blockIdx.x, wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+            orow[i][r] = m < M ? ((out && out_rows) ? out_rows[m] : m) : -1;
+        }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
         const bool nok = n < N;
+        // this lane's output column: matrix n / out_cb, column n % out_cb when the product is split into column blocks
+        float* ocol = out;
+        if (out) ocol += out_cb > 0 ? (int64_t)(n / out_cb) * out_bs + (n % out_cb) : (int64_t)n;
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int m = fn_row_of(cv, blockIdx.x, rl);
                 float v = acc[i][j][r] * acc_scale + bcol[j];
                 if (act == 1) v = fmaxf(v, 0.f);
                 if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU() (exact, erf form)
                 acc[i][j][r] = v;
-                const bool ok = nok && m < M;
-                if (out && ok) {
-                    const int64_t mrow = (int64_t)((out_rows && m < M) ? out_rows[m] : m) * ldc;
-                    if (out_cb > 0)
-                        out[(int64_t)(n / out_cb) * out_bs + mrow + (n % out_cb)] = v;
-                    else
-                        out[mrow + n] = v;
-                }
+                const bool ok = nok && orow[i][r] >= 0;
+                if (out && ok) ocol[(int64_t)orow[i][r] * ldc] = v;
                 if (stats && ok) {
                     s1 += (double)v;
                     s2 += (double)v * (double)v;
@@ -279,6 +286,12 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
     if (o_hi) {
         constexpr int PPR = WN / 8;  // 16-byte pieces per row
         bool sat = false;
+        int prow[PPR];  // (as orow above: the rows of this lane's transposed pieces, looked up before any store)
+#pragma unroll
+        for (int it = 0; it < PPR; ++it) {
+            const int m = fn_row_of(cv, blockIdx.x, wm * 64 + (it * 64 + lane) / PPR);
+            prow[it] = m < M ? (out_rows ? out_rows[m] : m) : -1;
+        }
 #pragma unroll
         for (int plane = 0; plane < 2; ++plane) {
 #pragma unroll
@@ -297,10 +310,10 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
 #pragma unroll
             for (int it = 0; it < PPR; ++it) {
                 const int id = it * 64 + lane, rr = id / PPR, pc = id % PPR;
-                const int m = fn_row_of(cv, blockIdx.x, wm * 64 + rr), n = n0 + wn * WN + pc * 8;
+                const int n = n0 + wn * WN + pc * 8;
                 const half8_t v8 = *reinterpret_cast<const half8_t*>(tp + rr * TROW + pc * 16);
-                if (m < M && n < N)  // (N % 8 == 0: launcher)
-                    *reinterpret_cast<half8_t*>(op + (int64_t)(out_rows ? out_rows[m] : m) * ldo + n) = v8;
+                if (prow[it] >= 0 && n < N)  // (N % 8 == 0: launcher)
+                    *reinterpret_cast<half8_t*>(op + (int64_t)prow[it] * ldo + n) = v8;
             }
         }
         // (accumulators of rows / columns outside the problem are products with the zero page: never out of range)

@@ -1290,7 +1290,27 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
         if (kc + 1 < nk) store(st ^ 1);
         __syncthreads();
     }
-    // epilogue: dV^T, and (dotp) this workgroup's share of <V, dV> per pixel: the sum over its 128 channels
+    // epilogue: dV^T, and (dotp) this workgroup's share of <V, dV> per pixel: the sum over its 128 channels.
+    // The V values of the lane's 64 elements are loaded BEFORE the first store (round 6): with the two loads behind every
+    // store hipcc waited with vmcnt(0) in front of each fmaf -- on this target that counter covers the stores as well, so the 64
+    // (store, load, load) groups of a lane ran one behind the other's round trip: ~11 of the launch's 19 us on the 8 x 8
+    // planes.  Same products, same accumulation order: identical bits.
+    float vv[2][2][16];
+    if (dotp) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = p0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = c0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    vv[mi][ni][r] = (row < C && col < hw)
+                                        ? (float)vhb[(int64_t)row * hw + col] + (float)vlb[(int64_t)row * hw + col]
+                                        : 0.f;
+                }
+            }
+    }
     float dsum[2] = {0.f, 0.f};
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -1304,7 +1324,7 @@ __global__ __launch_bounds__(256) void sv16_kernel(const half_t* __restrict__ vh
                     const int64_t o = ((int64_t)b * C + row) * hw + col;
                     const float val = acc[mi][ni][r] * alpha;
                     dvt[o] = val;
-                    if (dotp) dsum[ni] = fmaf(val, (float)vhb[(int64_t)row * hw + col] + (float)vlb[(int64_t)row * hw + col], dsum[ni]);
+                    if (dotp) dsum[ni] = fmaf(val, vv[mi][ni][r], dsum[ni]);
                 }
             }
         }
