@@ -79,7 +79,17 @@ __device__ __forceinline__ void fn_wait_barrier() {
 // on the read side (fragment piece p of row R sits at position p ^ ((R >> 2) & 3)): conflict-free ds_read_b128 in the b128
 // lane groups.  Rows outside the problem (m >= M, n >= N, the zero padding of a convolution) are fetched from a 16-byte
 // page of zeros.
-template <int BN>
+//
+// PATCH (3 x 3, stride 1, pad 1 convolutions on maps of whole 16 x 16 patches): the im2col view re-reads every input pixel
+// nine times -- 32 KB of A pieces per 32-wide K chunk, and with a 3-slot ring only two chunks in flight per CU, the loop
+// runs at the DMA's latency (13 B/clk/CU at 256^2), not at the matrix pipe's rate.  This form turns the K loop inside out
+// -- channel chunks OUTER, the nine taps INNER -- and keeps the 18 x 18 input window of the patch, 32 channels deep, in
+// LDS: 324 pixel rows of 64 bytes per plane, fetched ONCE per channel chunk (two slots: chunk c + 1 arrives, one piece per
+// tap step, under the taps of chunk c), the A fragments of tap (ky, kx) are ds_read_b128 at pixel (oy + ky, ox + kx).
+// Only the weights still stream per step (their own 3-slot ring): 4.6 + 8 KB per step instead of 32 + 8.  Window pixel
+// P = 18 py + px keeps its 16-byte pieces at position piece ^ ((py + 2 (P >> 2)) & 3): conflict-free for all nine taps
+// in the ds_read_b128 lane groups (searched by enumeration; (P >> 2) & 3 alone is 2-way on four of the taps).
+template <int BN, bool PATCH>
 __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restrict__ a_hi, const half_t* __restrict__ a_lo,
                                                          int64_t lda, FnConv cv, const half_t* __restrict__ w_hi,
                                                          const half_t* __restrict__ w_lo, const float* __restrict__ bias,
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                                                          double* __restrict__ stats, const void* __restrict__ zeros,
                                                          const int32_t* __restrict__ a_rows,
                                                          const int32_t* __restrict__ out_rows, int32_t* range_flag,
-                                                         int out_cb, int64_t out_bs) {
+                                                         int out_cb, int64_t out_bs, int rb, int nb, int xmap) {
     // out_cb > 0 (fp32 output only): the N columns are out_cb-wide BLOCKS that go to separate (M, out_cb) matrices out_bs
     // floats apart (row stride ldc) -- q | k | v of one source in ONE product, each landing in a matrix of its own
     // a_rows / out_rows (linear layers; NULL = identity): problem row m reads input row a_rows[m] and its results go to output
@@ -104,77 +114,40 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.y * BN;
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
-
-    // ---- DMA sources.  A: this wave copies pieces 2 wave, 2 wave + 1 of both A planes (16 rows each); a lane owns LDS
-    // position q = lane & 3 of row R = 16 piece + (lane >> 2) and fetches source piece q ^ ((R >> 2) & 3) of that row
-    const int q = lane & 3;
-    int a_pc[2], a_iy[2], a_ix[2];
-    int64_t a_base[2];
-    bool a_ok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int R = (2 * wave + i) * 16 + (lane >> 2);
-        a_pc[i] = q ^ ((R >> 2) & 3);
-        const int m = fn_row_of(cv, blockIdx.x, R);
-        a_ok[i] = m < M;
-        const int mm = a_ok[i] ? m : 0;
-        if (cv.kh == 0) {
-            a_base[i] = (int64_t)(a_rows ? a_rows[mm] : mm) * lda;
-            a_iy[i] = a_ix[i] = 0;
+    // Workgroup -> (row block bx, column block by).  The grid is 1-D and the hardware deals consecutive workgroups to the 8
+    // XCDs in turn, each with an L2 of its own: with nb > 1 column blocks, XCD x takes row blocks x, x + 8, .. and walks
+    // the nb column blocks of one row block back to back, so the 256 x K operand rows are fetched into ONE L2 once and hit
+    // there nb - 1 times (column block outermost, the plain order, re-reads the whole A from HBM / MALL nb times: at
+    // (65536, 1024, 256) 536 MB instead of 67).  The last rb % 8 row blocks keep the plain order.
+    int bx, by;
+    {
+        const int L = blockIdx.x, full = (rb >> 3) * 8 * nb;
+        if (nb == 1) {
+            bx = L;
+            by = 0;
+        } else if (!xmap) {
+            by = L / rb;
+            bx = L - by * rb;
+        } else if (L < full) {
+            const int j = L >> 3;
+            bx = (j / nb) * 8 + (L & 7);
+            by = j % nb;
         } else {
-            const int ohw = cv.OH * cv.OW;
-            const int img = mm / ohw, r = mm - img * ohw;
-            const int oy = r / cv.OW, ox = r - oy * cv.OW;
-            a_iy[i] = oy * cv.stride - cv.pad;
-            a_ix[i] = ox * cv.stride - cv.pad;
-            a_base[i] = (int64_t)img * cv.H * cv.W;
+            const int t = L - full;
+            bx = (rb >> 3) * 8 + t / nb;
+            by = t % nb;
         }
     }
+    const int n0 = by * BN;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+
+    const int q = lane & 3;
     // W: BN = 128: piece `wave` of both W planes; BN = 64: waves 0-3 piece `wave` of W hi, waves 4-7 piece wave - 4 of W lo
     const int w_piece = BN == 128 ? wave : (wave & 3);
     const int w_R = w_piece * 16 + (lane >> 2);
     const int w_pc = q ^ ((w_R >> 2) & 3);
     const bool w_ok = n0 + w_R < N;
     const int64_t w_off = (int64_t)(w_ok ? n0 + w_R : 0) * K + w_pc * 8;
-    const int nk = K / BK;
-
-    auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
-        const int k0 = kc * BK;
-        int ky = 0, kx = 0, c0 = k0;
-        if (cv.kh != 0) {  // a 32-channel chunk lies inside one (ky, kx): cin % 32 == 0
-            const int t = k0 / cv.cin;
-            c0 = k0 - t * cv.cin;
-            ky = t / cv.kw;
-            kx = t - ky * cv.kw;
-        }
-        const uint32_t sb = lds0 + (uint32_t)(slot * SLOT);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bool ok = a_ok[i];
-            int64_t off;
-            if (cv.kh == 0) {
-                off = a_base[i] + k0 + a_pc[i] * 8;
-            } else {
-                const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-                ok = ok && iy >= 0 && iy < cv.H && ix >= 0 && ix < cv.W;
-                off = (a_base[i] + (int64_t)iy * cv.W + ix) * lda + c0 + a_pc[i] * 8;
-            }
-            const void* ph = ok ? static_cast<const void*>(a_hi + off) : zeros;
-            const void* pl = ok ? static_cast<const void*>(a_lo + off) : zeros;
-            fn_dma16(ph, sb + (uint32_t)((2 * wave + i) * 1024));
-            fn_dma16(pl, sb + (uint32_t)(A_PL + (2 * wave + i) * 1024));
-        }
-        if (BN == 128) {
-            fn_dma16(w_ok ? static_cast<const void*>(w_hi + w_off + k0) : zeros, sb + (uint32_t)(2 * A_PL + wave * 1024));
-            fn_dma16(w_ok ? static_cast<const void*>(w_lo + w_off + k0) : zeros, sb + (uint32_t)(2 * A_PL + W_PL + wave * 1024));
-        } else {
-            const half_t* wp = wave < 4 ? w_hi : w_lo;
-            fn_dma16(w_ok ? static_cast<const void*>(wp + w_off + k0) : zeros,
-                     sb + (uint32_t)(2 * A_PL + (wave < 4 ? 0 : W_PL) + (wave & 3) * 1024));
-        }
-    };
 
     floatx16 acc[2][NB];
 #pragma unroll
@@ -184,45 +157,213 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
     const int sw = (l31 >> 2) & 3;
-    int slot = 0;
-    for (int kc = 0; kc < nk; ++kc) {
-        // own pieces of chunk kc have landed (what may still fly: chunk kc + 1's), then everyone's, and every wave is done
-        // with chunk kc - 1: its slot takes chunk kc + 2
-        if (kc + 1 < nk)
-            fn_wait_barrier<NPW>();
-        else
-            fn_wait_barrier<0>();
-        if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : NS - 1);
-        const char* s = smem + slot * SLOT;
-        const char* sa = s + (wm * 64 + l31) * 64;
-        const char* sw_ = s + 2 * A_PL + (wn * WN + l31) * 64;
+    if constexpr (!PATCH) {
+        // ---- DMA sources.  A: this wave copies pieces 2 wave, 2 wave + 1 of both A planes (16 rows each); a lane owns LDS
+        // position q = lane & 3 of row R = 16 piece + (lane >> 2) and fetches source piece q ^ ((R >> 2) & 3) of that row
+        int a_pc[2], a_iy[2], a_ix[2];
+        int64_t a_base[2];
+        bool a_ok[2];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int pos = ((ks * 2 + hi) ^ sw) * 16;
-            half8_t ah[2], al[2], bh[NB], bl[NB];
+        for (int i = 0; i < 2; ++i) {
+            const int R = (2 * wave + i) * 16 + (lane >> 2);
+            a_pc[i] = q ^ ((R >> 2) & 3);
+            const int m = fn_row_of(cv, bx, R);
+            a_ok[i] = m < M;
+            const int mm = a_ok[i] ? m : 0;
+            if (cv.kh == 0) {
+                a_base[i] = (int64_t)(a_rows ? a_rows[mm] : mm) * lda;
+                a_iy[i] = a_ix[i] = 0;
+            } else {
+                const int ohw = cv.OH * cv.OW;
+                const int img = mm / ohw, r = mm - img * ohw;
+                const int oy = r / cv.OW, ox = r - oy * cv.OW;
+                a_iy[i] = oy * cv.stride - cv.pad;
+                a_ix[i] = ox * cv.stride - cv.pad;
+                a_base[i] = (int64_t)img * cv.H * cv.W;
+            }
+        }
+        const int nk = K / BK;
+        auto stage = [&](int kc, int slot) __attribute__((always_inline)) {
+            const int k0 = kc * BK;
+            int ky = 0, kx = 0, c0 = k0;
+            if (cv.kh != 0) {  // a 32-channel chunk lies inside one (ky, kx): cin % 32 == 0
+                const int t = k0 / cv.cin;
+                c0 = k0 - t * cv.cin;
+                ky = t / cv.kw;
+                kx = t - ky * cv.kw;
+            }
+            const uint32_t sb = lds0 + (uint32_t)(slot * SLOT);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const half8_t*>(sa + i * 32 * 64 + pos);
-                al[i] = *reinterpret_cast<const half8_t*>(sa + A_PL + i * 32 * 64 + pos);
+                bool ok = a_ok[i];
+                int64_t off;
+                if (cv.kh == 0) {
+                    off = a_base[i] + k0 + a_pc[i] * 8;
+                } else {
+                    const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+                    ok = ok && iy >= 0 && iy < cv.H && ix >= 0 && ix < cv.W;
+                    off = (a_base[i] + (int64_t)iy * cv.W + ix) * lda + c0 + a_pc[i] * 8;
+                }
+                const void* ph = ok ? static_cast<const void*>(a_hi + off) : zeros;
+                const void* pl = ok ? static_cast<const void*>(a_lo + off) : zeros;
+                fn_dma16(ph, sb + (uint32_t)((2 * wave + i) * 1024));
+                fn_dma16(pl, sb + (uint32_t)(A_PL + (2 * wave + i) * 1024));
             }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                bh[j] = *reinterpret_cast<const half8_t*>(sw_ + j * 32 * 64 + pos);
-                bl[j] = *reinterpret_cast<const half8_t*>(sw_ + W_PL + j * 32 * 64 + pos);
+            if (BN == 128) {
+                fn_dma16(w_ok ? static_cast<const void*>(w_hi + w_off + k0) : zeros, sb + (uint32_t)(2 * A_PL + wave * 1024));
+                fn_dma16(w_ok ? static_cast<const void*>(w_lo + w_off + k0) : zeros, sb + (uint32_t)(2 * A_PL + W_PL + wave * 1024));
+            } else {
+                const half_t* wp = wave < 4 ? w_hi : w_lo;
+                fn_dma16(w_ok ? static_cast<const void*>(wp + w_off + k0) : zeros,
+                         sb + (uint32_t)(2 * A_PL + (wave < 4 ? 0 : W_PL) + (wave & 3) * 1024));
             }
+        };
+
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        int slot = 0;
+        for (int kc = 0; kc < nk; ++kc) {
+            // own pieces of chunk kc have landed (what may still fly: chunk kc + 1's), then everyone's, and every wave is done
+            // with chunk kc - 1: its slot takes chunk kc + 2
+            if (kc + 1 < nk)
+                fn_wait_barrier<NPW>();
+            else
+                fn_wait_barrier<0>();
+            if (kc + 2 < nk) stage(kc + 2, slot >= 1 ? slot - 1 : NS - 1);
+            const char* s = smem + slot * SLOT;
+            const char* sa = s + (wm * 64 + l31) * 64;
+            const char* sw_ = s + 2 * A_PL + (wn * WN + l31) * 64;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int pos = ((ks * 2 + hi) ^ sw) * 16;
+                half8_t ah[2], al[2], bh[NB], bl[NB];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *reinterpret_cast<const half8_t*>(sa + i * 32 * 64 + pos);
+                    al[i] = *reinterpret_cast<const half8_t*>(sa + A_PL + i * 32 * 64 + pos);
+                }
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    bh[j] = *reinterpret_cast<const half8_t*>(sw_ + j * 32 * 64 + pos);
+                    bl[j] = *reinterpret_cast<const half8_t*>(sw_ + W_PL + j * 32 * 64 + pos);
                 }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            slot = slot == NS - 1 ? 0 : slot + 1;
         }
-        slot = slot == NS - 1 ? 0 : slot + 1;
+    } else {
+        // ---- the window of this patch: block -> (image, patch row, patch column); this wave copies pieces wave, wave + 8,
+        // wave + 16 of both planes (24 pieces of 16 pixel rows per plane, rows >= 324 and pixels outside the image from the
+        // zero page); a lane owns LDS position q of pixel row R and fetches source piece q ^ swizzle(R)
+        constexpr int P_PL = 24 * 1024, P_SLOT = 2 * P_PL, W_SLOT = 2 * W_PL;
+        constexpr int NW = BN == 128 ? 2 : 1;
+        const int tw = cv.OW >> 4, per_img = (cv.OH >> 4) * tw;
+        const int img = bx / per_img, tt = bx - img * per_img;
+        const int ty = tt / tw, tx = tt - ty * tw;
+        int64_t p_off[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int R = (wave + 8 * n) * 16 + (lane >> 2);
+            const int py = R / 18, px = R - py * 18;
+            const int iy = ty * 16 - 1 + py, ix = tx * 16 - 1 + px;
+            const bool ok = R < 324 && iy >= 0 && iy < cv.H && ix >= 0 && ix < cv.W;
+            p_off[n] = ok ? (((int64_t)img * cv.H + iy) * cv.W + ix) * lda + ((q ^ ((py + 2 * (R >> 2)) & 3)) * 8) : -1;
+        }
+        const int nc = cv.cin >> 5, total = nc * 9;
+        // output pixel of this lane's A rows: (oy, ox) = (4 wm + 2 i + (l31 >> 4), l31 & 15)
+        const int oyb = wm * 4 + (l31 >> 4), ox = l31 & 15;
+#define FN_PATCH_PIECE(C_, N_)                                                                                              \
+    do {                                                                                                                    \
+        const int64_t po_ = p_off[(N_) % 3];                                                                                \
+        const half_t* pl_ = (N_) < 3 ? a_hi : a_lo;                                                                         \
+        fn_dma16(po_ >= 0 ? static_cast<const void*>(pl_ + po_ + (C_) * 32) : zeros,                                        \
+                 lds0 + (uint32_t)((((C_) & 1) * P_SLOT) + ((N_) / 3) * P_PL + (wave + 8 * ((N_) % 3)) * 1024));            \
+    } while (0)
+#define FN_PATCH_WSTAGE(K0_, SLOT_)                                                                                         \
+    do {                                                                                                                    \
+        const uint32_t sb_ = lds0 + (uint32_t)(2 * P_SLOT + (SLOT_) * W_SLOT);                                              \
+        if (BN == 128) {                                                                                                    \
+            fn_dma16(w_ok ? static_cast<const void*>(w_hi + w_off + (K0_)) : zeros, sb_ + (uint32_t)(wave * 1024));         \
+            fn_dma16(w_ok ? static_cast<const void*>(w_lo + w_off + (K0_)) : zeros, sb_ + (uint32_t)(W_PL + wave * 1024));  \
+        } else {                                                                                                            \
+            const half_t* wp_ = wave < 4 ? w_hi : w_lo;                                                                     \
+            fn_dma16(w_ok ? static_cast<const void*>(wp_ + w_off + (K0_)) : zeros,                                          \
+                     sb_ + (uint32_t)((wave < 4 ? 0 : W_PL) + (wave & 3) * 1024));                                          \
+        }                                                                                                                   \
+    } while (0)
+        // one tap step: W chunk (tap T_, channels 32 c ..) against the window pixels (oy + ky, ox + kx).  Issue order per step:
+        // the W pieces of step s + 2, then ONE window piece of chunk c + 1 (taps 0-5) -- so the pieces younger than step s's
+        // W pieces at its wait are step s + 1's W pieces plus the window pieces of steps s - 2 and s - 1 of the same chunk
+#define FN_PATCH_STEP(T_)                                                                                                   \
+    do {                                                                                                                    \
+        constexpr int older_ = (((T_) >= 1 && (T_) <= 6) ? 1 : 0) + (((T_) >= 2 && (T_) <= 7) ? 1 : 0);                     \
+        const int s_ = c * 9 + (T_);                                                                                        \
+        if (s_ + 1 >= total)                                                                                                \
+            fn_wait_barrier<0>();                                                                                           \
+        else if (nxt)                                                                                                       \
+            fn_wait_barrier<NW + older_>();                                                                                 \
+        else                                                                                                                \
+            fn_wait_barrier<NW>();                                                                                          \
+        if (s_ + 2 < total) {                                                                                               \
+            const int t2_ = (T_) + 2 >= 9 ? (T_) + 2 - 9 : (T_) + 2, c2_ = (T_) + 2 >= 9 ? c + 1 : c;                       \
+            FN_PATCH_WSTAGE(t2_ * cv.cin + c2_ * 32, slot >= 1 ? slot - 1 : NS - 1);                                        \
+        }                                                                                                                   \
+        if ((T_) < 6 && nxt) FN_PATCH_PIECE(c + 1, (T_));                                                                   \
+        const char* pa_ = smem + (c & 1) * P_SLOT;                                                                          \
+        const char* sw2_ = smem + 2 * P_SLOT + slot * W_SLOT + (wn * WN + l31) * 64;                                        \
+        int aoff_[2];                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                     \
+            const int py_ = oyb + 2 * i + (T_) / 3, P_ = py_ * 18 + ox + (T_) % 3;                                          \
+            aoff_[i] = P_ * 64 + ((hi ^ ((py_ + 2 * (P_ >> 2)) & 3)) * 16);                                                 \
+        }                                                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                            \
+            const int pos = ((ks * 2 + hi) ^ sw) * 16;                                                                      \
+            half8_t ah[2], al[2], bh[NB], bl[NB];                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
+                ah[i] = *reinterpret_cast<const half8_t*>(pa_ + (aoff_[i] ^ (ks * 32)));                                    \
+                al[i] = *reinterpret_cast<const half8_t*>(pa_ + P_PL + (aoff_[i] ^ (ks * 32)));                             \
+            }                                                                                                               \
+            _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                                \
+                bh[j] = *reinterpret_cast<const half8_t*>(sw2_ + j * 32 * 64 + pos);                                        \
+                bl[j] = *reinterpret_cast<const half8_t*>(sw2_ + W_PL + j * 32 * 64 + pos);                                 \
+            }                                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                   \
+                _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                            \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);                   \
+                }                                                                                                           \
+        }                                                                                                                   \
+        slot = slot == NS - 1 ? 0 : slot + 1;                                                                               \
+    } while (0)
+#pragma unroll
+        for (int n = 0; n < 6; ++n) FN_PATCH_PIECE(0, n);
+        FN_PATCH_WSTAGE(0, 0);
+        FN_PATCH_WSTAGE(cv.cin, 1);
+        int slot = 0;
+        for (int c = 0; c < nc; ++c) {
+            const bool nxt = c + 1 < nc;
+            FN_PATCH_STEP(0);
+            FN_PATCH_STEP(1);
+            FN_PATCH_STEP(2);
+            FN_PATCH_STEP(3);
+            FN_PATCH_STEP(4);
+            FN_PATCH_STEP(5);
+            FN_PATCH_STEP(6);
+            FN_PATCH_STEP(7);
+            FN_PATCH_STEP(8);
+        }
+#undef FN_PATCH_STEP
+#undef FN_PATCH_WSTAGE
+#undef FN_PATCH_PIECE
     }
     // ---- epilogue: lane (l31, hi) holds column n = .. + l31 and rows (r & 3) + 8 (r >> 2) + 4 hi of each 32 x 32 block.
     // fp32 results go out as they sit (a store instruction writes 32 consecutive floats of one row = one 128-byte line).
@@ -248,7 +389,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = fn_row_of(cv, blockIdx.x, wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+            const int m = fn_row_of(cv, bx, wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
             orow[i][r] = m < M ? ((out && out_rows) ? out_rows[m] : m) : -1;
         }
 #pragma unroll
@@ -277,7 +418,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
         if (stats) {  // the two half-waves hold the two row halves of the same column: add them in a fixed order
             const double t1 = __shfl_xor(s1, 32, 64), t2 = __shfl_xor(s2, 32, 64);
             if (hi == 0 && nok) {
-                double* o = stats + (((int64_t)blockIdx.x * 4 + wm) * N + n) * 2;
+                double* o = stats + (((int64_t)bx * 4 + wm) * N + n) * 2;
                 o[0] = s1 + t1;
                 o[1] = s2 + t2;
             }
@@ -289,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
         int prow[PPR];  // (as orow above: the rows of this lane's transposed pieces, looked up before any store)
 #pragma unroll
         for (int it = 0; it < PPR; ++it) {
-            const int m = fn_row_of(cv, blockIdx.x, wm * 64 + (it * 64 + lane) / PPR);
+            const int m = fn_row_of(cv, bx, wm * 64 + (it * 64 + lane) / PPR);
             prow[it] = m < M ? (out_rows ? out_rows[m] : m) : -1;
         }
 #pragma unroll
@@ -614,23 +755,38 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
     half_t* ol = static_cast<half_t*>(out_lo);
     double* sp = static_cast<double*>(stats);
     const int rb = (M + FN_BM - 1) / FN_BM;
+    // 3 x 3 / stride 1 / pad 1 on whole 16 x 16 patches: the window-in-LDS form (FRESCO_FN_CONV_PATCH=0: the im2col form)
+    static const bool patch_on = [] {
+        const char* e = getenv("FRESCO_FN_CONV_PATCH");
+        return !(e && e[0] == '0');
+    }();
+    static const bool xmap_on = [] {  // FRESCO_FN_XCD_MAP=0: column block outermost (the plain workgroup order)
+        const char* e = getenv("FRESCO_FN_XCD_MAP");
+        return !(e && e[0] == '0');
+    }();
+    const bool patch = patch_on && cv.tiled && kh == 3 && kw == 3 && stride == 1 && pad == 1;
+#define FN_LAUNCH(BN_, PATCH_)                                                                                                \
+    do {                                                                                                                      \
+        const int lds = (PATCH_) ? 2 * 2 * 24 * 1024 + FN_NS * 2 * (BN_) * 64 : FN_NS * (2 * FN_BM * 64 + 2 * (BN_) * 64);    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN_, PATCH_>),                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                           \
+        const int nb = (N + (BN_) - 1) / (BN_);                                                                               \
+        hipLaunchKernelGGL((fn_gemm_kernel<BN_, PATCH_>), dim3(rb * nb), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,   \
+                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows,          \
+                           range_flag, out_col_block, out_block_stride, rb, nb, xmap_on ? 1 : 0);                             \
+    } while (0)
     if (N <= 64) {
-        constexpr int BN = 64;
-        const int lds = FN_NS * (2 * FN_BM * 64 + 2 * BN * 64);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
-                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows, range_flag, out_col_block,
-                           out_block_stride);
+        if (patch)
+            FN_LAUNCH(64, true);
+        else
+            FN_LAUNCH(64, false);
     } else {
-        constexpr int BN = 128;
-        const int lds = FN_NS * (2 * FN_BM * 64 + 2 * BN * 64);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_gemm_kernel<BN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((fn_gemm_kernel<BN>), dim3(rb, (N + BN - 1) / BN), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,
-                           out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows, range_flag, out_col_block,
-                           out_block_stride);
+        if (patch)
+            FN_LAUNCH(128, true);
+        else
+            FN_LAUNCH(128, false);
     }
+#undef FN_LAUNCH
     return check_launch();
 }
 

@@ -47,10 +47,14 @@ def test_fn_gemm_linear(M, K, N, act, bias):
                                                             (96, 128, 3, 2, 1, 16, 24, False), (64, 96, 1, 2, 0, 20, 28, True),
                                                             (128, 128, 3, 1, 1, 9, 13, False), (130, 256, 3, 1, 1, 8, 12, True),
                                                             (64, 64, 3, 1, 1, 32, 32, False), (64, 96, 3, 2, 1, 32, 64, False),
-                                                            (96, 128, 1, 2, 0, 32, 64, True)])
+                                                            (96, 128, 1, 2, 0, 32, 64, True),
+                                                            (128, 128, 3, 1, 1, 16, 32, False), (96, 96, 3, 1, 1, 32, 16, True),
+                                                            (130, 256, 3, 1, 1, 16, 16, True), (64, 64, 3, 1, 1, 48, 16, True)])
 def test_fn_gemm_implicit_conv(cin, cout, k, stride, pad, H, W, bias):
     """nn.Conv2d as the implicit GEMM over NHWC rows: every encoder / upsampler shape class (3 x 3 stride 1 / 2, the 1 x 1
-    stride-2 shortcut with bias, a map whose width is no multiple of anything, and the 130-channel input padded to 160)"""
+    stride-2 shortcut with bias, a map whose width is no multiple of anything, and the 130-channel input padded to 160);
+    the 3 x 3 / stride-1 cases on maps of whole 16 x 16 patches take the window-in-LDS form of the kernel (1 - 5 channel
+    chunks, one and several patches per image, every border)"""
     import fresco_amd.ops as ops
     g = synth.gen(cin + cout + k + H)
     n = 3

@@ -93,7 +93,7 @@ def test_flow_network_gemm_fits_two_waves_per_simd_and_sv_reads_stay_split(tmp_p
     layout its swizzle is conflict-free for); hipcc once fused them into a ds_read2st64_b64 (16-lane groups, 32 banks:
     2-way conflicts, 24 % of the kernel's LDS cycles in profiles/r05_pmc_opt_C640_h64.csv)."""
     k = _listing("flownet.hip", tmp_path)
-    for pat in (r"fn_gemm_kernelILi64E", r"fn_gemm_kernelILi128E"):
+    for pat in (r"fn_gemm_kernelILi64ELb0E", r"fn_gemm_kernelILi128ELb0E", r"fn_gemm_kernelILi64ELb1E", r"fn_gemm_kernelILi128ELb1E"):  # Lb1: the window-in-LDS convolution form
         r = _one(k, pat)
         assert r["vgpr"] + r["agpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (pat, r)
     _listing("opt_fast.hip", tmp_path)
