@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                                                          double* __restrict__ stats, const void* __restrict__ zeros,
                                                          const int32_t* __restrict__ a_rows,
                                                          const int32_t* __restrict__ out_rows, int32_t* range_flag,
-                                                         int out_cb, int64_t out_bs, int rb, int nb, int xmap) {
+                                                         int out_cb, int64_t out_bs, int nb_xmap) {
     // out_cb > 0 (fp32 output only): the N columns are out_cb-wide BLOCKS that go to separate (M, out_cb) matrices out_bs
     // floats apart (row stride ldc) -- q | k | v of one source in ONE product, each landing in a matrix of its own
     // a_rows / out_rows (linear layers; NULL = identity): problem row m reads input row a_rows[m] and its results go to output
@@ -121,6 +121,8 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
     // (65536, 1024, 256) 536 MB instead of 67).  The last rb % 8 row blocks keep the plain order.
     int bx, by;
     {
+        // (nb_xmap = nb | xmap << 16; rb = the row blocks of the problem)
+        const int nb = nb_xmap & 0xffff, xmap = nb_xmap >> 16, rb = (M + FN_BM - 1) / FN_BM;
         const int L = blockIdx.x, full = (rb >> 3) * 8 * nb;
         if (nb == 1) {
             bx = L;
@@ -399,7 +401,6 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
         // this lane's output column: matrix n / out_cb, column n % out_cb when the product is split into column blocks
         float* ocol = out;
         if (out) ocol += out_cb > 0 ? (int64_t)(n / out_cb) * out_bs + (n % out_cb) : (int64_t)n;
-        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -408,13 +409,27 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
                 if (act == 1) v = fmaxf(v, 0.f);
                 if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU() (exact, erf form)
                 acc[i][j][r] = v;
-                const bool ok = nok && orow[i][r] >= 0;
-                if (out && ok) ocol[(int64_t)orow[i][r] * ldc] = v;
-                if (stats && ok) {
-                    s1 += (double)v;
-                    s2 += (double)v * (double)v;
-                }
             }
+        // (one branch per column block around the stores, a row test per store only where rows can lie outside the problem:
+        // a patch form's 256 rows never do)
+        if (out && nok) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (PATCH || orow[i][r] >= 0) ocol[(int64_t)orow[i][r] * ldc] = acc[i][j][r];
+        }
+        double s1 = 0.0, s2 = 0.0;
+        if (stats) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double v = (PATCH || orow[i][r] >= 0) ? (double)acc[i][j][r] : 0.0;
+                    s1 += v;
+                    s2 += v * v;
+                }
+        }
         if (stats) {  // the two half-waves hold the two row halves of the same column: add them in a fixed order
             const double t1 = __shfl_xor(s1, 32, 64), t2 = __shfl_xor(s2, 32, 64);
             if (hi == 0 && nok) {
@@ -773,7 +788,7 @@ extern "C" int fresco_fn_gemm(const void* a_hi, const void* a_lo, int64_t lda, c
         const int nb = (N + (BN_) - 1) / (BN_);                                                                               \
         hipLaunchKernelGGL((fn_gemm_kernel<BN_, PATCH_>), dim3(rb * nb), dim3(512), lds, st, ah, al, lda, cv, wh, wl, bias,   \
                            out, oh, ol, ldc, ldo, M, N, K, act, acc_scale, split_scale, sp, zeros, a_rows, out_rows,          \
-                           range_flag, out_col_block, out_block_stride, rb, nb, xmap_on ? 1 : 0);                             \
+                           range_flag, out_col_block, out_block_stride, nb | (xmap_on ? 1 << 16 : 0));                        \
     } while (0)
     if (N <= 64) {
         if (patch)
