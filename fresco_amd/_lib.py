@@ -63,7 +63,7 @@ SIGNATURES = {
     "fresco_fn_colstats": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _vp]),
     "fresco_fn_prep": (_i, [_vp] * 7 + [_i64, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "fresco_fn_layernorm": (_i, [_vp] * 7 + [_i64, _i64, _i64, _i, _f, _f, _vp, _vp]),
-    "fresco_fn_conv7_rgb": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fresco_fn_conv7_rgb": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "fresco_fn_convex_upsample": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fresco_flow_occlusion": (_i, [_vp] * 5 + [_i, _i, _i, _i, _f, _f, _f, _vp]),
     "fresco_warp_fuse_chain": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i, _vp]),

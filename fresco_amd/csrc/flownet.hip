@@ -640,47 +640,161 @@ __global__ __launch_bounds__(256) void fn_layernorm_kernel(const float* __restri
     }
 }
 
-// The stem: Conv2d(3, 64, 7, stride 2, padding 3, bias=False) on NHWC fp32, direct fp32 FMAs.  A block = 64 consecutive
-// output pixels of one output row x 64 output channels: thread (pixel = tid & 63, 16 channels = tid >> 6).  The 7 input rows
-// x (2 * 64 + 5) columns x 3 channels and the 147 x 64 weights live in LDS; a wave reads each weight as a broadcast.
-__global__ __launch_bounds__(256) void fn_conv7_rgb_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ out, int H, int W, int OH, int OW) {
-    constexpr int PW = 2 * 64 + 5;  // input columns of a block
-    __shared__ __attribute__((aligned(16))) float ws[147 * 64];  // [k = (ky, kx, ci)][cout]
-    __shared__ float xs[7 * PW * 3];
-    const int tid = threadIdx.x;
-    const int img = blockIdx.z, oy = blockIdx.y, ox0 = blockIdx.x * 64;
-    for (int i = tid; i < 147 * 64; i += 256) ws[i] = w[i];
-    const int iy0 = oy * 2 - 3, ix0 = ox0 * 2 - 3;
-    for (int i = tid; i < 7 * PW * 3; i += 256) {
-        const int ky = i / (PW * 3), r = i - ky * (PW * 3);
-        const int cx = r / 3, ci = r - cx * 3;
-        const int iy = iy0 + ky, ix = ix0 + cx;
-        xs[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)img * H + iy) * W + ix) * 3 + ci] : 0.f;
+// The stem: Conv2d(3, 64, 7, stride 2, padding 3, bias=False) on NHWC fp32 (backbone.py:69).  Rounds 5: direct fp32 FMAs from
+// an LDS patch (K = 147 "is no MFMA shape"): 496 us at 16 x 512^2, LDS-read bound (one broadcast b128 per four FMAs).
+// Round 6: on the matrix pipe like every other product of the network -- the contraction index is laid out as
+// k' = 32 ky + (3 kx + ci), 21 real positions per kernel row + 11 ZERO WEIGHTS, K' = 224 = 14 k-steps: for output pixel
+// (oy, ox) the 32 values of kernel row ky are the 32 CONSECUTIVE floats of input row 2 oy - 3 + ky starting at pixel
+// 2 ox - 3 (NHWC, 3 channels), so an A fragment is 8 consecutive values of the staged row -- no im2col, no gather; what the
+// 11 surplus positions read (the next pixels of the row: finite) meets zero weights.
+//   block = 8 waves = 2 output rows x 256 output columns, wave = 64 pixels x 64 channels; LDS: the 9 input rows of the tile
+//   as (hi, lo) fp16 planes (split once per input value at staging, 2^6 pre-scale as every activation plane) + the weight
+//   planes (64 rows of 224 halfs, 464-byte rows = an odd number of 16-byte units: conflict-free b128 rows); per k-step and
+//   wave 16 ds_read_b32 (A: 4-byte aligned runs) + 4 ds_read_b128 (W) feed 12 MFMAs; epilogue: fp32 NHWC rows (a store =
+//   32 consecutive floats) and, stats != NULL, the InstanceNorm partial sums of the wave's 64 pixels (slab layout of
+//   fn_gemm_kernel's epilogue: fresco_fn_colstats_finish combines them).
+constexpr int C7_PROW = 1568;  // halfs per staged input row: (2 * 256 + 5) * 3 = 1551 values, reads run to 6 * 255 + 31
+constexpr int C7_ROWS = 9;     // input rows of two output rows
+constexpr int C7_K = 224, C7_WROW = 464;
+typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
+static_assert(C7_K == 28 * 8 && C7_WROW >= C7_K * 2 && (C7_WROW / 16) % 2 == 1, "stem weight rows: 28 pieces, odd LDS pitch");
+__global__ __launch_bounds__(512, 1) void fn_conv7_rgb_kernel(const float* __restrict__ x, const half_t* __restrict__ w_hi,
+                                                              const half_t* __restrict__ w_lo, float* __restrict__ out,
+                                                              double* __restrict__ stats, int H, int W, int OH, int OW,
+                                                              float in_scale, float acc_scale, int32_t* range_flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* xh = reinterpret_cast<half_t*>(smem);
+    half_t* xl = xh + C7_ROWS * C7_PROW;
+    char* wh = smem + 2 * C7_ROWS * C7_PROW * 2;
+    char* wl = wh + 64 * C7_WROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int img = blockIdx.z, oy0 = blockIdx.y * 2, ox0 = blockIdx.x * 256;
+    // ---- weights: 64 rows x 28 16-byte pieces per plane = 7 pieces per thread (all loads, then all LDS writes)
+    {
+        uintx4 wv[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int i = tid + 512 * k, pl = i / (64 * 28), r = i - pl * (64 * 28);
+            wv[k] = *reinterpret_cast<const uintx4*>((pl ? w_lo : w_hi) + r * 8);  // (piece pc of row n: n * 224 + pc * 8 = r * 8)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int i = tid + 512 * k, pl = i / (64 * 28), r = i - pl * (64 * 28);
+            const int n = r / 28, pc = r - n * 28;
+            *reinterpret_cast<uintx4*>((pl ? wl : wh) + n * C7_WROW + pc * 16) = wv[k];
+        }
     }
-    __syncthreads();
-    const int p = tid & 63, cg = tid >> 6;
-    float acc[16];
+    // ---- input rows: value e = 3 cx + ci of staged row ry is x[img][2 oy0 - 3 + ry][2 ox0 - 3 + cx][ci] (zero outside)
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    // Value e of a staged row sits 3 ix0 + e floats into its input row (NHWC rows are contiguous): no division per address,
+    // in-row test = 0 <= 3 ix0 + e < 3 W.  ALL of a thread's 36 loads are issued before the first split, unconditionally
+    // (clamped offsets, zeroed afterwards): left as one loop with the test around the load hipcc waits for every value
+    // before the next load -- 28 dependent round trips per block, 215 us per launch at 16 x 512^2.
+    bool sat = false;
+    float v[C7_ROWS][4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    for (int ky = 0; ky < 7; ++ky)
-        for (int t = 0; t < 21; ++t) {  // t = kx * 3 + ci
-            const float a = xs[ky * (PW * 3) + p * 6 + t];
-            const float* wp = ws + (ky * 21 + t) * 64 + cg * 16;
+    for (int ry = 0; ry < C7_ROWS; ++ry) {
+        const int iy = iy0 + ry;
+        const float* xr = x + ((int64_t)img * H + ((iy >= 0 && iy < H) ? iy : 0)) * W * 3;  // (wave-uniform)
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {
-                const floatx4 wv = *reinterpret_cast<const floatx4*>(wp + j4 * 4);
+        for (int m = 0; m < 4; ++m) {
+            const int off = ix0 * 3 + tid + 512 * m;
+            v[ry][m] = xr[(off >= 0 && off < 3 * W) ? off : 0];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j4 * 4 + e] = fmaf(a, wv[e], acc[j4 * 4 + e]);
+    for (int ry = 0; ry < C7_ROWS; ++ry) {
+        const int iy = iy0 + ry;
+        const bool rok = iy >= 0 && iy < H;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int e = tid + 512 * m, off = ix0 * 3 + e;
+            const float val = (rok && e < 1551 && off >= 0 && off < 3 * W) ? v[ry][m] : 0.f;
+            half_t h, l;
+            sat |= fn_split(val, in_scale, h, l);
+            if (e < C7_PROW) {
+                xh[ry * C7_PROW + e] = h;
+                xl[ry * C7_PROW + e] = l;
             }
         }
-    const int ox = ox0 + p;
-    if (ox < OW) {
-        float* o = out + (((int64_t)img * OH + oy) * OW + ox) * 64 + cg * 16;
+    }
+    fn_flag_range(range_flag, sat);
+    __syncthreads();
+    // ---- products: wave = output row oy0 + (wave >> 2), columns ox0 + 64 (wave & 3) + 32 i + l31
+    floatx16 acc[2][2];
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-            floatx4 v = {acc[j4 * 4], acc[j4 * 4 + 1], acc[j4 * 4 + 2], acc[j4 * 4 + 3]};
-            *reinterpret_cast<floatx4*>(o + j4 * 4) = v;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wr = wave >> 2, wc = (wave & 3) * 64;
+    const char* wrow = wh + l31 * C7_WROW + hi * 16;
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            half8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wr * 2 + ky) * C7_PROW + 6 * (wc + i * 32 + l31) + h2 * 16 + hi * 8;  // (even: 4-byte aligned)
+                const uint32_t* ph = reinterpret_cast<const uint32_t*>(xh + off);
+                const uint32_t* pl = reinterpret_cast<const uint32_t*>(xl + off);
+                uintx4 vh = {ph[0], ph[1], ph[2], ph[3]}, vl = {pl[0], pl[1], pl[2], pl[3]};
+                ah[i] = __builtin_bit_cast(half8_t, vh);
+                al[i] = __builtin_bit_cast(half8_t, vl);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const half8_t*>(wrow + j * 32 * C7_WROW + (ky * 32 + h2 * 16) * 2);
+                bl[j] = *reinterpret_cast<const half8_t*>(wrow + 64 * C7_WROW + j * 32 * C7_WROW + (ky * 32 + h2 * 16) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // ---- epilogue: lane (l31, hi) holds channel 32 j + l31 of pixels 32 i + (r & 3) + 8 (r >> 2) + 4 hi of the wave's 64
+    const int oy = oy0 + wr;
+    const bool yok = oy < OH;
+    int64_t orow[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ox = ox0 + wc + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            orow[i][r] = (yok && ox < OW) ? (((int64_t)img * OH + oy) * OW + ox) * 64 : -1;
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r] * acc_scale;
+                if (orow[i][r] >= 0) out[orow[i][r] + j * 32 + l31] = v;
+                const double d = orow[i][r] >= 0 ? (double)v : 0.0;
+                s1 += d;
+                s2 += d * d;
+            }
+        if (stats) {  // (launcher: OW % 64 == 0 -> the wave's 64 pixels are rows [64 s, 64 s + 64) of the (n OH OW, 64) matrix)
+            const double t1 = __shfl_xor(s1, 32, 64), t2 = __shfl_xor(s2, 32, 64);
+            if (hi == 0 && yok && ox0 + wc < OW) {
+                const int64_t slab = (((int64_t)img * OH + oy) * OW + ox0 + wc) >> 6;
+                double* o = stats + (slab * 64 + j * 32 + l31) * 2;
+                o[0] = s1 + t1;
+                o[1] = s2 + t2;
+            }
         }
     }
 }
@@ -862,13 +976,21 @@ extern "C" int fresco_fn_layernorm(const float* x, const float* gamma, const flo
     return check_launch();
 }
 
-extern "C" int fresco_fn_conv7_rgb(const float* x, const float* w, float* out, int n_img, int H, int W, void* stream) {
-    if (!x || !w || !out || n_img <= 0 || H <= 0 || W <= 0) return FRESCO_EINVAL;
-    const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
-    if (OH > 65535 || n_img > 65535) return FRESCO_EUNSUPPORTED;
+extern "C" int fresco_fn_conv7_rgb(const float* x, const void* w_hi, const void* w_lo, float* out, void* stats, int n_img,
+                                   int H, int W, int32_t* range_flag, void* stream) {
+    if (!x || !w_hi || !w_lo || !out || n_img <= 0 || H <= 0 || W <= 0) return FRESCO_EINVAL;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    if (n_img > 65535 || (OH + 1) / 2 > 65535) return FRESCO_EUNSUPPORTED;
+    // fused InstanceNorm partial sums: a wave's 64 pixels must be one 64-row slab of the (n OH OW, 64) matrix, and
+    // fresco_fn_colstats_finish combines whole 256-row groups
+    if (stats && (OW % 64 != 0 || ((int64_t)OH * OW) % 256 != 0)) return FRESCO_EUNSUPPORTED;
+    const int lds = 2 * C7_ROWS * C7_PROW * 2 + 2 * 64 * C7_WROW;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_conv7_rgb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipStream_t st = as_stream(stream);
     ProfScope ps(FRESCO_PROF_FN_GEMM, n_img * OH * OW, 64, 147, 7, st);
-    hipLaunchKernelGGL(fn_conv7_rgb_kernel, dim3((OW + 63) / 64, OH, n_img), dim3(256), 0, st, x, w, out, H, W, OH, OW);
+    hipLaunchKernelGGL(fn_conv7_rgb_kernel, dim3((OW + 255) / 256, (OH + 1) / 2, n_img), dim3(512), lds, st, x,
+                       static_cast<const half_t*>(w_hi), static_cast<const half_t*>(w_lo), out, static_cast<double*>(stats), H, W,
+                       OH, OW, 64.f, 1.f / (64.f * 1024.f), range_flag);
     return check_launch();
 }
 

@@ -236,12 +236,11 @@ class _Weights:
             if pad_cin is not None and pad_cin > w.shape[-1]:
                 w = F.pad(w, (0, pad_cin - w.shape[-1]))
             w = w.reshape(w.shape[0], -1)
-        elif kind == "stem":  # (64, 3, 7, 7) -> (7, 7, 3, 64) fp32 (direct fp32 FMAs: no range limit)
-            val = w.permute(2, 3, 1, 0).contiguous()
-            self.cache[key] = (stamp, val, False)
-            return val
         with ops.fn_range_guard(w.device) as g:
-            _, val = ops.fn_prep(w.contiguous(), scale=ops.FN_W_SCALE)
+            if kind == "stem":  # (64, 3, 7, 7) -> the (64, 224) layout of fresco_fn_conv7_rgb
+                val = ops.fn_conv7_weight(w)
+            else:
+                _, val = ops.fn_prep(w.contiguous(), scale=ops.FN_W_SCALE)
         bad = g.tripped()  # (one host sync per parameter version)
         self.out_of_range |= bad
         self.cache[key] = (stamp, val, bad)
@@ -292,10 +291,10 @@ def _res_block(wts, blk, x, xs, n, H, W):
 def _backbone_native(bb, wts, x_nchw):
     """CNNEncoder.forward -> tokens (n, h * w, C) fp32 (= NHWC), h, w"""
     n, _, H, W = x_nchw.shape
-    c = ops.fn_conv7_rgb(x_nchw.permute(0, 2, 3, 1).contiguous(), wts.get(bb.conv1.weight, "stem"))
+    c, (m, r) = ops.fn_conv7_rgb(x_nchw.permute(0, 2, 3, 1).contiguous(), wts.get(bb.conv1.weight, "stem"),
+                                 instance_norm_eps=bb.norm1.eps)
     H, W = c.shape[1], c.shape[2]
     c = c.view(n * H * W, 64)
-    m, r = ops.fn_colstats(c, n, bb.norm1.eps)
     x, xs = ops.fn_prep(c, m, r, rows_per_img=H * W, relu_a=True, want_f32=True)
     for layer in (bb.layer1, bb.layer2, bb.layer3):
         for blk in layer:

@@ -514,16 +514,47 @@ def fn_layernorm(x, gamma, beta, residual=None, eps=1e-5, want_f32=True, want_sp
     return y, ((oh, ol) if oh is not None else None)
 
 
-def fn_conv7_rgb(x_nhwc, w_khwc):
-    """Conv2d(3, 64, 7, stride 2, padding 3, bias=False) on (n, H, W, 3) fp32 NHWC with w (7, 7, 3, 64) -> (n, OH, OW, 64)"""
-    _need_gpu(x_nhwc, w_khwc)
-    x_nhwc, w_khwc = _f32c(x_nhwc), _f32c(w_khwc)
-    n, H, W, _ = x_nhwc.shape
+def fn_conv7_weight(weight):
+    """(hi, lo) planes of the stem's weight as fresco_fn_conv7_rgb reads it: (64, 3, 7, 7) -> W'[cout][32 ky + 3 kx + ci],
+    the 11 surplus positions of every kernel row zero"""
+    w = weight.detach().float().permute(0, 2, 3, 1).reshape(64, 7, 21)
+    w = torch.nn.functional.pad(w, (0, 11)).reshape(64, 224).contiguous()
+    _, planes = fn_prep(w, scale=FN_W_SCALE)
+    return planes
+
+
+def fn_conv7_rgb(x_nhwc, w_split, instance_norm_eps=None):
+    """Conv2d(3, 64, 7, stride 2, padding 3, bias=False) on (n, H, W, 3) fp32 NHWC, w_split = fn_conv7_weight(weight)
+    -> (n, OH, OW, 64); instance_norm_eps: also the (mean, rstd) of the InstanceNorm2d that follows (partial sums out of
+    the epilogue where the map allows it, a second pass otherwise)"""
+    _need_gpu(x_nhwc, *w_split)
+    x_nhwc = _f32c(x_nhwc)
+    wh, wl = w_split
+    if tuple(wh.shape) != (64, 224) or tuple(wl.shape) != (64, 224) or wh.dtype != torch.float16 or wl.dtype != torch.float16 \
+            or not wh.is_contiguous() or not wl.is_contiguous():
+        raise ValueError("fn_conv7_rgb: w_split must be the (64, 224) fp16 planes of fn_conv7_weight")
+    n, H, W, c = x_nhwc.shape
+    if c != 3:
+        raise ValueError("fn_conv7_rgb: x must be (n, H, W, 3)")
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty(n, OH, OW, 64, dtype=torch.float32, device=x_nhwc.device)
-    rc = _lib.load().fresco_fn_conv7_rgb(x_nhwc.data_ptr(), w_khwc.data_ptr(), out.data_ptr(), n, H, W, _stream())
+    dev = x_nhwc.device
+    out = torch.empty(n, OH, OW, 64, dtype=torch.float32, device=dev)
+    fused = instance_norm_eps is not None and OW % 64 == 0 and (OH * OW) % 256 == 0
+    stats = torch.empty((n * OH * OW // 64) * 64 * 2, dtype=torch.float64, device=dev) if fused else None
+    lib = _lib.load()
+    rc = lib.fresco_fn_conv7_rgb(x_nhwc.data_ptr(), wh.data_ptr(), wl.data_ptr(), out.data_ptr(), _ptr(stats), n, H, W,
+                                 _fn_flag_ptr(dev), _stream())
     _lib.check(rc, "fresco_fn_conv7_rgb(n=%d,H=%d,W=%d)" % (n, H, W))
-    return out
+    if instance_norm_eps is None:
+        return out
+    if not fused:
+        return out, fn_colstats(out.view(n * OH * OW, 64), n, instance_norm_eps)
+    mean = torch.empty(n, 64, dtype=torch.float32, device=dev)
+    rstd = torch.empty(n, 64, dtype=torch.float32, device=dev)
+    rc = lib.fresco_fn_colstats_finish(stats.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n, OH * OW, 64,
+                                       float(instance_norm_eps), _stream())
+    _lib.check(rc, "fresco_fn_colstats_finish")
+    return out, (mean, rstd)
 
 
 def fn_convex_upsample(logits, flow_tok, B, h, w):

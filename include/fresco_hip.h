@@ -293,9 +293,15 @@ int fresco_fn_layernorm(const float* x, const float* gamma, const float* beta, c
                         void* out_lo, int64_t ldy, int64_t ldo, int64_t M, int C, float eps, float split_scale,
                         int32_t* range_flag, void* stream);
 
-/* The encoder's stem: Conv2d(3, 64, 7, stride 2, padding 3, bias=False), direct fp32 FMAs.  x (n_img, H, W, 3) NHWC,
- * w (7, 7, 3, 64) = weight.permute(2, 3, 1, 0), out (n_img, OH, OW, 64) NHWC. */
-int fresco_fn_conv7_rgb(const float* x, const float* w, float* out, int n_img, int H, int W, void* stream);
+/* The encoder's stem: Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (gmflow/backbone.py:69) on the matrix pipe (split-fp16
+ * products, fp32-class accuracy; round 6 -- rounds 5: direct fp32 FMAs).  x (n_img, H, W, 3) NHWC fp32; w_hi / w_lo: fp16
+ * planes (scale 2^10, as fresco_fn_prep writes them) of the (64, 224) matrix W'[cout][32 ky + 3 kx + ci] = weight[cout][ci][ky][kx],
+ * the 11 surplus positions of every kernel row ZERO; out (n_img, OH, OW, 64) NHWC fp32, OH = (H - 1) / 2 + 1.
+ * stats (may be NULL): fp64 InstanceNorm partial sums of `out`, (n_img OH OW / 64) slabs x 64 channels x 2, combined by
+ * fresco_fn_colstats_finish; needs OW % 64 == 0 and OH OW % 256 == 0 (FRESCO_EUNSUPPORTED otherwise).
+ * range_flag (may be NULL): OR 1 when an input value leaves the operand planes' range (|x| >= 1015). */
+int fresco_fn_conv7_rgb(const float* x, const void* w_hi, const void* w_lo, float* out, void* stats, int n_img, int H, int W,
+                        int32_t* range_flag, void* stream);
 
 /* Convex upsampling by 8 (gmflow.py:75-90): out (B, 2, 8h, 8w) = softmax-over-9-weighted mix of the 3 x 3 coarse neighbourhood
  * of 8 * flow.  logits (B, h, w, 576) = the mask head's NHWC rows (channel = n * 64 + ky * 8 + kx), flow (B, h * w, 2). */

@@ -113,17 +113,36 @@ def test_fn_instance_norm_prep_and_layernorm():
     assert float((y2.cpu().double() - ref2).abs().max()) < 5e-6
 
 
-def test_fn_conv7_rgb_stem():
+@pytest.mark.parametrize("n,H,W", [(2, 40, 72), (1, 37, 51), (2, 64, 256), (1, 6, 1030), (3, 128, 128)])
+def test_fn_conv7_rgb_stem(n, H, W):
+    """the 7 x 7 / stride-2 stem (backbone.py:69) as split-fp16 MFMA products over the k' = 32 ky + 3 kx + ci layout: odd
+    maps, maps narrower / wider than one 256-column tile, every border; InstanceNorm statistics out of the epilogue
+    ((2, 64, 256): OW = 128, (3, 128, 128): OW = 64 -- two waves of a tile lie outside the map) and from the second pass"""
     import fresco_amd.ops as ops
-    g = synth.gen(7)
-    n, H, W = 2, 40, 72
-    x = torch.randn(n, 3, H, W, generator=g)
+    g = synth.gen(7 + H)
+    x = torch.randn(n, 3, H, W, generator=g) * 1.3
+    x[:, :, ::5] *= 1e-3
     w = torch.randn(64, 3, 7, 7, generator=g) * 0.08
-    out = ops.fn_conv7_rgb(x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(2, 3, 1, 0).contiguous().to(DEV))
+    ws = ops.fn_conv7_weight(w.to(DEV))
+    out, (mean, rstd) = ops.fn_conv7_rgb(x.permute(0, 2, 3, 1).contiguous().to(DEV), ws, instance_norm_eps=1e-5)
     ref = F.conv2d(x.double(), w.double(), None, stride=2, padding=3)
     got = out.permute(0, 3, 1, 2).cpu().double()
     assert tuple(got.shape) == tuple(ref.shape)
-    assert float((got - ref).abs().max()) < 2e-5
+    bar = _bar(F.conv2d(x.abs().double(), w.abs().double(), None, stride=2, padding=3))
+    err = float((got - ref).abs().max())
+    assert err < bar, (err, bar)
+    rf = ref.reshape(n, 64, -1)
+    assert float((mean.cpu().double() - rf.mean(2)).abs().max()) < 2e-6
+    assert float((rstd.cpu().double() * (rf.var(2, unbiased=False) + 1e-5).sqrt() - 1).abs().max()) < 1e-5
+    # without the statistics: the same map, bit for bit
+    assert torch.equal(ops.fn_conv7_rgb(x.permute(0, 2, 3, 1).contiguous().to(DEV), ws), out)
+    # an input outside the operand planes' range trips the guard
+    with ops.fn_range_guard(out.device) as g2:
+        ops.fn_conv7_rgb((x * 2000).permute(0, 2, 3, 1).contiguous().to(DEV), ws)
+    assert g2.tripped()
+    with ops.fn_range_guard(out.device) as g3:
+        ops.fn_conv7_rgb(x.permute(0, 2, 3, 1).contiguous().to(DEV), ws)
+    assert not g3.tripped()
 
 
 def test_fn_convex_upsample():
