@@ -222,6 +222,10 @@ __global__ __launch_bounds__(512, 1) void fn_gemm_kernel(const half_t* __restric
             }
         };
 
+        // (Round 6, measured and not kept: fragments of chunk kc + 1 read into a second register set under the MFMAs of chunk
+        // kc, three chunks in flight -- bit-identical, no faster (EXPERIMENTS.md 4): tools/ubench_fn_gemm_k.py puts a
+        // 256 x 128 x 32 chunk at 2.0 us on a full chip = 48 KB per CU and chunk at 10 B/clk/CU, the rate at which a CU's
+        // LDS-DMA requests are served when all 256 stream, not the LDS-read / MFMA lockstep behind the barrier.)
         stage(0, 0);
         if (nk > 1) stage(1, 1);
         int slot = 0;
