@@ -3,6 +3,7 @@ projections / FFN / LayerNorms, upsampler head -- gmflow/backbone.py:7-117, tran
 torch in fp64 on the same fp32 inputs.  The products run on the fp16 matrix pipe from (hi, lo) operand planes: the bar is
 fp32-class accuracy, a few 1e-6 of sum |a| |w| (an fp32 GEMM's own error grows like sqrt(K) 6e-8 of the same sum)."""
 import math
+import os
 
 import pytest
 import torch
@@ -283,3 +284,62 @@ def test_fn_gemm_stacked_projections_in_one_product():
     assert float((fused[1].double() - ref).abs().max()) < _bar(x.abs().double()[table.long()] @ ws[1].abs().double().t())
     with pytest.raises(ValueError):
         ops.fn_gemm(xs, stacked, 3 * C, C, out_blocks=3, want_split=True)
+
+
+_FORMS_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import synth
+import fresco_amd.ops as ops
+g = synth.gen(99)
+dev = "cuda"
+res = {}
+# a 3 x 3 / stride-1 convolution on whole 16 x 16 patches (the window-in-LDS form when FRESCO_FN_CONV_PATCH != 0) ...
+n, cin, cout, H, W = 3, 96, 128, 64, 48
+x = torch.randn(n * H * W, cin, generator=g)
+w = torch.randn(cout, 9 * cin, generator=g) * 0.03
+_, xs = ops.fn_prep(x.to(dev))
+_, ws = ops.fn_prep(w.to(dev), scale=ops.FN_W_SCALE)
+out, sp, (mean, rstd) = ops.fn_gemm(xs, ws, cout, 9 * cin, conv=(n, H, W, 3, 3, 1, 1), want_split=True, instance_norm_eps=1e-5)
+res["conv"], res["conv_hi"], res["conv_lo"], res["mean"], res["rstd"] = out.cpu(), sp[0].cpu(), sp[1].cpu(), mean.cpu(), rstd.cpu()
+# ... and a linear product with five column blocks (the XCD-aware workgroup order when FRESCO_FN_XCD_MAP != 0), 19 row blocks
+M, K, N = 19 * 256 - 77, 256, 576
+a = torch.randn(M, K, generator=g)
+b = torch.randn(N, K, generator=g) * 0.05
+_, as_ = ops.fn_prep(a.to(dev))
+_, bs = ops.fn_prep(b.to(dev), scale=ops.FN_W_SCALE)
+lin, lsp = ops.fn_gemm(as_, bs, N, K, act=2, want_split=True)
+res["lin"], res["lin_hi"], res["lin_lo"] = lin.cpu(), lsp[0].cpu(), lsp[1].cpu()
+torch.save(res, sys.argv[2])
+"""
+
+
+def test_fn_gemm_forms_agree(tmp_path):
+    """the build's two A/B switches, each in a process of its own (they are read once per process): the XCD-aware workgroup
+    order is a pure re-ordering of workgroups -- identical bits; the window-in-LDS convolution contracts in another order
+    (channel chunks outer, taps inner) -- fp32-class agreement with the im2col form, identical InstanceNorm statistics to
+    1e-6, and (hi, lo) planes that reproduce each form's own fp32 output"""
+    import subprocess
+    import sys
+    import fresco_amd.ops as ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("default", {}), ("im2col", {"FRESCO_FN_CONV_PATCH": "0"}), ("plain_order", {"FRESCO_FN_XCD_MAP": "0"})):
+        path = str(tmp_path / (tag + ".pt"))
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", _FORMS_SCRIPT, root, path], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = torch.load(path)
+    d, p, q = outs["default"], outs["plain_order"], outs["im2col"]
+    for k in d:  # workgroup order: nothing changes
+        assert torch.equal(d[k], p[k]), k
+    for k in ("lin", "lin_hi", "lin_lo"):  # the convolution switch does not touch linear products
+        assert torch.equal(d[k], q[k]), k
+    scale = float(d["conv"].abs().max())
+    assert float((d["conv"] - q["conv"]).abs().max()) < 2e-6 * scale + 1e-7, "window form vs im2col form"
+    assert not torch.equal(d["conv"], q["conv"])  # (the two forms really are two: another summation order)
+    assert float((d["mean"] - q["mean"]).abs().max()) < 1e-6 and float((d["rstd"] / q["rstd"] - 1).abs().max()) < 1e-5
+    for o in (d, q):
+        rec = (o["conv_hi"].float() + o["conv_lo"].float()) / ops.FN_A_SCALE
+        assert float((rec - o["conv"]).abs().max()) <= 2 ** -21 * scale + 1e-7
