@@ -20,6 +20,11 @@
 
 namespace fresco {
 
+// 2^x for x <= 0: the bare v_exp_f32 (1 ulp).  exp2f() wraps it in five more instructions that only matter for results below
+// 2^-126 (they come out as 0 here: softmax weights 38 orders of magnitude under the row maximum) -- 85 of the 368 vector
+// instructions per tile and wave of attn_f32p_kernel (round 6).
+__device__ __forceinline__ float a32_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <int D, int DV>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, float* __restrict__ out,
@@ -99,12 +104,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
         for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = a32_exp2(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = exp2f(s[r] - m_new);
+            s[r] = a32_exp2(s[r] - m_new);
             psum += s[r];
         }
         l_run = l_run * alpha + psum;
@@ -280,12 +285,12 @@ __global__ __launch_bounds__(256, 2) void attn_f32s_kernel(const float* __restri
         for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = a32_exp2(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = exp2f(s[r] - m_new);
+            s[r] = a32_exp2(s[r] - m_new);
             psum += s[r];
         }
         l_run = l_run * alpha + psum;
@@ -400,46 +405,57 @@ __device__ __forceinline__ void a32_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
 }
 
-template <int D, int DV>
-__global__ __launch_bounds__(256, 2) void attn_f32p_kernel(const float* __restrict__ q, const char* __restrict__ img,
-                                                            float* __restrict__ out, int Lq, int Lk, int dv_real,
-                                                            float scale_log2) {
+// Round 6: TWO tile buffers and NW = 4 or 8 waves (128 or 256 queries) per workgroup.  The single-buffer form of rounds 4-5
+// could only request K(t + 1) once every wave was done with K(t), i.e. half a tile ahead: with the image coming from HBM /
+// MALL (a 1024-token window has 8 query blocks to share a tile, and they run in lockstep: the first to ask pays the miss and
+// the others wait on it) that latency sat on every tile -- 5.6 us per tile at (B 64, L 1024) against 3.1 at (B 16, L 4096),
+// where 32 query blocks share and somebody has usually been there before.  Now tile t + 1 is requested as a whole (K | V,
+// one contiguous image) at the top of tile t into the other buffer: a full tile of lead, ONE barrier per tile instead of
+// four, no counted waits (what is outstanding at the top of tile t is tile t, requested a tile ago).  With 8 waves one
+// image stream feeds 256 queries: half the LDS-DMA bytes per flop.  Same arithmetic on the same pieces: identical bits.
+// Worth 4 % (197.8 -> 188.9 us for range pass + split + attention at (B 64, L 1024), 420 -> 413 at (B 16, L 4096)): the
+// counters of this form (tools/pmc_attn32.sh, profiles/r06_pmc_attn32_B64_L1024.csv) say what bounds it instead -- 4.72 M
+// MFMAs x 32 cycles = 147 k busy cycles per SIMD of 305 k (48 %), 24.1 M VALU instructions = 23.5 k per SIMD ~ 105 k port
+// cycles + 32 k of MFMA issue: as in the flash kernel the vector strand (368 instructions per tile and wave: P's (hi, lo)
+// split, the rescale of O, exp2, the two 2^-12 scalings) and the matrix strand of a SIMD add up instead of overlapping;
+// LDS bank conflicts 0, L2 hit rate 83 %.
+template <int D, int DV, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_f32p_kernel(const float* __restrict__ q,
+                                                                              const char* __restrict__ img,
+                                                                              float* __restrict__ out, int Lq, int Lk,
+                                                                              int dv_real, float scale_log2) {
     using I = A32Img<D, DV>;
-    constexpr int KROW = I::KROW, VROW = I::VROW, NKP = I::NKP, NVP = I::NVP;
+    constexpr int KROW = I::KROW, VROW = I::VROW;
     constexpr int NDB = DV / 32, NKS = D / 16;
-    __shared__ __attribute__((aligned(16))) char kbuf[I::KIMGP];
-    __shared__ __attribute__((aligned(16))) char vbuf[I::VIMGP];
+    constexpr int PPW = I::TILE / 1024 / NW;  // 1 KiB pieces per wave and tile
+    static_assert(I::TILE % (1024 * NW) == 0, "every wave copies the same number of pieces");
+    extern __shared__ __attribute__((aligned(16))) char tbuf[];  // [2][TILE]: K image | V image of a tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.y;
-    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    // workgroup -> (problem b, query block qb), query blocks of a problem on consecutive ids.  (Round 6, measured and not
+    // kept: an XCD-aware order that keeps a problem's query blocks on ONE XCD's L2 -- 197.8 / 204.5 us against 202.7 / 210.1
+    // at (B 64, L 1024), profiles/r06_ab_attn32_forms.txt: the launch is not bound by where its images come from, see the
+    // counters quoted below.)
+    const int nqb = (Lq + NW * 32 - 1) / (NW * 32);
+    const int b = blockIdx.x / nqb, qb = blockIdx.x - b * nqb;
+    const int qrow = qb * (NW * 32) + wave * 32 + l31;
     const float* qp = q + ((int64_t)b * Lq + (qrow < Lq ? qrow : Lq - 1)) * D + hi * 8;
     const int nT = (Lk + 31) / 32;
     const char* ib = img + (int64_t)b * nT * I::TILE;
-    const uint32_t ldsk =
-        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)kbuf);
-    const uint32_t ldsv =
-        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)vbuf);
+    const uint32_t lds0 =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)tbuf);
     const uint32_t voff = (uint32_t)lane * 16;
-    auto stage_k = [&](int t) __attribute__((always_inline)) {  // wave w copies KiB w, w + 4, ... of the K image
+    auto stage = [&](int t) __attribute__((always_inline)) {  // wave w copies KiB w, w + NW, ... of tile t's image
         const char* src = ib + (int64_t)t * I::TILE + wave * 1024;
+        const uint32_t dst = lds0 + (uint32_t)((t & 1) * I::TILE + wave * 1024);
 #pragma unroll
-        for (int i = 0; i < NKP; ++i)
-            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src + i * 4096),
-                         "s"(ldsk + (uint32_t)(wave * 1024 + i * 4096))
+        for (int i = 0; i < PPW; ++i)
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src + i * (NW * 1024)),
+                         "s"(dst + (uint32_t)(i * (NW * 1024)))
                          : "memory");
     };
-    auto stage_v = [&](int t) __attribute__((always_inline)) {
-        const char* src = ib + (int64_t)t * I::TILE + I::KIMGP + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < NVP; ++i)
-            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src + i * 4096),
-                         "s"(ldsv + (uint32_t)(wave * 1024 + i * 4096))
-                         : "memory");
-    };
-    stage_k(0);
-    stage_v(0);
+    stage(0);
 
     half8_t qh[NKS], ql[NKS], qm[NKS];
 #pragma unroll
@@ -463,14 +479,16 @@ __global__ __launch_bounds__(256, 2) void attn_f32p_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
-    const char* kh_s = kbuf;
-    const char* kl_s = kbuf + 32 * KROW;
-    const char* km_s = kbuf + 2 * 32 * KROW;
-    const char* vh_s = vbuf;
-    const char* vl_s = vbuf + DV * VROW;
 
     for (int t = 0; t < nT; ++t) {
-        a32_wait_barrier<NVP>();  // K(t) has landed for everyone (the V(t) pieces, issued after it, may still fly)
+        // tile t has landed for everyone, and everyone is done with tile t - 1: its buffer takes tile t + 1
+        a32_wait_barrier<0>();
+        if (t + 1 < nT) stage(t + 1);
+        const char* kh_s = tbuf + (t & 1) * I::TILE;
+        const char* kl_s = kh_s + 32 * KROW;
+        const char* km_s = kh_s + 2 * 32 * KROW;
+        const char* vh_s = kh_s + I::KIMGP;
+        const char* vl_s = vh_s + DV * VROW;
         floatx16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -492,8 +510,6 @@ __global__ __launch_bounds__(256, 2) void attn_f32p_kernel(const float* __restri
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], s, 0, 0, 0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done reading the K buffer
-        if (t + 1 < nT) stage_k(t + 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] *= 0x1p-12f;  // undo the 2^6 of Q and of K (exact)
         if ((t + 1) * 32 > Lk) {
@@ -508,12 +524,12 @@ __global__ __launch_bounds__(256, 2) void attn_f32p_kernel(const float* __restri
         for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = a32_exp2(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = exp2f(s[r] - m_new);
+            s[r] = a32_exp2(s[r] - m_new);
             psum += s[r];
         }
         l_run = l_run * alpha + psum;
@@ -521,11 +537,6 @@ __global__ __launch_bounds__(256, 2) void attn_f32p_kernel(const float* __restri
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        // V(t) has landed (what may still fly is K(t + 1), issued after it)
-        if (t + 1 < nT)
-            a32_wait_barrier<NKP>();
-        else
-            a32_wait_barrier<0>();
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             half8_t ph, pl;
@@ -544,10 +555,6 @@ __global__ __launch_bounds__(256, 2) void attn_f32p_kernel(const float* __restri
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl, o[db], 0, 0, 0);
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph, o[db], 0, 0, 0);
             }
-        }
-        if (t + 1 < nT) {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done reading the V buffer
-            stage_v(t + 1);
         }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -570,8 +577,25 @@ static int launch_attn32p(const float* q, const float* k, const float* v, float*
     ProfScope ps(FRESCO_PROF_ATTN_F32, B, Lq, Lk, D, st);
     const int nT = (Lk + 31) / 32;
     hipLaunchKernelGGL((kv_split_kernel<D, DV>), dim3(nT, B), dim3(256), 0, st, k, v, img, Lk, dv);
-    hipLaunchKernelGGL((attn_f32p_kernel<D, DV>), dim3((Lq + 127) / 128, B), dim3(256), 0, st, q, img, out, Lq, Lk, dv,
-                       scale * 1.4426950408889634f);
+    using I = A32Img<D, DV>;
+    const int lds = 2 * I::TILE;
+    // 256-query workgroups (8 waves: one image stream per 256 queries) when they alone fill the chip and the tile's pieces
+    // divide by 8 waves; else 128-query workgroups
+    constexpr bool can8 = I::TILE % 8192 == 0;
+    const int64_t wg8 = (int64_t)((Lq + 255) / 256) * B;
+    if (can8 && wg8 >= 256) {
+        if constexpr (can8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32p_kernel<D, DV, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((attn_f32p_kernel<D, DV, 8>), dim3((unsigned)wg8), dim3(512), lds, st, q, img, out, Lq, Lk, dv,
+                               scale * 1.4426950408889634f);
+        }
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32p_kernel<D, DV, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((attn_f32p_kernel<D, DV, 4>), dim3(((Lq + 127) / 128) * B), dim3(256), lds, st, q, img, out, Lq, Lk,
+                           dv, scale * 1.4426950408889634f);
+    }
     return check_launch();
 }
 
