@@ -12,7 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import closed_form as cf  # noqa: E402
 
-CASES = {"a": (2, 96, 128), "b": (3, 64, 96)}
+CASES = {"a": (2, 96, 128), "b": (3, 64, 96), "c": (2, 256, 256)}
+# case c (round 6): every map of the encoder is whole 16 x 16 patches and 64-pixel rows -- the sizes at which the GPU path takes the
+# window-in-LDS convolutions, the fused InstanceNorm sums of the stem and 256-token windows; stored at every 4th pixel
+STRIDE = {"c": 4}
 
 
 def main():
@@ -31,9 +34,17 @@ def main():
         with torch.no_grad():
             flow = m(imgs, imgs[nxt], attn_splits_list=[2], corr_radius_list=[-1], prop_radius_list=[-1],
                      pred_bidir_flow=True)["flow_preds"][-1]
-        out["flow_" + tag] = flow.numpy()
+        st = STRIDE.get(tag, 1)
+        out["flow_" + tag] = flow[:, :, ::st, ::st].contiguous().numpy()
         print(tag, tuple(flow.shape), "mean |flow| %.3f max %.3f" % (float(flow.abs().mean()), float(flow.abs().max())))
-    np.savez_compressed(os.path.join(HERE, "gmflow_golden.npz"), **out)
+    path = os.path.join(HERE, "gmflow_golden.npz")
+    if os.path.exists(path):  # earlier cases stay byte for byte what they were (report how a re-run compares)
+        old = dict(np.load(path))
+        for k, v in old.items():
+            if k in out and k.startswith("flow_"):
+                print("re-run vs stored", k, "max |d| = %.3g" % float(np.abs(out[k] - v).max()))
+            out[k] = v
+    np.savez_compressed(path, **out)
     print("wrote gmflow_golden.npz")
 
 
