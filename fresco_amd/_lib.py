@@ -57,6 +57,7 @@ SIGNATURES = {
     "fresco_attn_f32_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fresco_attn_f32_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _f, _vp]),
     "fresco_attn_f32_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "fresco_attn_f32_guarded_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "fresco_fn_gemm": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64] + [_i] * 4 + [_f, _f] + [_i] * 7 + [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "fresco_fn_colstats_finish": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "fresco_fn_colstats_workspace_bytes": (_sz, [_i, _i, _i]),

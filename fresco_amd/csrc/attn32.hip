@@ -354,7 +354,9 @@ struct A32Img {
 
 template <int D, int DV>
 __global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__ k, const float* __restrict__ v,
-                                                        char* __restrict__ img, int Lk, int dv_real) {
+                                                        char* __restrict__ img, int Lk, int dv_real, int* __restrict__ flag) {
+    // flag != NULL (fresco_attn_f32_guarded_ws): the range test of the guarded entry on the values this pass reads anyway --
+    // |k|, |v| >= 1000 (or NaN) would overflow the hi piece after the 2^6 pre-scale: OR 1 into the launch's flag word
     using I = A32Img<D, DV>;
     constexpr int KROW = I::KROW, VROW = I::VROW;
     __shared__ __attribute__((aligned(16))) char s[I::TILE];
@@ -368,11 +370,16 @@ __global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__
     char* km_s = s + 2 * 32 * KROW;
     char* vh_s = s + I::KIMGP;
     char* vl_s = vh_s + DV * VROW;
+    bool bad = false;
     for (int c = tid; c < 32 * (D / 4); c += 256) {
         const int r = c / (D / 4), d4 = c % (D / 4);
         const int key = t * 32 + r;
         floatx4 val = {0.f, 0.f, 0.f, 0.f};
-        if (key < Lk) val = *reinterpret_cast<const floatx4*>(kb + (int64_t)key * D + d4 * 4) * 64.f;
+        if (key < Lk) {
+            const floatx4 raw = *reinterpret_cast<const floatx4*>(kb + (int64_t)key * D + d4 * 4);
+            bad |= !(fabsf(raw[0]) < 1000.f) || !(fabsf(raw[1]) < 1000.f) || !(fabsf(raw[2]) < 1000.f) || !(fabsf(raw[3]) < 1000.f);
+            val = raw * 64.f;
+        }
         half4_t h4, l4, m4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -389,7 +396,9 @@ __global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__
     for (int c = tid; c < 32 * DV; c += 256) {
         const int r = c / DV, d = c % DV;
         const int key = t * 32 + r;
-        const float val = (key < Lk && d < dv_real) ? vb[(int64_t)key * dv_real + d] * 64.f : 0.f;
+        const float vraw = (key < Lk && d < dv_real) ? vb[(int64_t)key * dv_real + d] : 0.f;
+        bad |= !(fabsf(vraw) < 1000.f);
+        const float val = vraw * 64.f;
         const int pos = (r >> 4) * 16 + ((r >> 2) & 1) * 8 + ((r >> 3) & 1) * 4 + (r & 3);
         const half_t hh = (half_t)val;
         *reinterpret_cast<half_t*>(vh_s + d * VROW + pos * 2) = hh;
@@ -398,6 +407,7 @@ __global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__
     __syncthreads();
     uint4* dst = reinterpret_cast<uint4*>(img + ((int64_t)b * nT + t) * I::TILE);
     for (int i = tid; i < I::TILE / 16; i += 256) dst[i] = reinterpret_cast<const uint4*>(s)[i];
+    if (flag && __any(bad) && (tid & 63) == 0) atomicOr(flag, 1);
 }
 
 template <int N_>
@@ -423,7 +433,8 @@ template <int D, int DV, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_f32p_kernel(const float* __restrict__ q,
                                                                               const char* __restrict__ img,
                                                                               float* __restrict__ out, int Lq, int Lk,
-                                                                              int dv_real, float scale_log2) {
+                                                                              int dv_real, float scale_log2,
+                                                                              int* __restrict__ flag) {
     using I = A32Img<D, DV>;
     constexpr int KROW = I::KROW, VROW = I::VROW;
     constexpr int NDB = DV / 32, NKS = D / 16;
@@ -458,11 +469,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_f32p_kernel(con
     stage(0);
 
     half8_t qh[NKS], ql[NKS], qm[NKS];
+    bool qbad = false;
+    const float qlim = 1000.f / scale_log2;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const floatx4 a = *reinterpret_cast<const floatx4*>(qp + ks * 16);
         const floatx4 c = *reinterpret_cast<const floatx4*>(qp + ks * 16 + 4);
         const float sq = scale_log2 * 64.f;
+        // the guarded entry's test |q scale log2 e| < 1000, on the RAW values: a second use of the products below would change
+        // which of them hipcc contracts into FMAs, and with it the last bit of the pieces (attn_f32s_kernel must get the same)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qbad |= !(fabsf(a[e]) < qlim) || !(fabsf(c[e]) < qlim);
         const float x[8] = {a[0] * sq, a[1] * sq, a[2] * sq, a[3] * sq, c[0] * sq, c[1] * sq, c[2] * sq, c[3] * sq};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -473,6 +490,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_f32p_kernel(con
             qm[ks][e] = (half_t)(((x[e] - (float)hh) - (float)ll) * 4096.f);
         }
     }
+    if (flag && __any(qbad) && lane == 0) atomicOr(flag, 1);
     floatx16 o[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -573,10 +591,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_f32p_kernel(con
 
 template <int D, int DV>
 static int launch_attn32p(const float* q, const float* k, const float* v, float* out, char* img, int B, int Lq, int Lk, int dv,
-                          float scale, hipStream_t st) {
+                          float scale, hipStream_t st, int* flag = nullptr) {
     ProfScope ps(FRESCO_PROF_ATTN_F32, B, Lq, Lk, D, st);
     const int nT = (Lk + 31) / 32;
-    hipLaunchKernelGGL((kv_split_kernel<D, DV>), dim3(nT, B), dim3(256), 0, st, k, v, img, Lk, dv);
+    hipLaunchKernelGGL((kv_split_kernel<D, DV>), dim3(nT, B), dim3(256), 0, st, k, v, img, Lk, dv, flag);
     using I = A32Img<D, DV>;
     const int lds = 2 * I::TILE;
     // 256-query workgroups (8 waves: one image stream per 256 queries) when they alone fill the chip and the tile's pieces
@@ -588,13 +606,13 @@ static int launch_attn32p(const float* q, const float* k, const float* v, float*
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32p_kernel<D, DV, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipLaunchKernelGGL((attn_f32p_kernel<D, DV, 8>), dim3((unsigned)wg8), dim3(512), lds, st, q, img, out, Lq, Lk, dv,
-                               scale * 1.4426950408889634f);
+                               scale * 1.4426950408889634f, flag);
         }
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32p_kernel<D, DV, 4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((attn_f32p_kernel<D, DV, 4>), dim3(((Lq + 127) / 128) * B), dim3(256), lds, st, q, img, out, Lq, Lk,
-                           dv, scale * 1.4426950408889634f);
+                           dv, scale * 1.4426950408889634f, flag);
     }
     return check_launch();
 }
@@ -742,5 +760,43 @@ extern "C" int fresco_attn_f32_guarded(const float* q, const float* k, const flo
     FRESCO_A32G(64)
     FRESCO_A32G(128)
 #undef FRESCO_A32G
+    return FRESCO_EUNSUPPORTED;
+}
+
+// ---- guarded workspace form WITHOUT the range pass and the flag memset (round 6: 20 us of short launches around every one of
+// the flow network's 26 attention calls).  `zero_flag` = one int32 of device memory that the CALLER guarantees to be zero in
+// stream order when the call is issued and that nobody else touches until the call's kernels are done (fresco_amd.ops hands out
+// the words of a zero-filled pool, each once).  The k / v range test runs inside the split pass (which reads them anyway), the
+// q test in the attention kernel's Q prologue; the exact-fp32 kernel behind them returns at once unless one of them raised
+// the flag.  Same results as fresco_attn_f32_guarded with a workspace, bit for bit, in range and out of range.
+extern "C" int fresco_attn_f32_guarded_ws(const float* q, const float* k, const float* v, float* out, void* workspace,
+                                          size_t workspace_bytes, int* zero_flag, int B, int Lq, int Lk, int D, int Dv,
+                                          float scale, void* stream) {
+    if (!zero_flag || !workspace) return FRESCO_EINVAL;
+    if (!q || !k || !v || !out || B <= 0 || Lq <= 0 || Lk <= 0 || D <= 0 || Dv <= 0 || !(scale > 0.f)) return FRESCO_EINVAL;
+    if (B > 65535) return FRESCO_EUNSUPPORTED;
+    const size_t need = fresco_attn_f32_workspace_bytes(B, Lk, D, Dv);
+    if (need == 0) return FRESCO_EUNSUPPORTED;
+    if (workspace_bytes < need) return FRESCO_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    char* img = static_cast<char*>(workspace);
+#define FRESCO_A32GW(DD)                                                                                                  \
+    if (D == DD) {                                                                                                        \
+        int rc;                                                                                                           \
+        if (Dv <= 32) {                                                                                                   \
+            rc = launch_attn32p<DD, 32>(q, k, v, out, img, B, Lq, Lk, Dv, scale, st, zero_flag);                          \
+            return rc != FRESCO_OK ? rc : launch_attn32_fallback<DD, 32>(q, k, v, out, B, Lq, Lk, Dv, scale, zero_flag, st);   \
+        }                                                                                                                 \
+        if (Dv <= 64) {                                                                                                   \
+            rc = launch_attn32p<DD, 64>(q, k, v, out, img, B, Lq, Lk, Dv, scale, st, zero_flag);                          \
+            return rc != FRESCO_OK ? rc : launch_attn32_fallback<DD, 64>(q, k, v, out, B, Lq, Lk, Dv, scale, zero_flag, st);   \
+        }                                                                                                                 \
+        rc = launch_attn32p<DD, 128>(q, k, v, out, img, B, Lq, Lk, Dv, scale, st, zero_flag);                             \
+        return rc != FRESCO_OK ? rc : launch_attn32_fallback<DD, 128>(q, k, v, out, B, Lq, Lk, Dv, scale, zero_flag, st);      \
+    }
+    FRESCO_A32GW(32)
+    FRESCO_A32GW(64)
+    FRESCO_A32GW(128)
+#undef FRESCO_A32GW
     return FRESCO_EUNSUPPORTED;
 }

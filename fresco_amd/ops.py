@@ -315,12 +315,42 @@ def attention_f32(q, k, v, scale):
     out = torch.empty(B, Lq, Dv, dtype=torch.float32, device=q.device)
     lib = _lib.load()
     need = lib.fresco_attn_f32_workspace_bytes(B, Lk, D, Dv) if Lq >= 256 else 0
-    ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need else None
+    if need:
+        # workspace form: the range tests ride in the split pass and the attention prologue; the flag is a word of a
+        # zero-filled pool, handed out once (no memset, no range pass: 20 us of short launches per call, round 6)
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+        rc = lib.fresco_attn_f32_guarded_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), ws.data_ptr(), need,
+                                            _a32_zero_flag(q.device), B, Lq, Lk, D, Dv, float(scale), _stream())
+        _lib.check(rc, "fresco_attn_f32_guarded_ws(B=%d,Lq=%d,Lk=%d,D=%d,Dv=%d)" % (B, Lq, Lk, D, Dv))
+        return out
     flag = torch.empty(1, dtype=torch.int32, device=q.device)
-    rc = lib.fresco_attn_f32_guarded(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(ws), need,
+    rc = lib.fresco_attn_f32_guarded(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), None, 0,
                                      flag.data_ptr(), B, Lq, Lk, D, Dv, float(scale), _stream())
     _lib.check(rc, "fresco_attn_f32_guarded(B=%d,Lq=%d,Lk=%d,D=%d,Dv=%d)" % (B, Lq, Lk, D, Dv))
     return out
+
+
+_A32_POOL_WORDS = 4096
+_a32_pools = None  # a threading.local with a dict keyed by (device index, stream), made on first use
+
+
+def _a32_zero_flag(device):
+    """address of an int32 that is zero in the current stream's order and has never been handed out: word i of a pool that
+    torch.zeros created ON THIS STREAM (one fill per 4096 calls).  A pool that runs out is dropped: its memory goes back to
+    the caching allocator, which re-issues it in this stream's order (the kernels that still read its words come first)."""
+    global _a32_pools
+    if _a32_pools is None:
+        _a32_pools = _threading.local()
+    pools = getattr(_a32_pools, "d", None)
+    if pools is None:
+        pools = _a32_pools.d = {}
+    key = (device.index, _stream())
+    ent = pools.get(key)
+    if ent is None or ent[1] >= _A32_POOL_WORDS:
+        ent = pools[key] = [torch.zeros(_A32_POOL_WORDS, dtype=torch.int32, device=device), 0]
+    ptr = ent[0].data_ptr() + 4 * ent[1]
+    ent[1] += 1
+    return ptr
 
 
 # ---- the flow network's dense layers (csrc/flownet.hip): fp32 tensors in NHWC / token layout, products on the fp16 matrix

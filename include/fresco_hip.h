@@ -240,6 +240,16 @@ int fresco_attn_f32_guarded(const float* q, const float* k, const float* v, floa
                             size_t workspace_bytes, int* flag, int B, int Lq, int Lk, int D, int Dv, float scale,
                             void* stream);
 
+/* The guarded workspace form without the separate range pass and flag memset (round 6): the k / v range test runs inside the
+ * split pass, the q test inside the attention kernel's prologue.  zero_flag: one int32 of device memory that the CALLER
+ * guarantees to be ZERO in stream order when the call is issued, and untouched by anyone else until the call's kernels are
+ * done (fresco_amd.ops hands out the words of a zero-filled pool, each once).  workspace as fresco_attn_f32_ws (not NULL).
+ * Results: fresco_attn_f32_guarded's with a workspace, bit for bit, in range and out of range.  fresco_amd.ops.attention_f32
+ * uses it whenever it takes the workspace form (Lq >= 256: every attention call of the flow network). */
+int fresco_attn_f32_guarded_ws(const float* q, const float* k, const float* v, float* out, void* workspace,
+                               size_t workspace_bytes, int* zero_flag, int B, int Lq, int Lk, int D, int Dv, float scale,
+                               void* stream);
+
 /* ---- the flow network's dense layers (f3): GMFlow's CNN encoder, transformer projections / FFN / LayerNorms, upsampler head
  * (gmflow/backbone.py:7-117, transformer.py:111-237, gmflow.py:44-90).  fp32 in, fp32 out, fp32-class accuracy on the fp16
  * matrix pipe: a tensor that feeds a product exists as a pair of fp16 planes (hi, lo), x = hi + lo to 2^-22, written by its
