@@ -317,30 +317,54 @@ def _group_rows(groups, B, L, device):
     return torch.cat(parts).to(torch.int32).contiguous(), spans
 
 
-def _layer_native(layer, wts, src, src_s, tgt_s, grows):
+def _cat_planes(M, C, device):
+    """(hi, lo) operand planes as the LEFT halves of two (M, 2C) buffers: a layer's output planes are born where the next
+    layer's FFN wants them -- mlp(cat(source, norm1(merge))) fills the right halves and reads the buffers whole (round 6:
+    the two copies per layer that built the concatenation are gone)"""
+    ch = torch.empty(M, 2 * C, dtype=torch.float16, device=device)
+    cl = torch.empty(M, 2 * C, dtype=torch.float16, device=device)
+    return ch, cl
+
+
+def _cat_base(planes, C):
+    """the (M, 2C) buffers whose left halves `planes` are (see _cat_planes), or None"""
+    bases = []
+    for t in planes:
+        b = t._base
+        if b is None or b.dim() != 2 or tuple(b.shape) != (t.shape[0], 2 * C) or not b.is_contiguous() \
+                or b.data_ptr() != t.data_ptr() or t.stride(0) != 2 * C:
+            return None
+        bases.append(b)
+    return tuple(bases)
+
+
+def _layer_native(layer, wts, src, src_s, tgt_s, grows, tgt_table=None):
     """TransformerLayer.forward on token rows: src (B, L, C) fp32, src_s / tgt_s planes (B L, C) -> (out fp32, planes).
     The window grouping costs nothing: the q / k / v projections READ their rows through the group-major table (their
     outputs are the attention problems, contiguous per size class) and the merge projection WRITES its rows back through
     it -- no gather / scatter passes over the tokens (PyTorch index kernels: 1.5 ms of the forward before)."""
     B, L, C = src.shape
     table, spans = grows
+    # tgt_table (cross-attention): the k / v projections read the OTHER image's rows of tgt_s through it -- the swap of the two
+    # image groups (transformer.py:279-288) is a row table, not two concatenation kernels per block (round 6)
+    ktable = table if tgt_table is None else tgt_table
     lin = lambda p: wts.get(p.weight, "lin")
     # q | k | v of one source (self-attention) as ONE product with three output matrices, k | v of the other image's tokens
     # (cross-attention) as one with two: the operand rows are read once instead of three / two times (round 6)
     fuse = os.environ.get("FRESCO_GMFLOW_FUSE_QKV", "1") != "0"  # (A/B switch)
-    if fuse and src_s is tgt_s:
+    if fuse and src_s is tgt_s and tgt_table is None:
         qkv, _ = ops.fn_gemm(src_s, wts.get_stacked((layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight)), 3 * C, C,
                              a_rows=table, out_blocks=3)
         q, k, v = qkv[0], qkv[1], qkv[2]
     elif fuse:
         q, _ = ops.fn_gemm(src_s, lin(layer.q_proj), C, C, a_rows=table)
-        kv, _ = ops.fn_gemm(tgt_s, wts.get_stacked((layer.k_proj.weight, layer.v_proj.weight)), 2 * C, C, a_rows=table,
+        kv, _ = ops.fn_gemm(tgt_s, wts.get_stacked((layer.k_proj.weight, layer.v_proj.weight)), 2 * C, C, a_rows=ktable,
                             out_blocks=2)
         k, v = kv[0], kv[1]
     else:
         q, _ = ops.fn_gemm(src_s, lin(layer.q_proj), C, C, a_rows=table)
-        k, _ = ops.fn_gemm(tgt_s, lin(layer.k_proj), C, C, a_rows=table)
-        v, _ = ops.fn_gemm(tgt_s, lin(layer.v_proj), C, C, a_rows=table)
+        k, _ = ops.fn_gemm(tgt_s, lin(layer.k_proj), C, C, a_rows=ktable)
+        v, _ = ops.fn_gemm(tgt_s, lin(layer.v_proj), C, C, a_rows=ktable)
     scale = 1.0 / math.sqrt(C)
     outs_ = []
     for off, G, n in spans:
@@ -352,23 +376,32 @@ def _layer_native(layer, wts, src, src_s, tgt_s, grows):
     mg = torch.empty(B * L, C, dtype=torch.float32, device=src.device)
     ops.fn_gemm(ms, lin(layer.merge), C, C, out_rows=table, out_f32=mg)
     src2 = src.view(B * L, C)
-    if layer.no_ffn:
-        out, outs = ops.fn_layernorm(mg, layer.norm1.weight, layer.norm1.bias, residual=src2, eps=layer.norm1.eps,
-                                     want_split=True)
-        return out.view(B, L, C), outs
-    # mlp(cat(source, norm1(merge))): the LayerNorm writes its planes into the right half of the concatenated operand
     dev = src.device
-    ch = torch.empty(B * L, 2 * C, dtype=torch.float16, device=dev)
-    cl = torch.empty(B * L, 2 * C, dtype=torch.float16, device=dev)
-    ch[:, :C].copy_(src_s[0])
-    cl[:, :C].copy_(src_s[1])
+    if layer.no_ffn:
+        oh, ol = _cat_planes(B * L, C, dev)
+        outs = (oh[:, :C], ol[:, :C])
+        out, _ = ops.fn_layernorm(mg, layer.norm1.weight, layer.norm1.bias, residual=src2, eps=layer.norm1.eps,
+                                  out_split=outs + (2 * C,))
+        return out.view(B, L, C), outs
+    # mlp(cat(source, norm1(merge))): the LayerNorm writes its planes into the right half of the concatenated operand, whose
+    # left half the source's planes already are when the layer before made them (_cat_planes)
+    base = _cat_base(src_s, C)
+    if base is not None:
+        ch, cl = base
+    else:
+        ch, cl = _cat_planes(B * L, C, dev)
+        ch[:, :C].copy_(src_s[0])
+        cl[:, :C].copy_(src_s[1])
     ops.fn_layernorm(mg, layer.norm1.weight, layer.norm1.bias, eps=layer.norm1.eps, want_f32=False,
                      out_split=(ch[:, C:], cl[:, C:], 2 * C))
     w1, w2 = lin(layer.mlp[0]), lin(layer.mlp[2])
     hid = layer.mlp[0].out_features
     _, hs = ops.fn_gemm((ch, cl), w1, hid, 2 * C, act=2, want_f32=False, want_split=True)
     o2, _ = ops.fn_gemm(hs, w2, C, hid)
-    out, outs = ops.fn_layernorm(o2, layer.norm2.weight, layer.norm2.bias, residual=src2, eps=layer.norm2.eps, want_split=True)
+    oh, ol = _cat_planes(B * L, C, dev)
+    outs = (oh[:, :C], ol[:, :C])
+    out, _ = ops.fn_layernorm(o2, layer.norm2.weight, layer.norm2.bias, residual=src2, eps=layer.norm2.eps,
+                              out_split=outs + (2 * C,))
     return out.view(B, L, C), outs
 
 
@@ -377,17 +410,19 @@ def _transformer_native(tr, wts, tok, b, h, w, splits):
     x = tok
     _, xs = ops.fn_prep(x.reshape(-1, x.shape[-1]))
     L, C = x.shape[1], x.shape[2]
-    swap = lambda t: torch.cat((t.view(2, b * L, C)[1], t.view(2, b * L, C)[0]), 0)
     B = x.shape[0]
     for i, blk in enumerate(tr.layers):
         shifted = splits > 1 and i % 2 == 1
         key = ("rows", h, w, splits, shifted, B, str(x.device))
         if key not in tr._groups:
-            tr._groups[key] = _group_rows(tr._get_groups(h, w, splits, shifted, x.device), B, L, x.device)
-        grows = tr._groups[key]
-        ys = (swap(xs[0]), swap(xs[1]))  # the other image's tokens BEFORE this block (transformer.py:279-288)
+            grows = _group_rows(tr._get_groups(h, w, splits, shifted, x.device), B, L, x.device)
+            # the same positions in the OTHER image group: row r of swap(t) = cat(t[b L:], t[:b L]) is row (r + b L) mod 2 b L of t
+            swapped = ((grows[0].long() + b * L) % (2 * b * L)).to(torch.int32).contiguous()
+            tr._groups[key] = (grows, swapped)
+        grows, swapped = tr._groups[key]
+        xs_before = xs  # the other image's tokens BEFORE this block (transformer.py:279-288), read through `swapped`
         x, xs = _layer_native(blk.self_attn, wts, x, xs, xs, grows)
-        x, xs = _layer_native(blk.cross_attn_ffn, wts, x, xs, ys, grows)
+        x, xs = _layer_native(blk.cross_attn_ffn, wts, x, xs, xs_before, grows, tgt_table=swapped)
     return x, xs
 
 
