@@ -337,7 +337,10 @@ _a32_pools = None  # a threading.local with a dict keyed by (device index, strea
 def _a32_zero_flag(device):
     """address of an int32 that is zero in the current stream's order and has never been handed out: word i of a pool that
     torch.zeros created ON THIS STREAM (one fill per 4096 calls).  A pool that runs out is dropped: its memory goes back to
-    the caching allocator, which re-issues it in this stream's order (the kernels that still read its words come first)."""
+    the caching allocator, which re-issues it in this stream's order (the kernels that still read its words come first).
+    Under stream capture a word is handed out once per CAPTURE and read by every replay: a replay whose operands left the
+    range leaves it set, and later replays of that graph take the exact-fp32 kernel as well (correct, slower) -- the flow
+    network is not captured anywhere in this package."""
     global _a32_pools
     if _a32_pools is None:
         _a32_pools = _threading.local()
